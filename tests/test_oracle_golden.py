@@ -1,0 +1,262 @@
+"""The CPU oracle (oracle/ref_cpu.py) against golden vectors captured from the reference
+(tools/gen_golden.py). These pin the oracle; the GPU tests then compare the HIP path with the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import philox, ref_cpu as R
+from oracle.weights import make_param, make_state_dict, unet_param_shapes
+from conftest import load_golden
+
+torch.set_num_threads(8)
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def close(a, b, atol, rtol=0.0):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = np.abs(a.astype(np.float64) - b.astype(np.float64))
+    tol = atol + rtol * np.abs(b)
+    assert (err <= tol).all(), f"max err {err.max():.3e} (tol {atol:g}+{rtol:g}*|ref|)"
+
+
+def named(prefix, shapes):
+    return {k: T(make_param(prefix + k, s)) for k, s in shapes.items()}
+
+
+def test_schedules_match_reference():
+    g = load_golden("schedules")
+    for sched in ("cosine", "linear", "quadratic", "sigmoid"):
+        for Tn in (10, 1000):
+            c = R.ddpm_constants(Tn, sched)
+            for n in R.CONSTANT_NAMES:
+                np.testing.assert_array_equal(c[n].numpy(), g[f"{sched}_{Tn}_{n}"], err_msg=f"{sched} {Tn} {n}")
+    c = R.ddpm_constants(50, "linear", beta_start=0.001, beta_end=0.05)
+    for n in R.CONSTANT_NAMES:
+        np.testing.assert_array_equal(c[n].numpy(), g[f"linearcfg_50_{n}"])
+
+
+def _rb_shapes(cin, cout, with_t):
+    s = {}
+    if with_t:
+        s["mlp.1.weight"], s["mlp.1.bias"] = (cout, 128), (cout,)
+    for b, ci in (("block1", cin), ("block2", cout)):
+        s[f"{b}.proj.weight"], s[f"{b}.proj.bias"] = (cout, ci, 3, 3), (cout,)
+        s[f"{b}.norm.weight"], s[f"{b}.norm.bias"] = (cout,), (cout,)
+    if cin != cout:
+        s["res_conv.weight"], s["res_conv.bias"] = (cout, cin, 1, 1), (cout,)
+    return s
+
+
+@pytest.mark.parametrize("tag,cin,cout,groups,with_t", [
+    ("rb_32_32", 32, 32, 8, True), ("rb_32_64", 32, 64, 8, True),
+    ("rb_64_32_g4", 64, 32, 4, True), ("rb_32_32_not", 32, 32, 8, False)])
+def test_resnet_block(tag, cin, cout, groups, with_t):
+    g = load_golden("blocks")
+    p = {"rb." + k: v for k, v in named(tag + ".", _rb_shapes(cin, cout, with_t)).items()}
+    y = R.resnet_block(p, "rb", T(g[tag + "_x"]), T(g["temb"]) if with_t else None, groups)
+    close(y, g[tag + "_y"], 2e-6, 1e-5)
+
+
+def test_block():
+    g = load_golden("blocks")
+    p = {"b." + k: v for k, v in named("blk.", {"proj.weight": (64, 32, 3, 3), "proj.bias": (64,),
+                                                 "norm.weight": (64,), "norm.bias": (64,)}).items()}
+    close(R.block(p, "b", T(g["blk_x"]), 8), g["blk_y"], 2e-6, 1e-5)
+
+
+@pytest.mark.parametrize("tag,c", [("la_32", 32), ("la_64", 64)])
+def test_linear_attention(tag, c):
+    g = load_golden("blocks")
+    shapes = {"fn.norm.weight": (c,), "fn.norm.bias": (c,), "fn.fn.to_qkv.weight": (384, c, 1, 1),
+              "fn.fn.to_out.0.weight": (c, 128, 1, 1), "fn.fn.to_out.0.bias": (c,),
+              "fn.fn.to_out.1.weight": (c,), "fn.fn.to_out.1.bias": (c,)}
+    p = {"a." + k: v for k, v in named(tag + ".", shapes).items()}
+    x = T(g[tag + "_x"])
+    close(R.linear_attention(p, "a.fn.fn", x), g[tag + "_bare_y"], 2e-6, 1e-5)
+    close(R.prenorm_residual(p, "a", x, R.linear_attention), g[tag + "_y"], 2e-6, 1e-5)
+
+
+@pytest.mark.parametrize("tag,c", [("at_64_4", 64), ("at_256_8", 256)])
+def test_attention(tag, c):
+    g = load_golden("blocks")
+    shapes = {"fn.norm.weight": (c,), "fn.norm.bias": (c,), "fn.fn.to_qkv.weight": (384, c, 1, 1),
+              "fn.fn.to_out.weight": (c, 128, 1, 1), "fn.fn.to_out.bias": (c,)}
+    p = {"a." + k: v for k, v in named(tag + ".", shapes).items()}
+    x = T(g[tag + "_x"])
+    close(R.attention(p, "a.fn.fn", x), g[tag + "_bare_y"], 2e-6, 1e-5)
+    close(R.prenorm_residual(p, "a", x, R.attention), g[tag + "_y"], 2e-6, 1e-5)
+
+
+def test_down_up_sinusoid():
+    import torch.nn.functional as F
+    g = load_golden("blocks")
+    w, b = T(make_param("down.weight", (32, 32, 4, 4))), T(make_param("down.bias", (32,)))
+    close(F.conv2d(T(g["down_x"]), w, b, stride=2, padding=1), g["down_y"], 2e-6, 1e-5)
+    w, b = T(make_param("ups.9.3.weight", (32, 32, 4, 4))), T(make_param("ups.9.3.bias", (32,)))
+    close(F.conv_transpose2d(T(g["up_x"]), w, b, stride=2, padding=1), g["up_y"], 2e-6, 1e-5)
+    close(R.sinusoidal_embedding(T(g["pe_t_long"]), 32), g["pe_long"], 0, 0)
+    close(R.sinusoidal_embedding(T(g["pe_t_float"]), 32), g["pe_float"], 0, 0)
+
+
+@pytest.mark.parametrize("tag,lv,groups,order", [
+    ("ddpm", False, 8, "bn_act_conv"), ("improved", True, 8, "bn_act_conv"),
+    ("sde_g4", False, 4, "bn_act_conv"), ("convbnact", False, 8, "conv_bn_act")])
+def test_unet_forward(tag, lv, groups, order):
+    g = load_golden("unet")
+    p = R.to_torch(make_state_dict(unet_param_shapes(learned_variance=lv, resnet_block_order=order)))
+    x = T(g["x"])
+    for t in (0, 500, 999):
+        y = R.unet_forward(p, x, torch.full((2,), t, dtype=torch.long), groups=groups)
+        close(y, g[f"{tag}_t{t}"], 1e-5, 1e-5)
+    close(R.unet_forward(p, x, torch.tensor([3, 977]), groups=groups), g[f"{tag}_tmixed"], 1e-5, 1e-5)
+    close(R.unet_forward(p, x, T(g["t_float"]), groups=groups), g[f"{tag}_tfloat"], 1e-5, 1e-5)
+
+
+def test_unet_forward_64():
+    g = load_golden("unet")
+    p = R.to_torch(make_state_dict(unet_param_shapes()))
+    close(R.unet_forward(p, T(g["x64"]), torch.tensor([250])), g["ddpm64_t250"], 1e-5, 1e-5)
+
+
+def test_p_sample_updates():
+    g = load_golden("p_sample")
+    x, eps, eps6, z = (T(g[k]) for k in ("x", "eps", "eps6", "z"))
+    for sched in ("cosine", "linear"):
+        c = R.ddpm_constants(1000, sched)
+        for tt in ([999, 999, 999], [1, 1, 1], [0, 0, 0], [0, 17, 640]):
+            t = torch.tensor(tt)
+            tag = f"{sched}_t{'_'.join(map(str, tt))}"
+            close(R.p_sample_update(c, x, t, eps, z), g["fixed_" + tag], 1e-6, 1e-6)
+            close(R.p_sample_update(c, x, t, eps6, z, learned_variance=True), g["learned_" + tag], 1e-6, 1e-6)
+        close(R.q_sample(c, x, torch.tensor([0, 499, 999]), z), g[f"qsample_{sched}"], 1e-7, 1e-6)
+    c = R.ddpm_constants(1000, "cosine")
+    close(R.p_sample_update(c, x, torch.tensor([5, 50, 500]), eps, z, objective="pred_x0"),
+          g["predx0_cosine"], 1e-6, 1e-6)
+
+
+def test_sde_units():
+    g = load_golden("sde_units")
+    ve, vp = R.VESDE(0.01, 50.0, 1000), R.VPSDE(0.1, 20.0, 1000)
+    np.testing.assert_array_equal(ve.discrete_sigmas.numpy(), g["ve_discrete_sigmas"])
+    np.testing.assert_array_equal(vp.betas.numpy(), g["vp_betas"])
+    np.testing.assert_array_equal(vp.sqrt_1m_alphas_cumprod.numpy(), g["vp_sqrt_1m_alphas_cumprod"])
+    tt, xx = T(g["tt"]), T(g["xx"])
+    for name, sde in (("ve", ve), ("vp", vp)):
+        d, gg = sde.sde(xx, tt)
+        m, s = sde.marginal_prob(xx, tt)
+        f, G = sde.discretize(xx, tt)
+        for k, v in (("drift", d), ("diffusion", gg), ("mean", m), ("std", s), ("f", f), ("G", G)):
+            close(v, g[f"{name}_{k}"], 1e-7, 1e-6)
+    x, z, z2, score, t = (T(g[k]) for k in ("x", "z", "z2", "score", "t"))
+    sfn = lambda a, b: score.clone()  # noqa: E731
+    for sname, sde in (("ve", ve), ("vp", vp)):
+        for pname in ("euler_maruyama", "reverse_diffusion", "ancestral_sampling"):
+            if sname == "vp" and pname == "ancestral_sampling":
+                with pytest.raises(NotImplementedError):
+                    R.predictor_step(pname, sde, sfn, x, t, z)
+                continue
+            xo, xm = R.predictor_step(pname, sde, sfn, x, t, z)
+            close(xo, g[f"{sname}_{pname}_x"], 1e-6, 1e-6)
+            close(xm, g[f"{sname}_{pname}_mean"], 1e-6, 1e-6)
+        for cname in ("langevin", "ald"):
+            zs = [z, z2]
+            xo, xm = R.corrector_step(cname, sde, sfn, x, t, lambda k: zs[k], 0.16, 2)
+            close(xo, g[f"{sname}_{cname}_x"], 1e-6, 2e-6)
+            close(xm, g[f"{sname}_{cname}_mean"], 1e-6, 2e-6)
+
+
+def test_score_function_adapters():
+    g = load_golden("sde_units")
+    p = R.to_torch(make_state_dict(unet_param_shapes()))
+    model = lambda x, t: R.unet_forward(p, x, t, groups=4)  # noqa: E731
+    x32, t = T(g["x32"]), T(g["t"])
+    for sname, sde in (("ve", R.VESDE(0.01, 50.0, 1000)), ("vp", R.VPSDE(0.1, 20.0, 1000))):
+        for cont in (True, False):
+            s = R.score_fn_for(sde, model, cont)(x32, t.clone())
+            ref = g[f"score_{sname}_{'cont' if cont else 'disc'}"]
+            close(s, ref, 2e-5 * max(1.0, float(np.abs(ref).max())), 1e-5)
+
+
+@pytest.mark.parametrize("tag,kind,pred,corr,n_steps", [
+    ("ve_rd_langevin", "ve", "reverse_diffusion", "langevin", 1),
+    ("ve_em_none", "ve", "euler_maruyama", None, 1),
+    ("vp_em_none", "vp", "euler_maruyama", None, 1),
+    ("vp_rd_langevin2", "vp", "reverse_diffusion", "langevin", 2),
+    ("ve_anc_ald", "ve", "ancestral_sampling", "ald", 1)])
+def test_pc_chain_20(tag, kind, pred, corr, n_steps):
+    g = load_golden("chain_sde_N20_B2_32")
+    N, shape, seed = 20, (2, 3, 32, 32), 5
+    sde = R.VESDE(0.01, 50.0, N) if kind == "ve" else R.VPSDE(0.1, 20.0, N)
+    p = R.to_torch(make_state_dict(unet_param_shapes()))
+    model = lambda x, t: R.unet_forward(p, x, t, groups=4)  # noqa: E731
+    noise = lambda step, stream: T(philox.normal_like(shape, seed, step, stream))  # noqa: E731
+    with torch.no_grad():
+        out = R.pc_sample_chain(model, sde, shape, noise, pred, corr, 0.16, n_steps, keep=(0, 9, 19))
+    for i in (0, 9, 19):
+        ref = g[f"{tag}_mean_{i}"]
+        scale = max(1.0, float(np.abs(ref).max()))
+        close(out[i], ref, 5e-5 * scale, 0)
+    assert int(g[f"{tag}_nfe"]) == N * (n_steps + 1)
+
+
+def test_training_step_loss_and_grads():
+    g = load_golden("train_step")
+    p = R.to_torch(make_state_dict(unet_param_shapes()))
+    for v in p.values():
+        v.requires_grad_(True)
+    c = R.ddpm_constants(1000, "cosine")
+    x0, noise, t = T(g["x0"]), T(g["noise"]), T(g["t"])
+    close(R.q_sample(c, x0, t, noise), g["x_t"], 1e-7, 1e-6)
+    loss = R.ddpm_training_loss(lambda x, tt: R.unet_forward(p, x, tt), c, x0, t, noise)
+    loss.backward()
+    close(loss, g["loss"], 1e-6, 1e-5)
+    gn = torch.sqrt(sum((v.grad.double() ** 2).sum() for v in p.values())).float()
+    close(gn, g["grad_norm"], 1e-5, 1e-4)
+    close(p["init_conv.bias"].grad, g["grad_init_conv_bias"], 1e-6, 1e-4)
+    close(p["final_conv.3.bias"].grad, g["grad_final_bias"], 1e-6, 1e-4)
+
+
+def test_ddpm_chain_1000_steps():
+    """Full 1000-step ancestral chain, B=2 @ 32x32, against the reference's own run."""
+    g = load_golden("chain_ddpm_T1000_B2_32")
+    T_, shape, seed = 1000, (2, 3, 32, 32), 0
+    p = R.to_torch(make_state_dict(unet_param_shapes()))
+    c = R.ddpm_constants(T_, "cosine")
+    noise = lambda step: T(philox.normal_like(shape, seed, step, 0 if step == T_ else 1))  # noqa: E731
+    with torch.no_grad():
+        out = R.ddpm_sample_chain(lambda x, t: R.unet_forward(p, x, t), c, shape, noise, keep=(999, 900, 500, 100, 0))
+    np.testing.assert_array_equal(out["x_T"].numpy(), g["x_T"])
+    for i in (999, 900, 500, 100, 0):
+        close(out[i], g[f"x_{i}"], 1e-4, 0)
+
+
+def test_improved_chain_100_steps():
+    g = load_golden("chain_improved_T100_B2_32")
+    T_, shape, seed = 100, (2, 3, 32, 32), 1
+    p = R.to_torch(make_state_dict(unet_param_shapes(learned_variance=True)))
+    c = R.ddpm_constants(T_, "cosine")
+    noise = lambda step: T(philox.normal_like(shape, seed, step, 0 if step == T_ else 1))  # noqa: E731
+    with torch.no_grad():
+        out = R.ddpm_sample_chain(lambda x, t: R.unet_forward(p, x, t), c, shape, noise,
+                                  learned_variance=True, keep=(99, 50, 10, 0))
+    for i in (99, 50, 10, 0):
+        close(out[i], g[f"x_{i}"], 1e-4, 0)
+
+
+def test_philox_known_answer_and_shard_invariance():
+    # Known-answer vector of Philox4x32-10 (Random123 kat_vectors: counter = key = 0)
+    r = philox.philox4x32_10(np.uint32(0), np.uint32(0), np.uint32(0), np.uint32(0), 0, 0)
+    assert [int(v) for v in r] == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    r = philox.philox4x32_10(np.uint32(0xFFFFFFFF), np.uint32(0xFFFFFFFF), np.uint32(0xFFFFFFFF),
+                             np.uint32(0xFFFFFFFF), 0xFFFFFFFF, 0xFFFFFFFF)
+    assert [int(v) for v in r] == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    full = philox.normal_like((4, 3, 8, 8), seed=3, step=17, stream=1)
+    part = philox.normal_like((2, 3, 8, 8), seed=3, step=17, stream=1, image_offset=2)
+    np.testing.assert_array_equal(full[2:], part)
+    big = philox.normal_like((64, 3, 32, 32), seed=9, step=1, stream=1)
+    assert abs(float(big.mean())) < 0.01 and abs(float(big.std()) - 1.0) < 0.01
