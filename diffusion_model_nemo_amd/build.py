@@ -1,0 +1,69 @@
+"""Builds libdmn_hip.so (hand-written HIP kernels + C-ABI) for gfx950 with hipcc, in-tree.
+
+``python -m diffusion_model_nemo_amd.build`` or ``build()``; cross-compiles without a GPU.
+Objects are cached under ``csrc/_obj`` and rebuilt when a source or header is newer.
+"""
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libdmn_hip.so")
+SOURCES = ["dmn_conv.hip", "dmn_elem.hip", "dmn_attn.hip", "dmn_sampler.hip", "dmn_unet.cpp", "dmn_api.cpp"]
+ARCH = "gfx950"
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found; the HIP kernels cannot be built")
+    return exe
+
+
+def _newest_header():
+    inc = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    inc.append(os.path.join(os.path.dirname(HERE), "include", "dmn.h"))
+    return max(os.path.getmtime(p) for p in inc)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    hipcc = _hipcc()
+    obj_dir = os.path.join(CSRC, "_obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    os.makedirs(LIB_DIR, exist_ok=True)
+    hdr_time = _newest_header()
+    flags = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+             "-ffp-contract=off"]
+    jobs = []
+    objs = []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        op = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
+        objs.append(op)
+        if force or not os.path.exists(op) or os.path.getmtime(op) < max(os.path.getmtime(sp), hdr_time):
+            cmd = [hipcc, *flags, "-x", "hip", "-c", sp, "-o", op]
+            jobs.append(cmd)
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+        if verbose and r.stderr.strip():
+            print(r.stderr)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+            list(ex.map(run, jobs))
+    if jobs or not os.path.exists(LIB_PATH):
+        run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB_PATH, *objs])
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

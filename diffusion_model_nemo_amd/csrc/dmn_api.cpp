@@ -1,0 +1,283 @@
+// Sampler entry points of the C-ABI (include/dmn.h): single-step updates, the graph-replayed sampling
+// loops, and per-kernel test hooks.
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/dmn.h"
+#include "dmn_kernels.h"
+#include "dmn_sampler.h"
+#include "dmn_unet_internal.h"
+
+static StepCommon step_common(const float* table, const int* step_idx, int row, const float* x, const float* net,
+                              const float* noise, float* x_out, int B, int C, int HW, uint64_t seed, int64_t img_offset,
+                              float* keep) {
+    StepCommon c;
+    memset(&c, 0, sizeof(c));
+    c.x = x;
+    c.net = net;
+    c.x_out = x_out;
+    c.table = table;
+    c.step_idx = step_idx;
+    c.step = row;
+    c.B = B;
+    c.C = C;
+    c.HW = HW;
+    c.seed = seed;
+    c.img_offset = img_offset;
+    c.noise = noise;
+    c.keep = keep;
+    c.keep_stride = (long long)B * C * HW;
+    return c;
+}
+
+extern "C" int dmn_ddpm_step(const float* table, int row, const float* x, const float* model_out, const float* noise,
+                             float* x_out, int B, int C, int H, int W, int learned_variance, int pred_x0, uint64_t seed,
+                             int64_t img_offset, void* stream) {
+    DMN_REQUIRE(table && x && model_out && x_out && row >= 0, DMN_ERR_INVALID, "dmn_ddpm_step: null argument");
+    DdpmStepArgs a;
+    a.c = step_common(table, nullptr, row, x, model_out, noise, x_out, B, C, H * W, seed, img_offset, nullptr);
+    a.learned_variance = learned_variance;
+    a.pred_x0 = pred_x0;
+    return launch_ddpm_step(a, (hipStream_t)stream);
+}
+
+extern "C" int dmn_sde_predictor_step(const float* table, int row, const float* x, const float* model_out,
+                                      const float* noise, float* x_out, float* x_mean, int B, int C, int H, int W,
+                                      uint64_t seed, int64_t img_offset, void* stream) {
+    DMN_REQUIRE(table && x && model_out && x_out && row >= 0, DMN_ERR_INVALID, "dmn_sde_predictor_step: null argument");
+    AffineStepArgs a;
+    a.c = step_common(table, nullptr, row, x, model_out, noise, x_out, B, C, H * W, seed, img_offset, nullptr);
+    a.x_mean = x_mean;
+    a.keep_mean = 0;
+    return launch_affine_step(a, (hipStream_t)stream);
+}
+
+extern "C" size_t dmn_sde_scratch_bytes(int B, int C, int H, int W) {
+    return (size_t)B * langevin_slots(C * H * W) * 2 * sizeof(float) + 256;
+}
+
+extern "C" int dmn_sde_corrector_step(const float* table, int row, const float* x, const float* model_out,
+                                      const float* noise, float* x_out, int B, int C, int H, int W, float snr, int inner,
+                                      int use_norms, uint64_t seed, int64_t img_offset, void* scratch, void* stream) {
+    DMN_REQUIRE(table && x && model_out && x_out && scratch && row >= 0, DMN_ERR_INVALID,
+                "dmn_sde_corrector_step: null argument");
+    LangevinArgs a;
+    memset(&a, 0, sizeof(a));
+    a.c = step_common(table, nullptr, row, x, model_out, noise, x_out, B, C, H * W, seed, img_offset, nullptr);
+    a.partials = (float*)scratch;
+    a.inner = inner;
+    a.use_norms = use_norms;
+    a.snr = snr;
+    return launch_langevin(a, (hipStream_t)stream);
+}
+
+extern "C" int dmn_fill_normal(float* x, int B, int per, uint64_t seed, uint32_t step, int64_t img_offset, float scale,
+                               void* stream) {
+    DMN_REQUIRE(x && B > 0 && per > 0, DMN_ERR_INVALID, "dmn_fill_normal: bad argument");
+    return launch_prior(x, B, per, seed, step, img_offset, scale, (hipStream_t)stream);
+}
+
+// ---- sampling loops ------------------------------------------------------------------------------------
+// Workspace layout: [0,256) control block (step counter), then net output, x_mean, Langevin partials, then the
+// U-Net arena.
+struct LoopBufs {
+    int* step_idx;
+    float* net;
+    float* xmean;
+    float* partials;
+    void* arena;
+    size_t arena_bytes;
+};
+
+static size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+static int carve(const DmnUnet* u, int B, int H, int W, void* ws, size_t ws_bytes, LoopBufs& lb, size_t* need) {
+    const size_t img = (size_t)B * u->cfg.channels * H * W * 4;
+    const size_t net = (size_t)B * u->cfg.out_dim * H * W * 4;
+    size_t unet_bytes = 0;
+    int rc = dmn_unet_workspace_bytes(u, B, H, W, &unet_bytes);
+    if (rc) return rc;
+    size_t off = 256;
+    const size_t o_net = off;
+    off += align256(net);
+    const size_t o_mean = off;
+    off += align256(img);
+    const size_t o_part = off;
+    off += align256(dmn_sde_scratch_bytes(B, u->cfg.channels, H, W));
+    const size_t o_arena = off;
+    off += unet_bytes;
+    if (need) *need = off;
+    if (ws) {
+        DMN_REQUIRE(ws_bytes >= off, DMN_ERR_WORKSPACE, "sampling workspace too small: %zu < %zu", ws_bytes, off);
+        char* b = (char*)ws;
+        lb.step_idx = (int*)b;
+        lb.net = (float*)(b + o_net);
+        lb.xmean = (float*)(b + o_mean);
+        lb.partials = (float*)(b + o_part);
+        lb.arena = b + o_arena;
+        lb.arena_bytes = ws_bytes - o_arena;
+    }
+    return DMN_OK;
+}
+
+extern "C" int dmn_sample_workspace_bytes(const DmnUnet* u, int B, int H, int W, size_t* bytes) {
+    DMN_REQUIRE(u && bytes, DMN_ERR_INVALID, "dmn_sample_workspace_bytes: null argument");
+    LoopBufs lb;
+    return carve(u, B, H, W, nullptr, 0, lb, bytes);
+}
+
+// Runs `body` nsteps times; when allowed, captures it once into a graph (cached on the handle) and replays it.
+template <typename Body>
+static int run_loop(DmnUnet* u, const SampleKey& key, int nsteps, hipStream_t s, int use_graph, Body body) {
+    if (!use_graph || s == nullptr) {
+        for (int i = 0; i < nsteps; ++i) {
+            int rc = body();
+            if (rc) return rc;
+        }
+        return DMN_OK;
+    }
+    if (!(u->graph_exec && u->graph_key == key)) {
+        if (u->graph_exec) {
+            (void)hipGraphExecDestroy(u->graph_exec);
+            u->graph_exec = nullptr;
+        }
+        hipGraph_t graph = nullptr;
+        DMN_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+        int rc = body();
+        hipError_t e = hipStreamEndCapture(s, &graph);
+        if (rc) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return rc;
+        }
+        DMN_HIP_CHECK(e);
+        DMN_HIP_CHECK(hipGraphInstantiate(&u->graph_exec, graph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(graph);
+        u->graph_key = key;
+    }
+    for (int i = 0; i < nsteps; ++i) DMN_HIP_CHECK(hipGraphLaunch(u->graph_exec, s));
+    return DMN_OK;
+}
+
+extern "C" int dmn_ddpm_sample_loop(DmnUnet* u, const float* table, int nsteps, float* x, int B, int H, int W,
+                                    int learned_variance, int pred_x0, int draw_prior, uint64_t seed, int64_t img_offset,
+                                    float* keep, void* workspace, size_t workspace_bytes, void* stream, int use_graph) {
+    DMN_REQUIRE(u && table && x && workspace && nsteps > 0, DMN_ERR_INVALID, "dmn_ddpm_sample_loop: bad argument");
+    DMN_REQUIRE(u->cfg.out_dim == u->cfg.channels * (learned_variance ? 2 : 1), DMN_ERR_INVALID,
+                "network emits %d channels, sampler expects %d", u->cfg.out_dim, u->cfg.channels * (learned_variance ? 2 : 1));
+    hipStream_t s = (hipStream_t)stream;
+    LoopBufs lb;
+    int rc = carve(u, B, H, W, workspace, workspace_bytes, lb, nullptr);
+    if (rc) return rc;
+    const int C = u->cfg.channels;
+    DMN_HIP_CHECK(hipMemsetAsync(lb.step_idx, 0, 256, s));
+    if (draw_prior && (rc = launch_prior(x, B, C * H * W, seed, (unsigned)nsteps, img_offset, 1.0f, s))) return rc;
+    SampleKey key = {x, table, workspace, keep, nullptr, 1, B, H, W, learned_variance | (pred_x0 << 1), nsteps, seed, img_offset, 0.f};
+    auto body = [&]() -> int {
+        int r = unet_forward_impl(u, x, nullptr, 1, table, lb.step_idx, lb.net, B, H, W, lb.arena, lb.arena_bytes, s, false, nullptr);
+        if (r) return r;
+        DdpmStepArgs a;
+        a.c = step_common(table, lb.step_idx, 0, x, lb.net, nullptr, x, B, C, H * W, seed, img_offset, keep);
+        a.learned_variance = learned_variance;
+        a.pred_x0 = pred_x0;
+        if ((r = launch_ddpm_step(a, s))) return r;
+        return launch_advance(lb.step_idx, s);
+    };
+    return run_loop(u, key, nsteps, s, use_graph, body);
+}
+
+extern "C" int dmn_pc_sample_loop(DmnUnet* u, const float* table, int nsteps, float* x, int B, int H, int W, int predictor,
+                                  int corrector, int n_corrector_steps, float snr, int denoise, int draw_prior,
+                                  float prior_scale, uint64_t seed, int64_t img_offset, float* keep, float* x_mean_out,
+                                  void* workspace, size_t workspace_bytes, void* stream, int use_graph) {
+    DMN_REQUIRE(u && table && x && workspace && nsteps > 0, DMN_ERR_INVALID, "dmn_pc_sample_loop: bad argument");
+    DMN_REQUIRE(u->cfg.out_dim == u->cfg.channels, DMN_ERR_INVALID, "score network must emit %d channels", u->cfg.channels);
+    DMN_REQUIRE(corrector >= 0 && corrector <= 2 && predictor >= 0 && predictor <= 1 && n_corrector_steps >= 0 &&
+                    n_corrector_steps <= 64, DMN_ERR_INVALID, "dmn_pc_sample_loop: bad predictor/corrector selection");
+    hipStream_t s = (hipStream_t)stream;
+    LoopBufs lb;
+    int rc = carve(u, B, H, W, workspace, workspace_bytes, lb, nullptr);
+    if (rc) return rc;
+    const int C = u->cfg.channels;
+    float* xmean = x_mean_out ? x_mean_out : lb.xmean;
+    DMN_HIP_CHECK(hipMemsetAsync(lb.step_idx, 0, 256, s));
+    if (draw_prior && (rc = launch_prior(x, B, C * H * W, seed, (unsigned)nsteps, img_offset, prior_scale, s))) return rc;
+    SampleKey key = {x, table, workspace, keep, xmean, 2, B, H, W,
+                     predictor | (corrector << 2) | (n_corrector_steps << 4) | (denoise << 12), nsteps, seed, img_offset, snr};
+    auto body = [&]() -> int {
+        int r;
+        if (corrector) {
+            for (int k = 0; k < n_corrector_steps; ++k) {
+                if ((r = unet_forward_impl(u, x, nullptr, 1, table, lb.step_idx, lb.net, B, H, W, lb.arena, lb.arena_bytes, s, false, nullptr))) return r;
+                LangevinArgs a;
+                memset(&a, 0, sizeof(a));
+                a.c = step_common(table, lb.step_idx, 0, x, lb.net, nullptr, x, B, C, H * W, seed, img_offset, nullptr);
+                a.partials = lb.partials;
+                a.inner = k;
+                a.use_norms = corrector == 1;
+                a.snr = snr;
+                if ((r = launch_langevin(a, s))) return r;
+            }
+        }
+        if (predictor) {
+            if ((r = unet_forward_impl(u, x, nullptr, 1, table, lb.step_idx, lb.net, B, H, W, lb.arena, lb.arena_bytes, s, false, nullptr))) return r;
+            AffineStepArgs a;
+            a.c = step_common(table, lb.step_idx, 0, x, lb.net, nullptr, x, B, C, H * W, seed, img_offset, keep);
+            a.x_mean = xmean;
+            a.keep_mean = denoise;
+            if ((r = launch_affine_step(a, s))) return r;
+        }
+        return launch_advance(lb.step_idx, s);
+    };
+    return run_loop(u, key, nsteps, s, use_graph, body);
+}
+
+// ---- per-kernel test hook ----------------------------------------------------------------------------------
+extern "C" int dmn_test_conv2d(int dtype, const void* in0, const void* in1, int C0, int C1, int B, int H, int W,
+                               const float* w_host, const float* bias_host, int Cout, int kh, int kw, int stride, int pad,
+                               int transposed, void* out, const void* res, const float* pro_gamma_host,
+                               const float* pro_beta_host, const float* pro_tbias_dev, const float* pro_stats_dev, int pro_G,
+                               int pro_slots, int pro_silu, float* epi_stats_dev, int epi_G, int* epi_slots_out,
+                               int cfg_tile, int cfg_bn, void* stream) {
+    int rc = conv_init_attributes();
+    if (rc) return rc;
+    PackedConv pc;
+    if ((rc = pack_conv(pc, dtype, w_host, bias_host, Cout, C0 + C1, kh, kw, stride, pad, transposed != 0))) return rc;
+    ConvArgs a;
+    conv_args_from(pc, dtype, a, B, H, W);
+    a.in0 = in0;
+    a.in1 = in1;
+    a.C0 = C0;
+    a.C1 = C1;
+    a.out = out;
+    a.res = res;
+    a.cfg_tile = cfg_tile;
+    a.cfg_bn = cfg_bn;
+    float *dg = nullptr, *db = nullptr;
+    if (pro_stats_dev) {
+        const int Cin = C0 + C1;
+        if (hipMalloc((void**)&dg, Cin * 4) != hipSuccess || hipMalloc((void**)&db, Cin * 4) != hipSuccess) return DMN_ERR_HIP;
+        (void)hipMemcpy(dg, pro_gamma_host, Cin * 4, hipMemcpyHostToDevice);
+        (void)hipMemcpy(db, pro_beta_host, Cin * 4, hipMemcpyHostToDevice);
+        a.pro.stats = pro_stats_dev;
+        a.pro.G = pro_G;
+        a.pro.slots = pro_slots;
+        a.pro.inv_count = 1.0f / ((float)(Cin / pro_G) * H * W);
+        a.pro.gamma = dg;
+        a.pro.beta = db;
+        a.pro.tbias = pro_tbias_dev;
+        a.pro.tb_stride = Cin;
+        a.pro.silu = pro_silu;
+    }
+    if (epi_stats_dev) {
+        a.epi.stats = epi_stats_dev;
+        a.epi.G = epi_G;
+    }
+    rc = launch_conv(a, (hipStream_t)stream);
+    if (epi_slots_out) *epi_slots_out = a.epi.slots;
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    free_conv(pc);
+    if (dg) (void)hipFree(dg);
+    if (db) (void)hipFree(db);
+    return rc;
+}

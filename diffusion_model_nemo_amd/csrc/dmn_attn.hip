@@ -1,0 +1,277 @@
+// Attention cores on a materialised qkv tensor [B][n][3*hidden] (channels: q | k | v, each head-major,
+// hidden = heads * d, d = 32), fp32 arithmetic.
+//
+//   linear attention  (diffusion_model_nemo/parts/mha.py:44-59):
+//       q = softmax_d(q) * d^-1/2 ; k = softmax_n(k) ; ctx[d][e] = sum_n k[d][n] v[e][n] ;
+//       out[e][n] = sum_d ctx[d][e] q[d][n]
+//   softmax attention (parts/mha.py:16-30): out[i] = softmax_j((q_i * d^-1/2) . k_j) v_j
+//
+// The softmax over n of linear attention is split over workgroups: every workgroup takes a slice of the
+// pixels, uses its LOCAL per-channel maximum, and writes {ctx, max, sum}; the consumer rescales the
+// partials to the global maximum (exact in real arithmetic, deterministic slot order).
+#include "dmn_kernels.h"
+
+namespace {
+
+constexpr int kD = 32;
+constexpr int kLaChunk = 256;           // pixels per workgroup in the context pass
+constexpr int kPartStride = kD * kD + 2 * kD;
+
+template <typename T>
+__device__ __forceinline__ void load32(const T* p, float* dst) {
+    constexpr int PER = ElemTraits<T>::kPer16B;
+    using V = decltype(Vec16<T>::v);
+#pragma unroll
+    for (int i = 0; i < kD / PER; ++i) {
+        Vec16<T> v;
+        v.v = *reinterpret_cast<const V*>(p + i * PER);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) dst[i * PER + j] = v.get(j);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void store32(T* p, const float* src) {
+    constexpr int PER = ElemTraits<T>::kPer16B;
+    using V = decltype(Vec16<T>::v);
+#pragma unroll
+    for (int i = 0; i < kD / PER; ++i) {
+        Vec16<T> v;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) v.set(j, src[i * PER + j]);
+        *reinterpret_cast<V*>(p + i * PER) = v.v;
+    }
+}
+
+// grid (splits, heads, B); 256 threads
+template <typename T>
+__global__ void __launch_bounds__(256) linattn_ctx_kernel(const LinAttnArgs a) {
+    __shared__ float sK[kLaChunk][kD + 1];
+    __shared__ float sV[kLaChunk][kD + 4];
+    __shared__ float sRed[8][kD];
+    __shared__ float sM[kD];
+    const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+    const int hidden = a.heads * kD;
+    const int p0 = split * kLaChunk;
+    const int np = min(kLaChunk, a.n - p0);
+    {
+        float kk[kD], vv[kD];
+        if (tid < np) {
+            const T* row = static_cast<const T*>(a.qkv) + ((size_t)b * a.n + p0 + tid) * 3 * hidden;
+            load32(row + hidden + h * kD, kk);
+            load32(row + 2 * hidden + h * kD, vv);
+        } else {
+#pragma unroll
+            for (int j = 0; j < kD; ++j) { kk[j] = -INFINITY; vv[j] = 0.f; }
+        }
+#pragma unroll
+        for (int j = 0; j < kD; ++j) { sK[tid][j] = kk[j]; sV[tid][j] = vv[j]; }
+    }
+    __syncthreads();
+    const int d = tid & 31, part = tid >> 5;   // 8 parts x 32 pixels
+    float m = -INFINITY;
+    for (int p = part * 32; p < part * 32 + 32; ++p) m = fmaxf(m, sK[p][d]);
+    sRed[part][d] = m;
+    __syncthreads();
+    if (tid < kD) {
+        float mm = sRed[0][tid];
+        for (int i = 1; i < 8; ++i) mm = fmaxf(mm, sRed[i][tid]);
+        sM[tid] = mm;
+    }
+    __syncthreads();
+    m = sM[d];
+    float z = 0.f;
+    for (int p = part * 32; p < part * 32 + 32; ++p) {
+        const float e = expf(sK[p][d] - m);   // exp(-inf) = 0 for the padded pixels
+        sK[p][d] = e;
+        z += e;
+    }
+    __syncthreads();
+    sRed[part][d] = z;
+    __syncthreads();
+    float* dst = a.ctx_part + ((size_t)(b * a.heads + h) * a.splits + split) * kPartStride;
+    if (tid < kD) {
+        float zz = 0.f;
+        for (int i = 0; i < 8; ++i) zz += sRed[i][tid];
+        dst[kD * kD + tid] = sM[tid];
+        dst[kD * kD + kD + tid] = zz;
+    }
+    // ctx[d][e]: thread -> (d = tid>>3, e0 = (tid&7)*4)
+    const int dd = tid >> 3, e0 = (tid & 7) * 4;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+    for (int p = 0; p < kLaChunk; ++p) {
+        const float kv = sK[p][dd];
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&sV[p][e0]);
+        c0 = fmaf(kv, v[0], c0);
+        c1 = fmaf(kv, v[1], c1);
+        c2 = fmaf(kv, v[2], c2);
+        c3 = fmaf(kv, v[3], c3);
+    }
+    *reinterpret_cast<f32x4*>(dst + dd * kD + e0) = f32x4{c0, c1, c2, c3};
+}
+
+// grid (ceil(n/256), B); 256 threads, one pixel per thread
+template <typename T>
+__global__ void __launch_bounds__(256) linattn_out_kernel(const LinAttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sCtx = reinterpret_cast<float*>(smem);          // [heads][d][e]
+    float* sScale = sCtx + a.heads * kD * kD;              // [heads][d][splits] rescale factors / Z
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int hidden = a.heads * kD;
+    // combine the partial contexts: factor_s[d] = exp(m_s[d] - M[d]) / sum_s Z_s[d] exp(m_s[d] - M[d])
+    for (int hd = tid; hd < a.heads * kD; hd += 256) {
+        const int h = hd / kD, d = hd % kD;
+        const float* base = a.ctx_part + ((size_t)(b * a.heads + h) * a.splits) * kPartStride;
+        float M = -INFINITY;
+        for (int s = 0; s < a.splits; ++s) M = fmaxf(M, base[(size_t)s * kPartStride + kD * kD + d]);
+        float Z = 0.f;
+        for (int s = 0; s < a.splits; ++s) {
+            const float f = expf(base[(size_t)s * kPartStride + kD * kD + d] - M);
+            sScale[hd * a.splits + s] = f;
+            Z += base[(size_t)s * kPartStride + kD * kD + kD + d] * f;
+        }
+        const float inv = 1.0f / Z;
+        for (int s = 0; s < a.splits; ++s) sScale[hd * a.splits + s] *= inv;
+    }
+    __syncthreads();
+    for (int i = tid; i < a.heads * kD * kD; i += 256) {
+        const int h = i / (kD * kD), de = i % (kD * kD), d = de / kD;
+        const float* base = a.ctx_part + ((size_t)(b * a.heads + h) * a.splits) * kPartStride;
+        float acc = 0.f;
+        for (int s = 0; s < a.splits; ++s) acc = fmaf(base[(size_t)s * kPartStride + de], sScale[(h * kD + d) * a.splits + s], acc);
+        sCtx[i] = acc;
+    }
+    __syncthreads();
+    const int p = blockIdx.x * 256 + tid;
+    if (p >= a.n) return;
+    const T* row = static_cast<const T*>(a.qkv) + ((size_t)b * a.n + p) * 3 * hidden;
+    T* orow = static_cast<T*>(a.out) + ((size_t)b * a.n + p) * hidden;
+    const float scale = 0.17677669529663687f;  // 32^-0.5
+    for (int h = 0; h < a.heads; ++h) {
+        float q[kD], o[kD];
+        load32(row + h * kD, q);
+        float m = q[0];
+#pragma unroll
+        for (int j = 1; j < kD; ++j) m = fmaxf(m, q[j]);
+        float z = 0.f;
+#pragma unroll
+        for (int j = 0; j < kD; ++j) { q[j] = expf(q[j] - m); z += q[j]; }
+        const float inv = scale / z;
+#pragma unroll
+        for (int e = 0; e < kD; ++e) o[e] = 0.f;
+        const float* ctx = sCtx + h * kD * kD;
+#pragma unroll
+        for (int dq = 0; dq < kD; ++dq) {
+            const float qq = q[dq] * inv;
+#pragma unroll
+            for (int e = 0; e < kD; e += 4) {
+                const f32x4 c = *reinterpret_cast<const f32x4*>(ctx + dq * kD + e);
+                o[e] = fmaf(c[0], qq, o[e]);
+                o[e + 1] = fmaf(c[1], qq, o[e + 1]);
+                o[e + 2] = fmaf(c[2], qq, o[e + 2]);
+                o[e + 3] = fmaf(c[3], qq, o[e + 3]);
+            }
+        }
+        store32(orow + h * kD, o);
+    }
+}
+
+// softmax attention; grid (heads, B, query blocks of 256); K/V of a 128-key chunk in LDS; online softmax
+template <typename T>
+__global__ void __launch_bounds__(256) attention_kernel(const AttnArgs a) {
+    constexpr int KC = 128;   // keys per LDS chunk
+    __shared__ float sK[KC][kD + 4];
+    __shared__ float sV[KC][kD + 4];
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int hidden = a.heads * kD;
+    const int qi = blockIdx.z * 256 + tid;
+    const bool active = qi < a.n;
+    const T* base = static_cast<const T*>(a.qkv) + (size_t)b * a.n * 3 * hidden;
+    float q[kD], acc[kD];
+    const float scale = 0.17677669529663687f;
+    if (active) {
+        load32(base + (size_t)qi * 3 * hidden + h * kD, q);
+#pragma unroll
+        for (int j = 0; j < kD; ++j) q[j] *= scale;
+    } else {
+#pragma unroll
+        for (int j = 0; j < kD; ++j) q[j] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < kD; ++j) acc[j] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    for (int k0 = 0; k0 < a.n; k0 += KC) {
+        const int nk = min(KC, a.n - k0);
+        __syncthreads();
+        if (tid < nk) {
+            float kk[kD], vv[kD];
+            const T* row = base + (size_t)(k0 + tid) * 3 * hidden;
+            load32(row + hidden + h * kD, kk);
+            load32(row + 2 * hidden + h * kD, vv);
+#pragma unroll
+            for (int j = 0; j < kD; ++j) { sK[tid][j] = kk[j]; sV[tid][j] = vv[j]; }
+        }
+        __syncthreads();
+        for (int j = 0; j < nk; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < kD; c += 4) {
+                const f32x4 kv = *reinterpret_cast<const f32x4*>(&sK[j][c]);
+                s = fmaf(q[c], kv[0], s);
+                s = fmaf(q[c + 1], kv[1], s);
+                s = fmaf(q[c + 2], kv[2], s);
+                s = fmaf(q[c + 3], kv[3], s);
+            }
+            const float mn = fmaxf(m, s);
+            const float alpha = expf(m - mn);
+            const float pj = expf(s - mn);
+            l = l * alpha + pj;
+#pragma unroll
+            for (int c = 0; c < kD; c += 4) {
+                const f32x4 vv = *reinterpret_cast<const f32x4*>(&sV[j][c]);
+                acc[c] = fmaf(pj, vv[0], acc[c] * alpha);
+                acc[c + 1] = fmaf(pj, vv[1], acc[c + 1] * alpha);
+                acc[c + 2] = fmaf(pj, vv[2], acc[c + 2] * alpha);
+                acc[c + 3] = fmaf(pj, vv[3], acc[c + 3] * alpha);
+            }
+            m = mn;
+        }
+    }
+    if (active) {
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int j = 0; j < kD; ++j) acc[j] *= inv;
+        store32(static_cast<T*>(a.out) + ((size_t)b * a.n + qi) * hidden + h * kD, acc);
+    }
+}
+
+}  // namespace
+
+int linear_attention_splits(int n) { return (n + kLaChunk - 1) / kLaChunk; }
+
+int launch_linear_attention(LinAttnArgs& a, hipStream_t s) {
+    DMN_REQUIRE(a.d == kD, DMN_ERR_INVALID, "linear attention: dim_head=%d (only 32)", a.d);
+    a.splits = linear_attention_splits(a.n);
+    const size_t lds = ((size_t)a.heads * kD * kD + (size_t)a.heads * kD * a.splits) * 4;
+    DMN_REQUIRE(lds <= 64 * 1024, DMN_ERR_LIMIT, "linear attention: %d pixels exceed the supported maximum", a.n);
+    dim3 g1(a.splits, a.heads, a.B), g2((a.n + 255) / 256, a.B);
+    if (a.dtype == DMN_F32) {
+        hipLaunchKernelGGL(linattn_ctx_kernel<float>, g1, dim3(256), 0, s, a);
+        hipLaunchKernelGGL(linattn_out_kernel<float>, g2, dim3(256), lds, s, a);
+    } else {
+        hipLaunchKernelGGL(linattn_ctx_kernel<__bf16>, g1, dim3(256), 0, s, a);
+        hipLaunchKernelGGL(linattn_out_kernel<__bf16>, g2, dim3(256), lds, s, a);
+    }
+    DMN_HIP_CHECK(hipGetLastError());
+    return DMN_OK;
+}
+
+int launch_attention(AttnArgs& a, hipStream_t s) {
+    DMN_REQUIRE(a.d == kD, DMN_ERR_INVALID, "attention: dim_head=%d (only 32)", a.d);
+    dim3 grid(a.heads, a.B, (a.n + 255) / 256);
+    if (a.dtype == DMN_F32)
+        hipLaunchKernelGGL(attention_kernel<float>, grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(attention_kernel<__bf16>, grid, dim3(256), 0, s, a);
+    DMN_HIP_CHECK(hipGetLastError());
+    return DMN_OK;
+}

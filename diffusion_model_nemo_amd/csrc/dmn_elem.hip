@@ -1,0 +1,295 @@
+// Memory-bound kernels of the U-Net: GroupNorm apply (+SiLU, +residual), time-embedding path,
+// 7x7 ingest (NCHW fp32 -> NHWC) and the 1x1 egress (NHWC -> NCHW fp32).
+#include "dmn_kernels.h"
+#include "dmn_norm.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------
+// out = [SiLU](GN(in)) [+ res], 16 bytes per lane, with optional partial statistics of `out`.
+// Closes a ResnetBlock (parts/convnext.py:85-86: block2's norm+act, then + res_conv(x)) and a
+// LinearAttention (parts/mha.py:41-42 GroupNorm(1) after to_out, utils.py:73-74 residual).
+// Grid: (chunks, B); every workgroup owns kPixPerWg consecutive pixels of one image.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kNormThreads = 256;
+
+template <typename T>
+__global__ void __launch_bounds__(kNormThreads) norm_apply_kernel(const NormApplyArgs a, int pix_per_wg) {
+    constexpr int PER = ElemTraits<T>::kPer16B;
+    using V = decltype(Vec16<T>::v);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sCoef = reinterpret_cast<float*>(smem);
+    float* sTmp = sCoef + 3 * a.C;            // max(2*G_in, 2*4*G_out)
+    const int b = blockIdx.y;
+    const int C = a.C;
+    norm_coefs_to_lds(a.norm, b, C, sCoef, sTmp);
+
+    const int vec_per_pix = C / PER;
+    const int p0 = blockIdx.x * pix_per_wg;
+    const int p1 = min(p0 + pix_per_wg, a.HW);
+    const int nvec = (p1 - p0) * vec_per_pix;
+    const T* in = static_cast<const T*>(a.in) + ((size_t)b * a.HW + p0) * C;
+    const T* res = a.res ? static_cast<const T*>(a.res) + ((size_t)b * a.HW + p0) * C : nullptr;
+    T* out = static_cast<T*>(a.out) + ((size_t)b * a.HW + p0) * C;
+
+    const bool want = a.epi.stats != nullptr;
+    const int Go = want ? a.epi.G : 1;
+    const int cpg_o = C / Go;
+    // A thread always visits the same channel offset when kNormThreads % vec_per_pix == 0, so it feeds
+    // one output group; otherwise (never for this network) fall back to group 0 bookkeeping per element.
+    float s = 0.f, ss = 0.f;
+    int my_group = 0;
+    for (int i = threadIdx.x; i < nvec; i += kNormThreads) {
+        const int cb = (i % vec_per_pix) * PER;
+        Vec16<T> v, r;
+        v.v = *reinterpret_cast<const V*>(in + (size_t)i * PER);
+        if (res) r.v = *reinterpret_cast<const V*>(res + (size_t)i * PER);
+        my_group = cb / cpg_o;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            float y = v.get(j) * sCoef[cb + j] + sCoef[C + cb + j];
+            if (a.norm.silu) y = (sizeof(T) == 4) ? silu_precise(y) : silu_f(y);
+            y += sCoef[2 * C + cb + j];
+            if (res) y += r.get(j);
+            v.set(j, y);
+            const float yr = v.get(j);  // statistics of the value the consumer will read
+            s += yr;
+            ss += yr * yr;
+        }
+        *reinterpret_cast<V*>(out + (size_t)i * PER) = v.v;
+    }
+    if (want) {
+        // threads -> LDS per (group, thread) would be large; instead reduce with LDS atomics-free two-step:
+        // each wave reduces lanes that share a group via a small per-wave table.
+        __syncthreads();
+        float* sAcc = sTmp;  // [4 waves][Go][2]
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        for (int g = 0; g < Go; ++g) {
+            const float ms = (my_group == g) ? s : 0.f;
+            const float mss = (my_group == g) ? ss : 0.f;
+            const float ws = wave_sum(ms), wss = wave_sum(mss);
+            if (lane == 0) {
+                sAcc[(wave * Go + g) * 2] = ws;
+                sAcc[(wave * Go + g) * 2 + 1] = wss;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < Go) {
+            const int g = threadIdx.x;
+            float ts = 0.f, tss = 0.f;
+            for (int w = 0; w < kNormThreads / 64; ++w) {
+                ts += sAcc[(w * Go + g) * 2];
+                tss += sAcc[(w * Go + g) * 2 + 1];
+            }
+            float* dst = a.epi.stats + ((size_t)(b * Go + g) * a.epi.slots + blockIdx.x) * 2;
+            dst[0] = ts;
+            dst[1] = tss;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Time path, one workgroup per sample, all fp32:
+//   SinusoidalPositionEmbeddings (parts/positional_encoding.py:11-18) -> Linear -> GELU(erf) -> Linear
+//   (modules/unet.py:61-66) -> for every ResnetBlock: SiLU -> Linear(4*dim, Cout) (parts/convnext.py:69,82)
+// The label is either read from `t` (int64 or float32) or from a per-step schedule table indexed by a
+// device-resident step counter (so a captured graph can be replayed for every step).
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) time_mlp_kernel(const TimeArgs a) {
+    __shared__ float sE[64];
+    __shared__ float sH[512];
+    __shared__ float sT[512];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int dim = a.dim, hid = 4 * a.dim, half = a.dim / 2;
+    float label;
+    if (a.t) {
+        label = a.t_is_float ? static_cast<const float*>(a.t)[b] : (float)static_cast<const long long*>(a.t)[b];
+    } else {
+        label = a.table[(size_t)(*a.step_idx) * a.table_cols + a.label_col];
+    }
+    if (tid < half) {
+        const float e = label * a.freqs[tid];
+        sE[tid] = sinf(e);
+        sE[half + tid] = cosf(e);
+    }
+    __syncthreads();
+    for (int o = tid; o < hid; o += 256) {
+        float acc = 0.f;
+        const float* w = a.w1 + (size_t)o * dim;
+        for (int k = 0; k < dim; ++k) acc = fmaf(sE[k], w[k], acc);
+        acc += a.b1[o];
+        sH[o] = 0.5f * acc * (1.0f + erff(acc * 0.70710678118654752440f));
+    }
+    __syncthreads();
+    for (int o = tid; o < hid; o += 256) {
+        float acc = 0.f;
+        const float* w = a.w2 + (size_t)o * hid;
+        for (int k = 0; k < hid; ++k) acc = fmaf(sH[k], w[k], acc);
+        acc += a.b2[o];
+        sT[o] = silu_precise(acc);
+    }
+    __syncthreads();
+    // each wave computes outputs with a coalesced row read + wave reduction
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int o = wave; o < a.nout; o += 4) {
+        const float* w = a.wb + (size_t)o * hid;
+        float acc = 0.f;
+        for (int k = lane; k < hid; k += 64) acc = fmaf(sT[k], w[k], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) a.out[(size_t)b * a.nout + o] = acc + a.bb[o];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Ingest: init_conv 7x7 pad 3 (modules/unet.py:41,132) reading the reference's NCHW fp32 layout and
+// writing NHWC T. Cin is 3 (too thin for an MFMA K dimension): a direct fp32 VALU convolution with the
+// weights read through uniform (scalar) loads. 16x16 output pixels per workgroup, one pixel per thread.
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int COUT>
+__global__ void __launch_bounds__(256) ingest_kernel(const IngestArgs a) {
+    constexpr int TS = 16, HALO = 3, IW = TS + 2 * HALO;
+    __shared__ float sIn[4][IW][IW + 1];
+    const int tiles_x = (a.W + TS - 1) / TS;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
+    const int b = blockIdx.y;
+    const int y0 = ty * TS - HALO, x0 = tx * TS - HALO;
+    for (int i = threadIdx.x; i < a.Cin * IW * IW; i += 256) {
+        const int c = i / (IW * IW), r = i % (IW * IW);
+        const int ly = r / IW, lx = r % IW;
+        const int gy = y0 + ly, gx = x0 + lx;
+        float v = 0.f;
+        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = a.x[((size_t)(b * a.Cin + c) * a.H + gy) * a.W + gx];
+        sIn[c][ly][lx] = v;
+    }
+    __syncthreads();
+    const int py = threadIdx.x / TS, px = threadIdx.x % TS;
+    float acc[COUT];
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) acc[o] = a.bias[o];
+    for (int c = 0; c < a.Cin; ++c)
+        for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) {
+                const float v = sIn[c][py + ky][px + kx];
+                const float* w = a.w + (c * 7 + ky) * 7 + kx;
+#pragma unroll
+                for (int o = 0; o < COUT; ++o) acc[o] = fmaf(v, w[(size_t)o * a.Cin * 49], acc[o]);
+            }
+    const int oy = ty * TS + py, ox = tx * TS + px;
+    if (oy < a.H && ox < a.W) {
+        T* dst = static_cast<T*>(a.out) + ((size_t)(b * a.H + oy) * a.W + ox) * COUT;
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) dst[o] = from_f32<T>(acc[o]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Egress: final_conv tail (modules/unet.py:112-116): [GroupNorm(groups) -> SiLU ->] 1x1 conv to 3 or 6
+// channels, written in the reference's NCHW fp32 layout. One pixel per thread.
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) egress_kernel(const EgressArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sCoef = reinterpret_cast<float*>(smem);   // 3*C
+    float* sW = sCoef + 3 * a.C;                     // Cout*C + Cout, then 2*G scratch
+    const int b = blockIdx.y, C = a.C;
+    const bool norm = a.norm.stats != nullptr;
+    if (norm) norm_coefs_to_lds(a.norm, b, C, sCoef, sW);
+    for (int i = threadIdx.x; i < a.Cout * C; i += 256) sW[i] = a.w[i];
+    for (int i = threadIdx.x; i < a.Cout; i += 256) sW[a.Cout * C + i] = a.bias[i];
+    __syncthreads();
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= a.HW) return;
+    constexpr int PER = ElemTraits<T>::kPer16B;
+    using V = decltype(Vec16<T>::v);
+    float acc[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] = o < a.Cout ? sW[a.Cout * C + o] : 0.f;
+    const T* in = static_cast<const T*>(a.in) + ((size_t)b * a.HW + p) * C;
+    for (int cb = 0; cb < C; cb += PER) {
+        Vec16<T> v;
+        v.v = *reinterpret_cast<const V*>(in + cb);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            float y = v.get(j);
+            if (norm) {
+                y = y * sCoef[cb + j] + sCoef[C + cb + j];
+                if (a.norm.silu) y = (sizeof(T) == 4) ? silu_precise(y) : silu_f(y);
+            }
+#pragma unroll
+            for (int o = 0; o < 8; ++o)
+                if (o < a.Cout) acc[o] = fmaf(y, sW[o * C + cb + j], acc[o]);
+        }
+    }
+    for (int o = 0; o < a.Cout; ++o) a.out[((size_t)b * a.Cout + o) * a.HW + p] = acc[o];
+}
+
+}  // namespace
+
+int norm_apply_slots(int HW, int C) {
+    // enough workgroups to fill the chip at batch 64 while keeping >= 8 KiB per workgroup
+    int pix = 8192 / C;
+    if (pix < 16) pix = 16;
+    if (pix > HW) pix = HW;
+    return (HW + pix - 1) / pix;
+}
+
+int launch_norm_apply(NormApplyArgs& a, hipStream_t s) {
+    const int per = a.dtype == DMN_F32 ? 4 : 8;
+    DMN_REQUIRE(a.C % per == 0 && a.C % a.norm.G == 0, DMN_ERR_INVALID, "norm_apply: C=%d groups=%d", a.C, a.norm.G);
+    DMN_REQUIRE(kNormThreads % (a.C / per) == 0 || !a.epi.stats, DMN_ERR_INVALID, "norm_apply: C=%d not supported with statistics", a.C);
+    const int slots = norm_apply_slots(a.HW, a.C);
+    const int pix = (a.HW + slots - 1) / slots;
+    int Go = 1;
+    if (a.epi.stats) {
+        Go = a.epi.G;
+        DMN_REQUIRE(a.C % Go == 0 && (a.C / Go) % per == 0, DMN_ERR_INVALID, "norm_apply: output groups %d", Go);
+        a.epi.slots = slots;
+    }
+    size_t tmp = 2 * (size_t)a.norm.G;
+    if ((size_t)8 * Go > tmp) tmp = 8 * Go;
+    const size_t lds = (3 * (size_t)a.C + tmp) * 4;
+    dim3 grid(slots, a.B);
+    if (a.dtype == DMN_F32)
+        hipLaunchKernelGGL(norm_apply_kernel<float>, grid, dim3(kNormThreads), lds, s, a, pix);
+    else
+        hipLaunchKernelGGL(norm_apply_kernel<__bf16>, grid, dim3(kNormThreads), lds, s, a, pix);
+    DMN_HIP_CHECK(hipGetLastError());
+    return DMN_OK;
+}
+
+int launch_time_mlp(TimeArgs& a, hipStream_t s) {
+    DMN_REQUIRE(a.dim <= 64 && a.dim % 2 == 0 && 4 * a.dim <= 512, DMN_ERR_LIMIT, "time_mlp: dim=%d exceeds 64", a.dim);
+    hipLaunchKernelGGL(time_mlp_kernel, dim3(a.B), dim3(256), 0, s, a);
+    DMN_HIP_CHECK(hipGetLastError());
+    return DMN_OK;
+}
+
+int launch_ingest(IngestArgs& a, hipStream_t s) {
+    DMN_REQUIRE(a.Cin >= 1 && a.Cin <= 4, DMN_ERR_LIMIT, "ingest: Cin=%d (max 4)", a.Cin);
+    dim3 grid(((a.H + 15) / 16) * ((a.W + 15) / 16), a.B);
+#define DMN_INGEST(T, N) hipLaunchKernelGGL((ingest_kernel<T, N>), grid, dim3(256), 0, s, a)
+    if (a.Cout == 32) {
+        if (a.dtype == DMN_F32) DMN_INGEST(float, 32); else DMN_INGEST(__bf16, 32);
+    } else if (a.Cout == 64) {
+        if (a.dtype == DMN_F32) DMN_INGEST(float, 64); else DMN_INGEST(__bf16, 64);
+    } else {
+        dmn_set_error("ingest: Cout=%d not instantiated (32 or 64)", a.Cout);
+        return DMN_ERR_INVALID;
+    }
+#undef DMN_INGEST
+    DMN_HIP_CHECK(hipGetLastError());
+    return DMN_OK;
+}
+
+int launch_egress(EgressArgs& a, hipStream_t s) {
+    DMN_REQUIRE(a.Cout >= 1 && a.Cout <= 8, DMN_ERR_LIMIT, "egress: Cout=%d (max 8)", a.Cout);
+    const size_t lds = (3 * (size_t)a.C + (size_t)a.Cout * a.C + a.Cout + 2 * (size_t)(a.norm.stats ? a.norm.G : 0) + 16) * 4;
+    dim3 grid((a.HW + 255) / 256, a.B);
+    if (a.dtype == DMN_F32)
+        hipLaunchKernelGGL(egress_kernel<float>, grid, dim3(256), lds, s, a);
+    else
+        hipLaunchKernelGGL(egress_kernel<__bf16>, grid, dim3(256), lds, s, a);
+    DMN_HIP_CHECK(hipGetLastError());
+    return DMN_OK;
+}

@@ -1,0 +1,135 @@
+// Internal launch interface of the gfx950 kernels (not part of the C-ABI; see include/dmn.h for that).
+// All activations are NHWC, element type T = float or __bf16 selected by `dtype`.
+#pragma once
+#include "dmn_common.h"
+
+enum { DMN_F32 = 0, DMN_BF16 = 1 };
+
+// ---- group-norm statistics passed between kernels -----------------------------------------------
+// A producer writes, for every (image, group), `slots` partial {sum, sum of squares} pairs, one per
+// contributing workgroup, each slot written exactly once: layout [B][G][slots][2] fp32. A consumer
+// adds the slots in index order (deterministic) and derives mean / rstd. `count` is the number of
+// elements per (image, group).
+struct NormIn {
+    const float* stats;   // nullptr: no normalisation
+    int G;
+    int slots;
+    float inv_count;
+    const float* gamma;   // [C]
+    const float* beta;    // [C]
+    const float* tbias;   // optional [B][tb_stride] added AFTER the activation (time-embedding bias)
+    int tb_stride;
+    int silu;             // apply SiLU after the affine normalisation
+};
+struct NormOut {
+    float* stats;         // nullptr: no statistics wanted
+    int G;
+    int slots;            // slots per (image, group) the launch will fill; set by the launcher
+};
+
+struct ConvPhase {
+    int pad_y, pad_x;     // top/left padding of this phase
+    int out_oy, out_ox;   // output pixel = tile-space pixel * out_s + out_o
+    long long w_off;      // element offset of this phase's packed weights
+};
+
+struct ConvArgs {
+    int dtype;
+    const void* in0;      // [B][H][W][C0]
+    const void* in1;      // optional second source, channel-concatenated after in0: [B][H][W][C1]
+    int C0, C1;
+    int B, H, W;
+    int Ho, Wo;           // tile-space output extent (for a transposed conv: the input extent)
+    int out_H, out_W;     // extent of the output tensor
+    int out_sy, out_sx;
+    int stride;
+    int ntaps;
+    signed char tap_dy[16], tap_dx[16];
+    int ext_y, ext_x;     // 1 + max tap offset
+    int nphase;
+    ConvPhase phase[4];
+    const void* w;        // packed [phase][Cin/kChunk][Cout][ntaps][kChunk]
+    const float* bias;    // [Cout] or nullptr
+    void* out;            // [B][out_H][out_W][Cout]
+    int Cout;
+    NormIn pro;           // normalise + activate the input while staging it (in0 only)
+    const void* res;      // optional residual added in the epilogue, same shape as out
+    NormOut epi;          // statistics of the output after bias (taken before the residual add)
+    int cfg_tile, cfg_bn; // 0 = choose automatically; otherwise force the pixel tile (8 or 16) / channel tile (32 or 64)
+};
+int launch_conv(ConvArgs& a, hipStream_t s);
+int conv_epi_slots(const ConvArgs& a);   // slots per (image, group) launch_conv will write
+int conv_init_attributes();
+
+// out = [SiLU](GN(in)) [+ tbias] [+ res], optional statistics of `out`.
+struct NormApplyArgs {
+    int dtype;
+    const void* in;
+    void* out;
+    const void* res;      // optional
+    int B, HW, C;
+    NormIn norm;
+    NormOut epi;
+};
+int launch_norm_apply(NormApplyArgs& a, hipStream_t s);
+int norm_apply_slots(int HW, int C);
+
+// time path: sinusoid -> Linear -> GELU -> Linear -> SiLU -> all per-block Linear(4*dim, Cout_i)
+struct TimeArgs {
+    const void* t;          // [B] int64 or float32, or nullptr to read `table`
+    int t_is_float;
+    const float* table;     // optional [nsteps][table_cols]; label = table[*step_idx][label_col]
+    const int* step_idx;
+    int table_cols, label_col;
+    int B, dim;             // sinusoid width; hidden = 4*dim
+    const float* freqs;     // [dim/2]
+    const float* w1; const float* b1;   // [4dim][dim]
+    const float* w2; const float* b2;   // [4dim][4dim]
+    const float* wb; const float* bb;   // concatenated per-block linears [nout][4dim], [nout]
+    int nout;
+    float* out;             // [B][nout]
+};
+int launch_time_mlp(TimeArgs& a, hipStream_t s);
+
+// 7x7 ingest: NCHW fp32 -> NHWC T, Cin <= 4
+struct IngestArgs {
+    int dtype;
+    const float* x;   // [B][Cin][H][W]
+    const float* w;   // [Cout][Cin][7][7]
+    const float* bias;
+    void* out;        // [B][H][W][Cout]
+    int B, Cin, H, W, Cout;
+};
+int launch_ingest(IngestArgs& a, hipStream_t s);
+
+// tail: [GN + SiLU] -> 1x1 conv -> NCHW fp32
+struct EgressArgs {
+    int dtype;
+    const void* in;   // [B][HW][C]
+    NormIn norm;      // stats == nullptr: plain 1x1
+    const float* w;   // [Cout][C]
+    const float* bias;
+    float* out;       // [B][Cout][HW]
+    int B, HW, C, Cout;
+};
+int launch_egress(EgressArgs& a, hipStream_t s);
+
+// linear attention core on a materialised qkv tensor [B][n][3*hidden] (q | k | v, head-major)
+struct LinAttnArgs {
+    int dtype;
+    const void* qkv;
+    void* out;          // [B][n][hidden]
+    float* ctx_part;    // workspace [B][heads][splits][d*d + 2*d]
+    int B, n, heads, d, splits;
+};
+int launch_linear_attention(LinAttnArgs& a, hipStream_t s);
+int linear_attention_splits(int n);
+
+// softmax attention core on qkv [B][n][3*hidden] -> out [B][n][hidden]
+struct AttnArgs {
+    int dtype;
+    const void* qkv;
+    void* out;
+    int B, n, heads, d;
+};
+int launch_attention(AttnArgs& a, hipStream_t s);

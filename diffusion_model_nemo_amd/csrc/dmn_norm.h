@@ -1,0 +1,35 @@
+// Device helper: turn the partial group-norm statistics of a producer kernel into per-channel
+// affine coefficients  y = x * a[c] + b[c]  (then optional SiLU, then + tb[c]) in LDS.
+// Matches GroupNorm(eps=1e-5, biased variance) as used by the reference blocks
+// (diffusion_model_nemo/parts/convnext.py:12,35; utils.py:89; parts/mha.py:42).
+#pragma once
+#include "dmn_kernels.h"
+
+// sCoef: 3*C floats (a | b | tb). sTmp: 2*G floats of scratch. Ends with a __syncthreads().
+__device__ __forceinline__ void norm_coefs_to_lds(const NormIn& n, int b, int C, float* sCoef, float* sTmp) {
+    const int tid = threadIdx.x;
+    const int nthr = blockDim.x;
+    for (int g = tid; g < n.G; g += nthr) {
+        const float* p = n.stats + ((size_t)(b * n.G + g) * n.slots) * 2;
+        float s = 0.f, ss = 0.f;
+        for (int i = 0; i < n.slots; ++i) {
+            s += p[2 * i];
+            ss += p[2 * i + 1];
+        }
+        const float mean = s * n.inv_count;
+        float var = ss * n.inv_count - mean * mean;
+        var = var > 0.f ? var : 0.f;
+        sTmp[2 * g] = mean;
+        sTmp[2 * g + 1] = 1.0f / sqrtf(var + 1e-5f);
+    }
+    __syncthreads();
+    const int cpg = C / n.G;
+    for (int c = tid; c < C; c += nthr) {
+        const int g = c / cpg;
+        const float aa = sTmp[2 * g + 1] * n.gamma[c];
+        sCoef[c] = aa;
+        sCoef[C + c] = n.beta[c] - sTmp[2 * g] * aa;
+        sCoef[2 * C + c] = n.tbias ? n.tbias[(size_t)b * n.tb_stride + c] : 0.f;
+    }
+    __syncthreads();
+}

@@ -1,0 +1,52 @@
+// Internal launch interface of the sampler update kernels (NCHW fp32 state).
+#pragma once
+#include "dmn_common.h"
+
+// Per-step schedule table: one row of DMN_TABLE_COLS floats per executed step, in execution order.
+//   col 0  network time label (DDPM: t; VE: sigma(t); VP: 999 t)
+//   DDPM rows:  1 sqrt(1/acp)  2 sqrt(1/acp - 1)  3 posterior_mean_coef1  4 posterior_mean_coef2
+//               5 posterior_log_variance_clipped  6 log(beta)  7 nonzero mask (t != 0)
+//   SDE rows:   1 a  2 b  3 c  (x_mean = a x + b net, x = x_mean + c z)
+//               4 score scale (score = scale * net)  5 alpha (Langevin)  6 fixed corrector step (ALD)
+//   col 8  step id used to key the noise generator
+#define DMN_TABLE_COLS 12
+
+struct StepCommon {
+    const float* x;       // [B][C][HW]
+    const float* net;     // network output
+    float* x_out;
+    const float* table;
+    const int* step_idx;  // device step counter, or nullptr to use `step`
+    int step;
+    int B, C, HW;
+    unsigned long long seed;
+    long long img_offset; // global index of image 0 of this batch
+    const float* noise;   // optional injected N(0,1) tensor [B][C][HW]; nullptr: generate
+    float* keep;          // optional history buffer [nsteps][keep_stride]
+    long long keep_stride;
+};
+struct DdpmStepArgs {
+    StepCommon c;
+    int learned_variance; // net has 2C channels: eps | v
+    int pred_x0;          // objective == 'pred_x0'
+};
+struct AffineStepArgs {
+    StepCommon c;
+    float* x_mean;        // optional
+    int keep_mean;        // history stores x_mean (denoise=True) instead of x
+};
+struct LangevinArgs {
+    StepCommon c;
+    float* partials;      // [B][slots][2]
+    int slots;
+    int inner;            // corrector inner step index (noise stream 2 + inner)
+    int use_norms;        // 1: Langevin, 0: annealed Langevin dynamics (fixed step)
+    float snr;
+};
+int launch_ddpm_step(const DdpmStepArgs& a, hipStream_t s);
+int launch_affine_step(const AffineStepArgs& a, hipStream_t s);
+int launch_langevin(LangevinArgs& a, hipStream_t s);
+int langevin_slots(int per);
+int launch_prior(float* x, int B, int per, unsigned long long seed, unsigned pstep, long long img_offset, float scale,
+                 hipStream_t s);
+int launch_advance(int* step_idx, hipStream_t s);

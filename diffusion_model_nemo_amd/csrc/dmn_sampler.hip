@@ -1,0 +1,229 @@
+// Per-step state updates of the samplers, on NCHW fp32 images (the reference's layout):
+//   * DDPM / improved-DDPM ancestral step
+//       diffusion_model_nemo/modules/gaussian_diffusion.py:118-123,91-101,157-167
+//       diffusion_model_nemo/modules/learned_gaussian_diffusion.py:35-48
+//   * score-SDE predictor step as an affine update  x_mean = a x + b net ; x = x_mean + c z
+//       sde_predictors/{euler_maruyama,reverse_diffusion,ancestral_sampling}_predictor.py
+//   * Langevin corrector (batch-mean of per-sample norms) sde_correctors/langevin_corrector.py:26-33
+// All per-step scalars come from a device table indexed by a device-resident step counter, so one
+// captured graph replays for every step. Noise is Philox (dmn_rng.h) or an injected tensor.
+#include "dmn_rng.h"
+#include "dmn_sampler.h"
+
+namespace {
+
+__device__ __forceinline__ void load_noise(const StepCommon& c, unsigned pstep, unsigned stream, int b, int q,
+                                            int per, float z[4]) {
+    if (c.noise) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = 4 * q + r;
+            z[r] = e < per ? c.noise[(size_t)b * per + e] : 0.f;
+        }
+    } else {
+        normal4(c.seed, pstep, stream, (unsigned)(c.img_offset + b), (unsigned)q, z);
+    }
+}
+
+// grid (ceil(per/4/256), B)
+__global__ void __launch_bounds__(256) ddpm_step_kernel(const DdpmStepArgs a) {
+    const StepCommon& c = a.c;
+    const int b = blockIdx.y;
+    const int per = c.C * c.HW;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (4 * q >= per) return;
+    const int row = c.step_idx ? *c.step_idx : c.step;
+    const float* tr = c.table + (size_t)row * DMN_TABLE_COLS;
+    const float sra = tr[1], srm1 = tr[2], c1 = tr[3], c2 = tr[4], plv = tr[5], logb = tr[6], mask = tr[7];
+    float z[4];
+    load_noise(c, (unsigned)tr[8], 1u, b, q, per, z);
+    const int mo_c = a.learned_variance ? 2 * c.C : c.C;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int e = 4 * q + r;
+        if (e >= per) break;
+        const size_t xi = (size_t)b * per + e;
+        const size_t mi = (size_t)b * mo_c * c.HW + e;
+        const float x = c.x[xi];
+        const float eps = c.net[mi];
+        float x0 = a.pred_x0 ? eps : sra * x - srm1 * eps;
+        x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+        const float mean = c1 * x0 + c2 * x;
+        float logvar = plv;
+        if (a.learned_variance) {
+            const float v = c.net[mi + (size_t)c.C * c.HW];
+            const float frac = (v + 1.0f) * 0.5f;
+            logvar = frac * logb + (1.0f - frac) * plv;
+        }
+        const float xn = mean + mask * expf(0.5f * logvar) * z[r];
+        c.x_out[xi] = xn;
+        if (c.keep) c.keep[(size_t)row * c.keep_stride + xi] = xn;
+    }
+}
+
+__global__ void __launch_bounds__(256) affine_step_kernel(const AffineStepArgs a) {
+    const StepCommon& c = a.c;
+    const int b = blockIdx.y;
+    const int per = c.C * c.HW;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (4 * q >= per) return;
+    const int row = c.step_idx ? *c.step_idx : c.step;
+    const float* tr = c.table + (size_t)row * DMN_TABLE_COLS;
+    const float ca = tr[1], cb = tr[2], cc = tr[3];
+    float z[4];
+    load_noise(c, (unsigned)tr[8], 1u, b, q, per, z);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int e = 4 * q + r;
+        if (e >= per) break;
+        const size_t xi = (size_t)b * per + e;
+        const float mean = ca * c.x[xi] + cb * c.net[xi];
+        c.x_out[xi] = mean + cc * z[r];
+        if (a.x_mean) a.x_mean[xi] = mean;
+        if (c.keep) c.keep[(size_t)row * c.keep_stride + xi] = a.keep_mean ? mean : mean + cc * z[r];
+    }
+}
+
+// Langevin pass 1: per-sample partial sums of net^2 and z^2. grid (slots, B); partials [B][slots][2]
+__global__ void __launch_bounds__(256) langevin_norms_kernel(const LangevinArgs a) {
+    __shared__ float sred[8];
+    const StepCommon& c = a.c;
+    const int b = blockIdx.y;
+    const int per = c.C * c.HW;
+    const int row = c.step_idx ? *c.step_idx : c.step;
+    const float* tr = c.table + (size_t)row * DMN_TABLE_COLS;
+    float sg = 0.f, sz = 0.f;
+    const int nq = (per + 3) / 4;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < nq; q += gridDim.x * 256) {
+        float z[4];
+        load_noise(c, (unsigned)tr[8], 2u + a.inner, b, q, per, z);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = 4 * q + r;
+            if (e >= per) break;
+            const float g = c.net[(size_t)b * per + e];
+            sg = fmaf(g, g, sg);
+            sz = fmaf(z[r], z[r], sz);
+        }
+    }
+    sg = wave_sum(sg);
+    sz = wave_sum(sz);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { sred[2 * wave] = sg; sred[2 * wave + 1] = sz; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tg = 0.f, tz = 0.f;
+        for (int w = 0; w < 4; ++w) { tg += sred[2 * w]; tz += sred[2 * w + 1]; }
+        float* dst = a.partials + ((size_t)b * gridDim.x + blockIdx.x) * 2;
+        dst[0] = tg;
+        dst[1] = tz;
+    }
+}
+
+// Langevin pass 2: step = k * (mean_b|z| / mean_b|score|)^2 ; x_mean = x + step*score ; x = x_mean + sqrt(2 step) z
+// Annealed Langevin (fixed step from the table) uses the same kernel with use_norms = 0.
+__global__ void __launch_bounds__(256) langevin_apply_kernel(const LangevinArgs a) {
+    __shared__ float sStep;
+    const StepCommon& c = a.c;
+    const int b = blockIdx.y;
+    const int per = c.C * c.HW;
+    const int row = c.step_idx ? *c.step_idx : c.step;
+    const float* tr = c.table + (size_t)row * DMN_TABLE_COLS;
+    const float sscale = tr[4];   // score = sscale * net
+    if (threadIdx.x == 0) {
+        float step;
+        if (a.use_norms) {
+            float gn = 0.f, zn = 0.f;
+            for (int i = 0; i < c.B; ++i) {
+                float tg = 0.f, tz = 0.f;
+                for (int s = 0; s < a.slots; ++s) {
+                    tg += a.partials[((size_t)i * a.slots + s) * 2];
+                    tz += a.partials[((size_t)i * a.slots + s) * 2 + 1];
+                }
+                gn += sqrtf(tg) * fabsf(sscale);
+                zn += sqrtf(tz);
+            }
+            gn /= (float)c.B;
+            zn /= (float)c.B;
+            const float ratio = a.snr * zn / gn;
+            step = ratio * ratio * 2.0f * tr[5];
+        } else {
+            step = tr[6];
+        }
+        sStep = step;
+    }
+    __syncthreads();
+    const float step = sStep;
+    const float nz = sqrtf(step * 2.0f);
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (4 * q >= per) return;
+    float z[4];
+    load_noise(c, (unsigned)tr[8], 2u + a.inner, b, q, per, z);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int e = 4 * q + r;
+        if (e >= per) break;
+        const size_t xi = (size_t)b * per + e;
+        const float mean = c.x[xi] + step * (sscale * c.net[xi]);
+        c.x_out[xi] = mean + nz * z[r];
+    }
+}
+
+// x = scale * N(0,1) (prior draw). grid (ceil(per/4/256), B)
+__global__ void __launch_bounds__(256) prior_kernel(float* x, int B, int per, unsigned long long seed, unsigned pstep,
+                                                     long long img_offset, float scale) {
+    const int b = blockIdx.y;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (4 * q >= per) return;
+    float z[4];
+    normal4(seed, pstep, 0u, (unsigned)(img_offset + b), (unsigned)q, z);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int e = 4 * q + r;
+        if (e < per) x[(size_t)b * per + e] = scale * z[r];
+    }
+}
+
+__global__ void advance_kernel(int* step_idx) { *step_idx += 1; }
+
+}  // namespace
+
+static dim3 step_grid(const StepCommon& c) { return dim3(((c.C * c.HW + 3) / 4 + 255) / 256, c.B); }
+
+int launch_ddpm_step(const DdpmStepArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(ddpm_step_kernel, step_grid(a.c), dim3(256), 0, s, a);
+    DMN_HIP_CHECK(hipGetLastError());
+    return DMN_OK;
+}
+int launch_affine_step(const AffineStepArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(affine_step_kernel, step_grid(a.c), dim3(256), 0, s, a);
+    DMN_HIP_CHECK(hipGetLastError());
+    return DMN_OK;
+}
+int langevin_slots(int per) {
+    int s = ((per + 3) / 4 + 255) / 256;
+    return s > 16 ? 16 : s;
+}
+int launch_langevin(LangevinArgs& a, hipStream_t s) {
+    const int per = a.c.C * a.c.HW;
+    a.slots = langevin_slots(per);
+    if (a.use_norms) {
+        hipLaunchKernelGGL(langevin_norms_kernel, dim3(a.slots, a.c.B), dim3(256), 0, s, a);
+        DMN_HIP_CHECK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(langevin_apply_kernel, step_grid(a.c), dim3(256), 0, s, a);
+    DMN_HIP_CHECK(hipGetLastError());
+    return DMN_OK;
+}
+int launch_prior(float* x, int B, int per, unsigned long long seed, unsigned pstep, long long img_offset, float scale,
+                 hipStream_t s) {
+    hipLaunchKernelGGL(prior_kernel, dim3(((per + 3) / 4 + 255) / 256, B), dim3(256), 0, s, x, B, per, seed, pstep,
+                       img_offset, scale);
+    DMN_HIP_CHECK(hipGetLastError());
+    return DMN_OK;
+}
+int launch_advance(int* step_idx, hipStream_t s) {
+    hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, s, step_idx);
+    DMN_HIP_CHECK(hipGetLastError());
+    return DMN_OK;
+}

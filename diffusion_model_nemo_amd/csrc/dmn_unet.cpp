@@ -1,0 +1,761 @@
+// U-Net handle, weight packing and forward orchestration behind the C-ABI (include/dmn.h).
+// Follows Unet.forward of the reference (diffusion_model_nemo/modules/unet.py:131-168) for
+// use_convnext=False; every tensor op is one of the gfx950 kernels declared in dmn_kernels.h.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <cmath>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/dmn.h"
+#include "dmn_kernels.h"
+#include "dmn_sampler.h"
+#include "dmn_unet_internal.h"
+
+// ---- error string ----------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+void dmn_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* dmn_last_error(void) { return g_err; }
+extern "C" const char* dmn_version(void) { return "dmn-hip 0.1 (gfx950)"; }
+
+// ---- host-side packing ---------------------------------------------------------------------------------
+static inline uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+static int upload(const void* host, size_t bytes, void** dev) {
+    DMN_HIP_CHECK(hipMalloc(dev, bytes));
+    DMN_HIP_CHECK(hipMemcpy(*dev, host, bytes, hipMemcpyHostToDevice));
+    return DMN_OK;
+}
+static int upload_f32(const float* host, size_t n, float** dev) { return upload(host, n * 4, (void**)dev); }
+
+// w: [Cout][Cin][kh][kw] (or [Cin][Cout][4][4] when transposed). Packed layout per phase:
+// [Cin/kch][Cout][ntaps][kch], tap = ky*kw + kx (conv) or a*2+b (transposed phase).
+int pack_conv(PackedConv& pc, int dtype, const float* w, const float* bias, int Cout, int Cin, int kh, int kw, int stride,
+              int pad, bool transposed) {
+    const int kch = dtype == DMN_F32 ? 16 : 32;
+    DMN_REQUIRE(Cin % kch == 0, DMN_ERR_WEIGHTS, "conv weight: Cin=%d not a multiple of %d", Cin, kch);
+    pc.Cin = Cin;
+    pc.Cout = Cout;
+    pc.stride = transposed ? 1 : stride;
+    pc.transposed = transposed;
+    std::vector<float> packed;
+    if (!transposed) {
+        pc.ntaps = kh * kw;
+        pc.ext_y = kh;
+        pc.ext_x = kw;
+        pc.nphase = 1;
+        pc.phase[0] = ConvPhase{pad, pad, 0, 0, 0};
+        for (int t = 0; t < pc.ntaps; ++t) {
+            pc.tap_dy[t] = (signed char)(t / kw);
+            pc.tap_dx[t] = (signed char)(t % kw);
+        }
+        packed.resize((size_t)Cin * Cout * pc.ntaps);
+        for (int ch = 0; ch < Cin / kch; ++ch)
+            for (int o = 0; o < Cout; ++o)
+                for (int t = 0; t < pc.ntaps; ++t)
+                    for (int k = 0; k < kch; ++k)
+                        packed[(((size_t)ch * Cout + o) * pc.ntaps + t) * kch + k] =
+                            w[((size_t)o * Cin + ch * kch + k) * pc.ntaps + t];
+    } else {
+        DMN_REQUIRE(kh == 4 && kw == 4 && stride == 2 && pad == 1, DMN_ERR_WEIGHTS, "transposed conv: only 4x4 s2 p1");
+        pc.ntaps = 4;
+        pc.ext_y = pc.ext_x = 2;
+        pc.nphase = 4;
+        for (int t = 0; t < 4; ++t) {
+            pc.tap_dy[t] = (signed char)(t / 2);
+            pc.tap_dx[t] = (signed char)(t % 2);
+        }
+        const size_t per_phase = (size_t)Cin * Cout * 4;
+        packed.resize(per_phase * 4);
+        for (int ph = 0; ph < 4; ++ph) {
+            const int py = ph / 2, px = ph % 2;
+            pc.phase[ph] = ConvPhase{1 - py, 1 - px, py, px, (long long)(per_phase * ph)};
+            for (int ch = 0; ch < Cin / kch; ++ch)
+                for (int o = 0; o < Cout; ++o)
+                    for (int t = 0; t < 4; ++t) {
+                        const int dy = t / 2, dx = t % 2;
+                        const int ky = py == 0 ? 3 - 2 * dy : 2 - 2 * dy;
+                        const int kx = px == 0 ? 3 - 2 * dx : 2 - 2 * dx;
+                        for (int k = 0; k < kch; ++k)
+                            packed[per_phase * ph + (((size_t)ch * Cout + o) * 4 + t) * kch + k] =
+                                w[(((size_t)(ch * kch + k) * Cout + o) * 4 + ky) * 4 + kx];
+                    }
+        }
+    }
+    int rc;
+    if (dtype == DMN_F32) {
+        if ((rc = upload(packed.data(), packed.size() * 4, &pc.w))) return rc;
+    } else {
+        std::vector<uint16_t> h(packed.size());
+        for (size_t i = 0; i < packed.size(); ++i) h[i] = f32_to_bf16_rne(packed[i]);
+        if ((rc = upload(h.data(), h.size() * 2, &pc.w))) return rc;
+    }
+    pc.bias = nullptr;
+    if (bias && (rc = upload_f32(bias, Cout, &pc.bias))) return rc;
+    return DMN_OK;
+}
+
+void free_conv(PackedConv& pc) {
+    if (pc.w) (void)hipFree(pc.w);
+    if (pc.bias) (void)hipFree(pc.bias);
+    pc.w = nullptr;
+    pc.bias = nullptr;
+}
+
+void conv_args_from(const PackedConv& pc, int dtype, ConvArgs& a, int B, int H, int W) {
+    memset(&a, 0, sizeof(a));
+    a.dtype = dtype;
+    a.B = B;
+    a.H = H;
+    a.W = W;
+    a.stride = pc.stride;
+    a.ntaps = pc.ntaps;
+    memcpy(a.tap_dy, pc.tap_dy, sizeof(a.tap_dy));
+    memcpy(a.tap_dx, pc.tap_dx, sizeof(a.tap_dx));
+    a.ext_y = pc.ext_y;
+    a.ext_x = pc.ext_x;
+    a.nphase = pc.nphase;
+    for (int i = 0; i < 4; ++i) a.phase[i] = pc.phase[i];
+    a.w = pc.w;
+    a.bias = pc.bias;
+    a.Cout = pc.Cout;
+    if (pc.transposed) {
+        a.Ho = H;
+        a.Wo = W;
+        a.out_H = 2 * H;
+        a.out_W = 2 * W;
+        a.out_sy = a.out_sx = 2;
+    } else {
+        const int pad = pc.phase[0].pad_y;
+        a.Ho = (H + 2 * pad - pc.ext_y) / pc.stride + 1;
+        a.Wo = (W + 2 * pad - pc.ext_x) / pc.stride + 1;
+        a.out_H = a.Ho;
+        a.out_W = a.Wo;
+        a.out_sy = a.out_sx = 1;
+    }
+}
+
+// ---- workspace arena: first-fit blocks over the caller's buffer -------------------------------------
+struct Arena {
+    struct Blk {
+        size_t off, size;
+        bool used;
+    };
+    char* base = nullptr;
+    size_t cap = 0, high = 0;
+    bool dry = false;
+    std::vector<Blk> blks;
+    void reset(void* b, size_t c, bool d) {
+        base = (char*)b;
+        cap = c;
+        dry = d;
+        high = 0;
+        blks.clear();
+        blks.push_back(Blk{0, dry ? (size_t)1 << 60 : c, false});
+    }
+    void* alloc(size_t n) {
+        n = (n + 255) & ~(size_t)255;
+        for (size_t i = 0; i < blks.size(); ++i) {
+            if (!blks[i].used && blks[i].size >= n) {
+                if (blks[i].size > n) {
+                    Blk rest{blks[i].off + n, blks[i].size - n, false};
+                    blks[i].size = n;
+                    blks.insert(blks.begin() + i + 1, rest);
+                }
+                blks[i].used = true;
+                if (blks[i].off + n > high) high = blks[i].off + n;
+                return base + blks[i].off;   // in a dry run only the offsets matter
+            }
+        }
+        return nullptr;
+    }
+    void release(void* p) {
+        if (!p) return;
+        const size_t off = (char*)p - base;
+        for (size_t i = 0; i < blks.size(); ++i)
+            if (blks[i].off == off && blks[i].used) {
+                blks[i].used = false;
+                if (i + 1 < blks.size() && !blks[i + 1].used) {
+                    blks[i].size += blks[i + 1].size;
+                    blks.erase(blks.begin() + i + 1);
+                }
+                if (i > 0 && !blks[i - 1].used) {
+                    blks[i - 1].size += blks[i].size;
+                    blks.erase(blks.begin() + i);
+                }
+                return;
+            }
+    }
+};
+
+struct Act {            // an NHWC activation + optional statistics of it
+    void* p = nullptr;
+    int C = 0, H = 0, W = 0;
+    float* stats = nullptr;
+    int sG = 0, sSlots = 0;
+};
+
+struct Fwd {
+    DmnUnet* u;
+    Arena ar;
+    hipStream_t s;
+    int B;
+    bool dry;
+    int rc = DMN_OK;
+    size_t esz() const { return u->cfg.dtype == DMN_F32 ? 4 : 2; }
+    void* alloc(size_t n) {
+        void* p = ar.alloc(n);
+        if (!p && rc == DMN_OK) {
+            dmn_set_error("workspace too small (need more than %zu bytes)", ar.cap);
+            rc = DMN_ERR_WORKSPACE;
+        }
+        return p;
+    }
+    Act new_act(int C, int H, int W) {
+        Act a;
+        a.C = C;
+        a.H = H;
+        a.W = W;
+        a.p = alloc((size_t)B * H * W * C * esz());
+        return a;
+    }
+    float* new_stats(int G, int slots) { return (float*)alloc((size_t)B * G * slots * 2 * 4); }
+    void free_act(Act& a) {
+        ar.release(a.p);
+        ar.release(a.stats);
+        a.p = nullptr;
+        a.stats = nullptr;
+    }
+    bool ok() const { return rc == DMN_OK; }
+    void run(int r) {
+        if (rc == DMN_OK && r != DMN_OK) rc = r;
+    }
+};
+
+static NormIn norm_in(const Act& a, const float* gamma, const float* beta, int B, int silu, const float* tbias, int tb_stride) {
+    NormIn n;
+    memset(&n, 0, sizeof(n));
+    n.stats = a.stats;
+    n.G = a.sG;
+    n.slots = a.sSlots;
+    n.inv_count = 1.0f / ((float)(a.C / a.sG) * a.H * a.W);
+    n.gamma = gamma;
+    n.beta = beta;
+    n.tbias = tbias;
+    n.tb_stride = tb_stride;
+    n.silu = silu;
+    return n;
+}
+
+// conv with optional: second source, input normalisation, residual, output statistics
+static Act do_conv(Fwd& f, const PackedConv& pc, const Act& in0, const Act* in1, const NormIn* pro, const Act* res, int epiG) {
+    ConvArgs a;
+    conv_args_from(pc, f.u->cfg.dtype, a, f.B, in0.H, in0.W);
+    a.in0 = in0.p;
+    a.C0 = in0.C;
+    if (in1) {
+        a.in1 = in1->p;
+        a.C1 = in1->C;
+    }
+    if (pro) a.pro = *pro;
+    Act out = f.new_act(pc.Cout, a.out_H, a.out_W);
+    a.out = out.p;
+    if (res) a.res = res->p;
+    if (epiG > 0) {
+        a.epi.G = epiG;
+        out.sG = epiG;
+        out.sSlots = conv_epi_slots(a);
+        out.stats = f.new_stats(epiG, out.sSlots);
+        a.epi.stats = out.stats;
+    }
+    if (f.ok() && !f.dry) f.run(launch_conv(a, f.s));
+    return out;
+}
+
+// ResnetBlock (parts/convnext.py:78-86). statsG > 0: also produce GroupNorm(statsG) statistics of the output.
+static Act resblock(Fwd& f, const ResBlockW& w, Act& x, Act* x2, const float* tb, int tb_stride, int statsG) {
+    const int G = f.u->cfg.groups;
+    Act h1 = do_conv(f, w.c1, x, x2, nullptr, nullptr, G);
+    NormIn n1 = norm_in(h1, w.g1, w.b1, f.B, 1, w.tb_off >= 0 ? tb + w.tb_off : nullptr, tb_stride);
+    Act h2 = do_conv(f, w.c2, h1, nullptr, &n1, nullptr, G);
+    f.free_act(h1);
+    Act r;
+    const Act* resp = &x;
+    if (w.has_res) {
+        r = do_conv(f, w.res, x, x2, nullptr, nullptr, 0);
+        resp = &r;
+    }
+    Act out = f.new_act(h2.C, h2.H, h2.W);
+    NormApplyArgs na;
+    memset(&na, 0, sizeof(na));
+    na.dtype = f.u->cfg.dtype;
+    na.in = h2.p;
+    na.out = out.p;
+    na.res = resp->p;
+    na.B = f.B;
+    na.HW = h2.H * h2.W;
+    na.C = h2.C;
+    na.norm = norm_in(h2, w.g2, w.b2, f.B, 1, nullptr, 0);
+    if (statsG > 0) {
+        out.sG = statsG;
+        out.sSlots = norm_apply_slots(na.HW, na.C);
+        out.stats = f.new_stats(statsG, out.sSlots);
+        na.epi.stats = out.stats;
+        na.epi.G = statsG;
+    }
+    if (f.ok() && !f.dry) f.run(launch_norm_apply(na, f.s));
+    f.free_act(h2);
+    if (w.has_res) f.free_act(r);
+    return out;
+}
+
+// Residual(PreNorm(dim, LinearAttention(dim))) (utils.py:68-93, parts/mha.py:44-59). x must carry GN(1) statistics.
+static Act lin_attn(Fwd& f, const AttnW& w, Act& x) {
+    const DmnUnetCfg& c = f.u->cfg;
+    const int hidden = c.heads * c.dim_head;
+    NormIn pn = norm_in(x, w.ng, w.nb, f.B, 0, nullptr, 0);
+    Act qkv = do_conv(f, w.qkv, x, nullptr, &pn, nullptr, 0);
+    Act la = f.new_act(hidden, x.H, x.W);
+    LinAttnArgs aa;
+    memset(&aa, 0, sizeof(aa));
+    aa.dtype = c.dtype;
+    aa.qkv = qkv.p;
+    aa.out = la.p;
+    aa.B = f.B;
+    aa.n = x.H * x.W;
+    aa.heads = c.heads;
+    aa.d = c.dim_head;
+    aa.splits = linear_attention_splits(aa.n);
+    float* part = (float*)f.alloc((size_t)f.B * c.heads * aa.splits * (c.dim_head * c.dim_head + 2 * c.dim_head) * 4);
+    aa.ctx_part = part;
+    if (f.ok() && !f.dry) f.run(launch_linear_attention(aa, f.s));
+    f.free_act(qkv);
+    f.ar.release(part);
+    Act y = do_conv(f, w.out, la, nullptr, nullptr, nullptr, 1);
+    f.free_act(la);
+    Act out = f.new_act(x.C, x.H, x.W);
+    NormApplyArgs na;
+    memset(&na, 0, sizeof(na));
+    na.dtype = c.dtype;
+    na.in = y.p;
+    na.out = out.p;
+    na.res = x.p;
+    na.B = f.B;
+    na.HW = x.H * x.W;
+    na.C = x.C;
+    na.norm = norm_in(y, w.og, w.ob, f.B, 0, nullptr, 0);
+    if (f.ok() && !f.dry) f.run(launch_norm_apply(na, f.s));
+    f.free_act(y);
+    return out;
+}
+
+// Residual(PreNorm(dim, Attention(dim))) (parts/mha.py:16-30)
+static Act full_attn(Fwd& f, const AttnW& w, Act& x) {
+    const DmnUnetCfg& c = f.u->cfg;
+    const int hidden = c.heads * c.dim_head;
+    NormIn pn = norm_in(x, w.ng, w.nb, f.B, 0, nullptr, 0);
+    Act qkv = do_conv(f, w.qkv, x, nullptr, &pn, nullptr, 0);
+    Act o = f.new_act(hidden, x.H, x.W);
+    AttnArgs aa;
+    memset(&aa, 0, sizeof(aa));
+    aa.dtype = c.dtype;
+    aa.qkv = qkv.p;
+    aa.out = o.p;
+    aa.B = f.B;
+    aa.n = x.H * x.W;
+    aa.heads = c.heads;
+    aa.d = c.dim_head;
+    if (f.ok() && !f.dry) f.run(launch_attention(aa, f.s));
+    f.free_act(qkv);
+    Act out = do_conv(f, w.out, o, nullptr, nullptr, &x, 0);
+    f.free_act(o);
+    return out;
+}
+
+// The whole forward. `t`/`t_is_float` or (`table`, `step_idx`) provide the time label.
+int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float, const float* table, const int* step_idx,
+                      float* out, int B, int H, int W, void* ws, size_t ws_bytes, hipStream_t s, bool dry, size_t* high) {
+    const DmnUnetCfg& c = u->cfg;
+    DMN_REQUIRE(u->loaded || dry, DMN_ERR_WEIGHTS, "dmn_unet_forward: weights not loaded");
+    const int nlev = c.n_mults;
+    const int div = 1 << (nlev - 1);
+    DMN_REQUIRE(B >= 1 && H % div == 0 && W % div == 0 && H >= div && W >= div, DMN_ERR_INVALID,
+                "unet: image %dx%d must be a multiple of %d", H, W, div);
+    Fwd f;
+    f.u = u;
+    f.s = s;
+    f.B = B;
+    f.dry = dry;
+    f.ar.reset(ws, ws_bytes, dry);
+
+    float* tb = nullptr;
+    if (c.with_time_emb) {
+        tb = (float*)f.alloc((size_t)B * u->tb_total * 4);
+        TimeArgs ta;
+        memset(&ta, 0, sizeof(ta));
+        ta.t = t;
+        ta.t_is_float = t_is_float;
+        ta.table = table;
+        ta.step_idx = step_idx;
+        ta.table_cols = DMN_TABLE_COLS;
+        ta.label_col = 0;
+        ta.B = B;
+        ta.dim = c.dim;
+        ta.freqs = u->freqs;
+        ta.w1 = u->tw1; ta.b1 = u->tb1;
+        ta.w2 = u->tw2; ta.b2 = u->tb2;
+        ta.wb = u->twb; ta.bb = u->tbb;
+        ta.nout = u->tb_total;
+        ta.out = tb;
+        if (f.ok() && !dry) f.run(launch_time_mlp(ta, s));
+    }
+    const int tbs = u->tb_total;
+
+    Act cur = f.new_act(c.dim, H, W);
+    {
+        IngestArgs ia;
+        memset(&ia, 0, sizeof(ia));
+        ia.dtype = c.dtype;
+        ia.x = x;
+        ia.w = u->init_w;
+        ia.bias = u->init_b;
+        ia.out = cur.p;
+        ia.B = B; ia.Cin = c.channels; ia.H = H; ia.W = W; ia.Cout = c.dim;
+        if (f.ok() && !dry) f.run(launch_ingest(ia, s));
+    }
+
+    std::vector<Act> skips;
+    for (int i = 0; i < nlev; ++i) {
+        Act a1 = resblock(f, u->downs[i].rb[0], cur, nullptr, tb, tbs, 0);
+        f.free_act(cur);
+        Act a2 = resblock(f, u->downs[i].rb[1], a1, nullptr, tb, tbs, 1);
+        f.free_act(a1);
+        Act a3 = lin_attn(f, u->downs[i].attn, a2);
+        f.free_act(a2);
+        if (i < nlev - 1) {
+            cur = do_conv(f, u->downs[i].resample, a3, nullptr, nullptr, nullptr, 0);
+            if (i == 0) f.free_act(a3);   // the top-level skip is never consumed (unet.py:95: ups uses in_out[1:])
+            else skips.push_back(a3);
+        } else {
+            skips.push_back(a3);
+            cur = a3;                     // Identity downsample: the bottleneck reads the skip tensor itself
+        }
+    }
+    {
+        Act m1 = resblock(f, u->mid1, cur, nullptr, tb, tbs, 1);
+        Act m2 = full_attn(f, u->mid_attn, m1);
+        f.free_act(m1);
+        cur = resblock(f, u->mid2, m2, nullptr, tb, tbs, 0);
+        f.free_act(m2);
+    }
+    for (int i = 0; i < nlev - 1; ++i) {
+        Act sk = skips.back();
+        skips.pop_back();
+        Act a1 = resblock(f, u->ups[i].rb[0], cur, &sk, tb, tbs, 0);
+        f.free_act(cur);
+        f.free_act(sk);
+        Act a2 = resblock(f, u->ups[i].rb[1], a1, nullptr, tb, tbs, 1);
+        f.free_act(a1);
+        Act a3 = lin_attn(f, u->ups[i].attn, a2);
+        f.free_act(a2);
+        cur = do_conv(f, u->ups[i].resample, a3, nullptr, nullptr, nullptr, 0);
+        f.free_act(a3);
+    }
+    {
+        Act fin = resblock(f, u->final_rb, cur, nullptr, nullptr, 0, c.tail_norm ? c.groups : 0);
+        f.free_act(cur);
+        EgressArgs ea;
+        memset(&ea, 0, sizeof(ea));
+        ea.dtype = c.dtype;
+        ea.in = fin.p;
+        if (c.tail_norm) ea.norm = norm_in(fin, u->tail_g, u->tail_b, B, 1, nullptr, 0);
+        ea.w = u->tail_w;
+        ea.bias = u->tail_bias;
+        ea.out = out;
+        ea.B = B; ea.HW = H * W; ea.C = c.dim; ea.Cout = c.out_dim;
+        if (f.ok() && !dry) f.run(launch_egress(ea, s));
+        f.free_act(fin);
+    }
+    if (high) *high = f.ar.high;
+    return f.rc;
+}
+
+// ---- weights ---------------------------------------------------------------------------------------------
+struct ParamMap {
+    std::map<std::string, const DmnTensorDesc*> m;
+    const DmnTensorDesc* get(const std::string& n, int ndim, const int64_t* shape) const {
+        auto it = m.find(n);
+        if (it == m.end()) {
+            dmn_set_error("missing parameter '%s'", n.c_str());
+            return nullptr;
+        }
+        const DmnTensorDesc* d = it->second;
+        bool ok = d->ndim == ndim;
+        for (int i = 0; ok && i < ndim; ++i) ok = d->shape[i] == shape[i];
+        if (!ok) {
+            dmn_set_error("parameter '%s' has the wrong shape", n.c_str());
+            return nullptr;
+        }
+        return d;
+    }
+};
+
+#define GETP(var, name, ...)                                  \
+    const DmnTensorDesc* var;                                 \
+    {                                                         \
+        const int64_t _s[] = {__VA_ARGS__};                   \
+        var = pm.get(name, (int)(sizeof(_s) / 8), _s);        \
+        if (!var) return DMN_ERR_WEIGHTS;                     \
+    }
+
+static int load_vec(const ParamMap& pm, const std::string& name, int n, float** dev) {
+    GETP(d, name, n);
+    return upload_f32(d->data, n, dev);
+}
+
+static int load_conv(const ParamMap& pm, int dtype, const std::string& name, int Cout, int Cin, int k, int stride, int pad,
+                     bool bias, bool transposed, PackedConv& pc) {
+    const DmnTensorDesc* w;
+    {
+        const int64_t s0[] = {Cout, Cin, k, k}, s1[] = {Cin, Cout, k, k};
+        w = pm.get(name + ".weight", 4, transposed ? s1 : s0);
+        if (!w) return DMN_ERR_WEIGHTS;
+    }
+    const float* b = nullptr;
+    if (bias) {
+        GETP(bd, name + ".bias", Cout);
+        b = bd->data;
+    }
+    return pack_conv(pc, dtype, w->data, b, Cout, Cin, k, k, stride, pad, transposed);
+}
+
+static int load_resblock(const ParamMap& pm, DmnUnet* u, const std::string& pre, int cin, int cout, bool time,
+                         std::vector<float>& twb, std::vector<float>& tbb, ResBlockW& rb) {
+    const int dtype = u->cfg.dtype;
+    int rc;
+    rb.tb_off = -1;
+    if (time && u->cfg.with_time_emb) {
+        const int td = 4 * u->cfg.dim;
+        GETP(w, pre + ".mlp.1.weight", cout, td);
+        GETP(b, pre + ".mlp.1.bias", cout);
+        rb.tb_off = (int)tbb.size();
+        twb.insert(twb.end(), w->data, w->data + (size_t)cout * td);
+        tbb.insert(tbb.end(), b->data, b->data + cout);
+    }
+    if ((rc = load_conv(pm, dtype, pre + ".block1.proj", cout, cin, 3, 1, 1, true, false, rb.c1))) return rc;
+    if ((rc = load_vec(pm, pre + ".block1.norm.weight", cout, &rb.g1))) return rc;
+    if ((rc = load_vec(pm, pre + ".block1.norm.bias", cout, &rb.b1))) return rc;
+    if ((rc = load_conv(pm, dtype, pre + ".block2.proj", cout, cout, 3, 1, 1, true, false, rb.c2))) return rc;
+    if ((rc = load_vec(pm, pre + ".block2.norm.weight", cout, &rb.g2))) return rc;
+    if ((rc = load_vec(pm, pre + ".block2.norm.bias", cout, &rb.b2))) return rc;
+    rb.has_res = cin != cout;
+    if (rb.has_res && (rc = load_conv(pm, dtype, pre + ".res_conv", cout, cin, 1, 1, 0, true, false, rb.res))) return rc;
+    return DMN_OK;
+}
+
+static int load_attn(const ParamMap& pm, DmnUnet* u, const std::string& pre, int c, bool linear, AttnW& a) {
+    const int dtype = u->cfg.dtype;
+    const int hidden = u->cfg.heads * u->cfg.dim_head;
+    int rc;
+    if ((rc = load_vec(pm, pre + ".fn.norm.weight", c, &a.ng))) return rc;
+    if ((rc = load_vec(pm, pre + ".fn.norm.bias", c, &a.nb))) return rc;
+    if ((rc = load_conv(pm, dtype, pre + ".fn.fn.to_qkv", 3 * hidden, c, 1, 1, 0, false, false, a.qkv))) return rc;
+    if (linear) {
+        if ((rc = load_conv(pm, dtype, pre + ".fn.fn.to_out.0", c, hidden, 1, 1, 0, true, false, a.out))) return rc;
+        if ((rc = load_vec(pm, pre + ".fn.fn.to_out.1.weight", c, &a.og))) return rc;
+        if ((rc = load_vec(pm, pre + ".fn.fn.to_out.1.bias", c, &a.ob))) return rc;
+    } else {
+        if ((rc = load_conv(pm, dtype, pre + ".fn.fn.to_out", c, hidden, 1, 1, 0, true, false, a.out))) return rc;
+    }
+    return DMN_OK;
+}
+
+static void free_rb(ResBlockW& rb) {
+    free_conv(rb.c1);
+    free_conv(rb.c2);
+    free_conv(rb.res);
+    float** v[] = {&rb.g1, &rb.b1, &rb.g2, &rb.b2};
+    for (auto p : v) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+}
+static void free_attn(AttnW& a) {
+    free_conv(a.qkv);
+    free_conv(a.out);
+    float** v[] = {&a.ng, &a.nb, &a.og, &a.ob};
+    for (auto p : v) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+}
+static void free_weights(DmnUnet* u) {
+    for (auto& l : u->downs) { free_rb(l.rb[0]); free_rb(l.rb[1]); free_attn(l.attn); free_conv(l.resample); }
+    for (auto& l : u->ups) { free_rb(l.rb[0]); free_rb(l.rb[1]); free_attn(l.attn); free_conv(l.resample); }
+    free_rb(u->mid1);
+    free_rb(u->mid2);
+    free_rb(u->final_rb);
+    free_attn(u->mid_attn);
+    float** v[] = {&u->freqs, &u->tw1, &u->tb1, &u->tw2, &u->tb2, &u->twb, &u->tbb, &u->init_w, &u->init_b,
+                   &u->tail_g, &u->tail_b, &u->tail_w, &u->tail_bias};
+    for (auto p : v) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    u->loaded = false;
+}
+
+extern "C" int dmn_unet_create(const DmnUnetCfg* cfg, DmnUnet** out) {
+    DMN_REQUIRE(cfg && out, DMN_ERR_INVALID, "dmn_unet_create: null argument");
+    DMN_REQUIRE(cfg->n_mults >= 1 && cfg->n_mults <= DMN_MAX_MULTS, DMN_ERR_INVALID, "n_mults=%d", cfg->n_mults);
+    DMN_REQUIRE(cfg->dtype == DMN_F32 || cfg->dtype == DMN_BF16, DMN_ERR_INVALID, "dtype=%d", cfg->dtype);
+    DMN_REQUIRE(cfg->dim % 32 == 0 && cfg->dim <= 64, DMN_ERR_LIMIT, "dim=%d must be 32 or 64", cfg->dim);
+    DMN_REQUIRE(cfg->dim_head == 32 && cfg->heads >= 1, DMN_ERR_INVALID, "dim_head=%d (only 32 supported)", cfg->dim_head);
+    DMN_REQUIRE(cfg->channels >= 1 && cfg->channels <= 4 && cfg->out_dim >= 1 && cfg->out_dim <= 8, DMN_ERR_LIMIT,
+                "channels=%d out_dim=%d", cfg->channels, cfg->out_dim);
+    DMN_REQUIRE(cfg->groups >= 1 && cfg->dim % cfg->groups == 0 && (cfg->dim / cfg->groups) % 4 == 0, DMN_ERR_INVALID,
+                "groups=%d needs >= 4 channels per group", cfg->groups);
+    for (int i = 0; i < cfg->n_mults; ++i)
+        DMN_REQUIRE(cfg->dim_mults[i] >= 1 && (i == 0 || true), DMN_ERR_INVALID, "dim_mults[%d]=%d", i, cfg->dim_mults[i]);
+    int rc = conv_init_attributes();
+    if (rc) return rc;
+    DmnUnet* u = new DmnUnet();
+    u->cfg = *cfg;
+    u->downs.resize(cfg->n_mults);
+    u->ups.resize(cfg->n_mults - 1);
+    *out = u;
+    return DMN_OK;
+}
+
+extern "C" void dmn_unet_destroy(DmnUnet* u) {
+    if (!u) return;
+    if (u->graph_exec) (void)hipGraphExecDestroy(u->graph_exec);
+    free_weights(u);
+    delete u;
+}
+
+extern "C" int dmn_unet_load_weights(DmnUnet* u, const DmnTensorDesc* params, int n) {
+    DMN_REQUIRE(u && params && n > 0, DMN_ERR_INVALID, "dmn_unet_load_weights: null argument");
+    DMN_HIP_CHECK(hipDeviceSynchronize());
+    free_weights(u);
+    if (u->graph_exec) {
+        (void)hipGraphExecDestroy(u->graph_exec);
+        u->graph_exec = nullptr;
+    }
+    ParamMap pm;
+    for (int i = 0; i < n; ++i) pm.m[params[i].name] = &params[i];
+    const DmnUnetCfg& c = u->cfg;
+    const int dim = c.dim, td = 4 * dim;
+    int rc;
+    std::vector<int> dims(1, dim);
+    for (int i = 0; i < c.n_mults; ++i) dims.push_back(dim * c.dim_mults[i]);
+    std::vector<float> twb, tbb;
+
+    {   // ingest weights stay fp32 [Cout][Cin][7][7]
+        GETP(w, "init_conv.weight", dim, c.channels, 7, 7);
+        GETP(b, "init_conv.bias", dim);
+        if ((rc = upload_f32(w->data, (size_t)dim * c.channels * 49, &u->init_w))) return rc;
+        if ((rc = upload_f32(b->data, dim, &u->init_b))) return rc;
+    }
+    if (c.with_time_emb) {
+        GETP(w1, "time_mlp.1.weight", td, dim);
+        GETP(b1, "time_mlp.1.bias", td);
+        GETP(w2, "time_mlp.3.weight", td, td);
+        GETP(b2, "time_mlp.3.bias", td);
+        if ((rc = upload_f32(w1->data, (size_t)td * dim, &u->tw1))) return rc;
+        if ((rc = upload_f32(b1->data, td, &u->tb1))) return rc;
+        if ((rc = upload_f32(w2->data, (size_t)td * td, &u->tw2))) return rc;
+        if ((rc = upload_f32(b2->data, td, &u->tb2))) return rc;
+        // exp(arange(half) * -(ln 1e4 / (half-1))) evaluated in float32 like the reference
+        // (parts/positional_encoding.py:13-15)
+        const int half = dim / 2;
+        std::vector<float> fr(half);
+        const float k = (float)(std::log(10000.0) / (half - 1));
+        for (int i = 0; i < half; ++i) fr[i] = expf((float)i * -k);
+        if ((rc = upload_f32(fr.data(), half, &u->freqs))) return rc;
+    }
+    const int nlev = c.n_mults;
+    for (int i = 0; i < nlev; ++i) {
+        const int ci = dims[i], co = dims[i + 1];
+        const std::string p = "downs." + std::to_string(i);
+        if ((rc = load_resblock(pm, u, p + ".0", ci, co, true, twb, tbb, u->downs[i].rb[0]))) return rc;
+        if ((rc = load_resblock(pm, u, p + ".1", co, co, true, twb, tbb, u->downs[i].rb[1]))) return rc;
+        if ((rc = load_attn(pm, u, p + ".2", co, true, u->downs[i].attn))) return rc;
+        if (i < nlev - 1 && (rc = load_conv(pm, c.dtype, p + ".3", co, co, 4, 2, 1, true, false, u->downs[i].resample))) return rc;
+    }
+    const int mid = dims[nlev];
+    if ((rc = load_resblock(pm, u, "mid_block1", mid, mid, true, twb, tbb, u->mid1))) return rc;
+    if ((rc = load_attn(pm, u, "mid_attn", mid, false, u->mid_attn))) return rc;
+    if ((rc = load_resblock(pm, u, "mid_block2", mid, mid, true, twb, tbb, u->mid2))) return rc;
+    for (int i = 0; i < nlev - 1; ++i) {
+        // reversed(in_out[1:]): level j = nlev-1-i has (dim_in, dim_out) = (dims[j], dims[j+1])
+        const int j = nlev - 1 - i;
+        const int ci = dims[j], co = dims[j + 1];
+        const std::string p = "ups." + std::to_string(i);
+        if ((rc = load_resblock(pm, u, p + ".0", co * 2, ci, true, twb, tbb, u->ups[i].rb[0]))) return rc;
+        if ((rc = load_resblock(pm, u, p + ".1", ci, ci, true, twb, tbb, u->ups[i].rb[1]))) return rc;
+        if ((rc = load_attn(pm, u, p + ".2", ci, true, u->ups[i].attn))) return rc;
+        if ((rc = load_conv(pm, c.dtype, p + ".3", ci, ci, 4, 2, 1, true, true, u->ups[i].resample))) return rc;
+    }
+    if ((rc = load_resblock(pm, u, "final_conv.0", dim, dim, false, twb, tbb, u->final_rb))) return rc;
+    {
+        const std::string last = c.tail_norm ? "final_conv.3" : "final_conv.1";
+        if (c.tail_norm) {
+            if ((rc = load_vec(pm, "final_conv.1.weight", dim, &u->tail_g))) return rc;
+            if ((rc = load_vec(pm, "final_conv.1.bias", dim, &u->tail_b))) return rc;
+        }
+        GETP(w, last + ".weight", c.out_dim, dim, 1, 1);
+        GETP(b, last + ".bias", c.out_dim);
+        if ((rc = upload_f32(w->data, (size_t)c.out_dim * dim, &u->tail_w))) return rc;
+        if ((rc = upload_f32(b->data, c.out_dim, &u->tail_bias))) return rc;
+    }
+    u->tb_total = (int)tbb.size();
+    if (u->tb_total > 0) {
+        if ((rc = upload_f32(twb.data(), twb.size(), &u->twb))) return rc;
+        if ((rc = upload_f32(tbb.data(), tbb.size(), &u->tbb))) return rc;
+    }
+    u->loaded = true;
+    return DMN_OK;
+}
+
+extern "C" int dmn_unet_workspace_bytes(const DmnUnet* u, int B, int H, int W, size_t* bytes) {
+    DMN_REQUIRE(u && bytes, DMN_ERR_INVALID, "dmn_unet_workspace_bytes: null argument");
+    size_t high = 0;
+    DmnUnet* uu = const_cast<DmnUnet*>(u);
+    int saved_total = uu->tb_total;
+    if (!u->loaded) {   // time-bias width is known from the configuration alone
+        int total = 0;
+        std::vector<int> dims(1, u->cfg.dim);
+        for (int i = 0; i < u->cfg.n_mults; ++i) dims.push_back(u->cfg.dim * u->cfg.dim_mults[i]);
+        for (int i = 0; i < u->cfg.n_mults; ++i) total += 2 * dims[i + 1];
+        total += 2 * dims[u->cfg.n_mults];
+        for (int i = 0; i < u->cfg.n_mults - 1; ++i) total += 2 * dims[u->cfg.n_mults - 1 - i];
+        uu->tb_total = total;
+    }
+    int rc = unet_forward_impl(uu, nullptr, nullptr, 0, nullptr, nullptr, nullptr, B, H, W, nullptr, 0, nullptr, true, &high);
+    uu->tb_total = saved_total;
+    if (rc) return rc;
+    *bytes = high + 4096;
+    return DMN_OK;
+}
+
+extern "C" int dmn_unet_forward(DmnUnet* u, const float* x, const void* t, int t_is_float, float* out, int B, int H, int W,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+    DMN_REQUIRE(u && x && t && out && workspace, DMN_ERR_INVALID, "dmn_unet_forward: null argument");
+    return unet_forward_impl(u, x, t, t_is_float, nullptr, nullptr, out, B, H, W, workspace, workspace_bytes,
+                             (hipStream_t)stream, false, nullptr);
+}

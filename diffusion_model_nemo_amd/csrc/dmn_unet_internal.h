@@ -1,0 +1,70 @@
+// Private layout of the DmnUnet handle (weights packed for the gfx950 kernels).
+#pragma once
+#include <vector>
+
+#include "../../include/dmn.h"
+#include "dmn_kernels.h"
+
+struct PackedConv {
+    void* w = nullptr;       // device, packed [phase][Cin/kch][Cout][ntaps][kch] in the network dtype
+    float* bias = nullptr;   // device fp32 [Cout] or nullptr
+    int Cin = 0, Cout = 0, stride = 1, ntaps = 0, ext_y = 0, ext_x = 0, nphase = 1;
+    bool transposed = false;
+    signed char tap_dy[16] = {0}, tap_dx[16] = {0};
+    ConvPhase phase[4] = {};
+};
+
+struct ResBlockW {
+    PackedConv c1, c2, res;
+    float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
+    bool has_res = false;
+    int tb_off = -1;         // offset of this block's time bias inside the per-sample bias vector
+};
+
+struct AttnW {
+    float *ng = nullptr, *nb = nullptr;   // PreNorm GroupNorm(1)
+    PackedConv qkv, out;
+    float *og = nullptr, *ob = nullptr;   // LinearAttention's GroupNorm(1) after to_out
+};
+
+struct LevelW {
+    ResBlockW rb[2];
+    AttnW attn;
+    PackedConv resample;     // Downsample conv or Upsample transposed conv
+};
+
+struct SampleKey {           // identifies a captured step graph
+    const void* x; const void* table; const void* ws; const void* keep; const void* xmean;
+    int kind, B, H, W, flags, nsteps;
+    unsigned long long seed;
+    long long img_offset;
+    float snr;
+    bool operator==(const SampleKey& o) const {
+        return x == o.x && table == o.table && ws == o.ws && keep == o.keep && xmean == o.xmean && kind == o.kind &&
+               B == o.B && H == o.H && W == o.W && flags == o.flags && nsteps == o.nsteps && seed == o.seed &&
+               img_offset == o.img_offset && snr == o.snr;
+    }
+};
+
+struct DmnUnet {
+    DmnUnetCfg cfg;
+    bool loaded = false;
+    std::vector<LevelW> downs, ups;
+    ResBlockW mid1, mid2, final_rb;
+    AttnW mid_attn;
+    // time path (fp32)
+    float *freqs = nullptr, *tw1 = nullptr, *tb1 = nullptr, *tw2 = nullptr, *tb2 = nullptr, *twb = nullptr, *tbb = nullptr;
+    int tb_total = 0;
+    // ingest / egress (fp32)
+    float *init_w = nullptr, *init_b = nullptr, *tail_g = nullptr, *tail_b = nullptr, *tail_w = nullptr, *tail_bias = nullptr;
+    // cached step graph of the sampling loops
+    hipGraphExec_t graph_exec = nullptr;
+    SampleKey graph_key = {};
+};
+
+int pack_conv(PackedConv& pc, int dtype, const float* w, const float* bias, int Cout, int Cin, int kh, int kw, int stride,
+              int pad, bool transposed);
+void free_conv(PackedConv& pc);
+void conv_args_from(const PackedConv& pc, int dtype, ConvArgs& a, int B, int H, int W);
+int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float, const float* table, const int* step_idx,
+                      float* out, int B, int H, int W, void* ws, size_t ws_bytes, hipStream_t s, bool dry, size_t* high);

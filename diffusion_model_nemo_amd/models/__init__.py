@@ -1,0 +1,5 @@
+"""Host-side mirror of `diffusion_model_nemo.models` (the classes the three example directories drive)."""
+from .ddpm import AbstractDiffusionModel, DDPM, ImprovedDDPM
+from .score_sde import ScoreSDE
+
+__all__ = ["AbstractDiffusionModel", "DDPM", "ImprovedDDPM", "ScoreSDE"]

@@ -1,0 +1,98 @@
+"""`DDPM` / `ImprovedDDPM` model wrappers with the reference's configuration surface.
+
+Mirror of diffusion_model_nemo/models/abstract_diffusion_model.py:26-135, models/ddpm.py:23-109 and
+models/improved_ddpm.py:21-25, without NeMo / Lightning (neither is needed to sample): the constructor takes the
+`model:` section of the reference's YAML (a mapping with `_target_` entries) and instantiates network, sampler and
+loss exactly like `ModelPT.__init__` + `hydra.utils.instantiate` do, so `examples/configs/*/unet_small.yaml` load
+unchanged. Parameter names match the reference (`diffusion_model.*`), so its checkpoints' state_dicts load.
+"""
+from typing import Dict, Iterable, Optional
+
+import torch
+import torch.nn as nn
+
+from ..config import Config, instantiate, load_config, to_config
+
+
+class AbstractDiffusionModel(nn.Module):
+    def __init__(self, cfg, trainer=None):
+        super().__init__()
+        self.cfg = cfg if isinstance(cfg, Config) else to_config(cfg)
+        self.trainer = trainer
+        # Timesteps must be defined at the global level
+        self.image_size = self.cfg.image_size
+        self.timesteps = self.cfg.timesteps
+        self.channels = self.cfg.channels
+        self.save_and_sample_every = self.cfg.get('save_every', 1000)
+
+    @classmethod
+    def from_config_file(cls, path: str, overrides: Optional[Iterable[str]] = None, trainer=None):
+        """Loads a reference YAML (e.g. examples/configs/ddpm/unet_small.yaml) with Hydra-style overrides such as
+        ``model.image_size=64`` and builds the model from its ``model:`` section."""
+        full = load_config(path, overrides)
+        return cls(full.model, trainer=trainer)
+
+    def get_diffusion_model(self, batch: Dict):
+        return self.forward
+
+    def change_sampler(self, sampler_cfg):
+        """abstract_diffusion_model.py:130-135."""
+        self.sampler = instantiate(sampler_cfg)
+        self.cfg.sampler = sampler_cfg
+
+    def set_compute_dtype(self, compute_dtype: str):
+        self.diffusion_model.set_compute_dtype(compute_dtype)
+        return self
+
+
+class DDPM(AbstractDiffusionModel):
+    def __init__(self, cfg, trainer=None):
+        super().__init__(cfg, trainer=trainer)
+        self.diffusion_model = instantiate(self.cfg.diffusion_model)
+        self.sampler = instantiate(self.cfg.sampler)
+        self.loss = instantiate(self.cfg.loss)
+
+    def forward(self, x_t: torch.Tensor, t: torch.Tensor, classes: torch.Tensor = None):
+        return self.diffusion_model(x_t, t)
+
+    def sample(self, batch_size: int, image_size: int, device: torch.device = None, **kwargs):
+        """models/ddpm.py:105-109; extra keyword arguments go to the sampler (keep=, seed=, image_offset=, ...)."""
+        with torch.inference_mode():
+            self.eval()
+            shape = [batch_size, self.channels, image_size, image_size]
+            return self.sampler.sample(self.diffusion_model, shape=shape, device=device, **kwargs)
+
+    def interpolate(self, x1, x2, t: Optional[int] = None, lambd: float = 0.5, **kwargs):
+        with torch.inference_mode():
+            self.eval()
+            assert x1.ndim == 4, f"x1 is not a batch of tensors ! Given shape {x1.shape}"
+            assert x2.ndim == 4, f"x2 is not a batch of tensors ! Given shape {x2.shape}"
+            dev = next(self.parameters()).device
+            return self.sampler.interpolate(self.diffusion_model, x1=x1.to(dev), x2=x2.to(dev), t=t, lambd=lambd)
+
+    def training_loss(self, batch, t: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None):
+        """Forward half of models/ddpm.py:43-57: t ~ U{0..T-1}, x_t = q_sample(x_0, t, eps), loss(net(x_t, t), eps).
+        The value is computed by the HIP forward and carries no autograd graph (backward kernels are not built)."""
+        samples = batch["pixel_values"]
+        B = samples.shape[0]
+        if t is None:
+            t = torch.randint(0, self.timesteps, size=(B,), device=samples.device, dtype=torch.long)
+        if noise is None:
+            noise = torch.randn_like(samples)
+        with torch.no_grad():
+            x_t = self.sampler.q_sample(x_start=samples, t=t, noise=noise)
+            out = self.forward(x_t, t)
+            if getattr(self.diffusion_model, "learned_variance", False):
+                out, _ = out.chunk(2, dim=1)
+            return self.loss(input=out, target=noise)
+
+    def training_step(self, batch, batch_nb):
+        raise NotImplementedError(
+            "training_step needs the backward pass, which is not implemented by the HIP kernels yet; "
+            "`training_loss(batch)` evaluates the forward half (q_sample + U-Net + L_simple) on the device")
+
+
+class ImprovedDDPM(DDPM):
+    """Learned-variance DDPM: same wrapper, `LearnedGaussianDiffusion` sampler and a 2C-channel network
+    (models/improved_ddpm.py:21-25; examples/configs/improved_ddpm/unet_small.yaml:25,40). The variational-bound
+    loss entry of the config (`vb_loss`) is only needed for training and is not instantiated."""

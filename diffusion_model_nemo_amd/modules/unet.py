@@ -1,0 +1,249 @@
+"""`Unet` with the reference's constructor and `state_dict` names, executed by the gfx950 kernels.
+
+Mirror of diffusion_model_nemo/modules/unet.py:13-168 for ``use_convnext=False``. The torch modules
+created here only HOLD parameters (so checkpoints of the reference load unchanged and optimizers see
+ordinary ``nn.Parameter`` objects); ``forward`` hands raw device pointers to libdmn_hip.so. There is no
+torch / CPU implementation of the forward: a CPU tensor, or a missing library, raises.
+"""
+import ctypes as C
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import _native as N
+
+
+class _ParamOnly(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover - never executed
+        raise RuntimeError("parameter container: the computation runs in libdmn_hip.so")
+
+
+def _conv(cin, cout, k, bias=True, transposed=False):
+    cls = nn.ConvTranspose2d if transposed else nn.Conv2d
+    return cls(cin, cout, kernel_size=k, bias=bias)
+
+
+class _Block(_ParamOnly):
+    def __init__(self, cin, cout, groups):
+        super().__init__()
+        self.proj = _conv(cin, cout, 3)
+        self.norm = nn.GroupNorm(groups, cout)
+
+
+class _ResnetBlock(_ParamOnly):
+    """Parameter layout of parts/convnext.py:66-76."""
+
+    def __init__(self, cin, cout, time_emb_dim=None, groups=8):
+        super().__init__()
+        self.mlp = nn.Sequential(nn.SiLU(), nn.Linear(time_emb_dim, cout)) if time_emb_dim is not None else None
+        self.block1 = _Block(cin, cout, groups)
+        self.block2 = _Block(cout, cout, groups)
+        self.res_conv = _conv(cin, cout, 1) if cin != cout else nn.Identity()
+
+
+class _LinearAttention(_ParamOnly):
+    def __init__(self, dim, heads=4, dim_head=32):
+        super().__init__()
+        hidden = heads * dim_head
+        self.to_qkv = _conv(dim, hidden * 3, 1, bias=False)
+        self.to_out = nn.Sequential(_conv(hidden, dim, 1), nn.GroupNorm(1, dim))
+
+
+class _Attention(_ParamOnly):
+    def __init__(self, dim, heads=4, dim_head=32):
+        super().__init__()
+        hidden = heads * dim_head
+        self.to_qkv = _conv(dim, hidden * 3, 1, bias=False)
+        self.to_out = _conv(hidden, dim, 1)
+
+
+class _PreNorm(_ParamOnly):
+    def __init__(self, dim, fn):
+        super().__init__()
+        self.fn = fn
+        self.norm = nn.GroupNorm(1, dim)
+
+
+class _Residual(_ParamOnly):
+    def __init__(self, fn):
+        super().__init__()
+        self.fn = fn
+
+
+class Unet(nn.Module):
+    HEADS, DIM_HEAD = 4, 32  # parts/mha.py:8,34
+
+    def __init__(
+        self,
+        input_dim: None,
+        dim: int,
+        out_dim: Optional[int] = None,
+        dim_mults: Optional[List[int]] = None,
+        channels: int = 3,
+        with_time_emb: bool = True,
+        resnet_block_groups: int = 8,
+        use_convnext: bool = True,
+        convnext_mult: int = 2,
+        resnet_block_order: str = 'bn_act_conv',
+        dropout: Optional[float] = None,
+        learned_variance: bool = False,
+        num_classes: Optional[int] = None,
+        compute_dtype: str = "bf16",
+    ):
+        super().__init__()
+        if use_convnext:
+            raise NotImplementedError("use_convnext=True is not part of the accelerated path "
+                                      "(every shipped config sets use_convnext: False)")
+        if num_classes is not None:
+            raise NotImplementedError("class conditioning is not part of the accelerated path yet")
+        if dropout not in (None, 0, 0.0):
+            raise NotImplementedError("dropout > 0 is not supported by the HIP forward (sampling path)")
+        if resnet_block_order not in ('conv_bn_act', 'bn_act_conv'):
+            raise ValueError("Valid ordering for block are : ['conv_bn_act', 'bn_act_conv']")
+        if compute_dtype not in ("bf16", "fp32"):
+            raise ValueError("compute_dtype must be 'bf16' or 'fp32'")
+        dim_mults = tuple(dim_mults) if dim_mults is not None else (1, 2, 4, 8)
+        self.channels = channels
+        self.learned_variance = learned_variance
+        self.dim = dim
+        self.resnet_block_order = resnet_block_order
+        self.resnet_block_groups = resnet_block_groups
+        self.num_classes = None
+        self.compute_dtype = compute_dtype
+        self.init_conv = nn.Conv2d(channels, dim, kernel_size=7, padding=3)
+
+        dims = [dim, *[dim * m for m in dim_mults]]
+        in_out = list(zip(dims[:-1], dims[1:]))
+        self.dim_list, self.in_out_list, self.dim_mults = dims, in_out, dim_mults
+        g = resnet_block_groups
+        if with_time_emb:
+            time_dim = dim * 4
+            # index 0 is the sinusoidal embedding (no parameters), so the Linear layers are .1 and .3
+            self.time_mlp = nn.Sequential(nn.Identity(), nn.Linear(dim, time_dim), nn.GELU(), nn.Linear(time_dim, time_dim))
+        else:
+            raise NotImplementedError("with_time_emb=False is not part of the accelerated path")
+
+        self.downs = nn.ModuleList([])
+        self.ups = nn.ModuleList([])
+        n_res = len(in_out)
+        for ind, (ci, co) in enumerate(in_out):
+            last = ind >= n_res - 1
+            self.downs.append(nn.ModuleList([
+                _ResnetBlock(ci, co, time_dim, g), _ResnetBlock(co, co, time_dim, g),
+                _Residual(_PreNorm(co, _LinearAttention(co, self.HEADS, self.DIM_HEAD))),
+                nn.Conv2d(co, co, 4, 2, 1) if not last else nn.Identity()]))
+        mid = dims[-1]
+        self.mid_block1 = _ResnetBlock(mid, mid, time_dim, g)
+        self.mid_attn = _Residual(_PreNorm(mid, _Attention(mid, self.HEADS, self.DIM_HEAD)))
+        self.mid_block2 = _ResnetBlock(mid, mid, time_dim, g)
+        for ind, (ci, co) in enumerate(reversed(in_out[1:])):
+            # every up level ends with a transposed convolution (unet.py:95-104)
+            self.ups.append(nn.ModuleList([
+                _ResnetBlock(co * 2, ci, time_dim, g), _ResnetBlock(ci, ci, time_dim, g),
+                _Residual(_PreNorm(ci, _LinearAttention(ci, self.HEADS, self.DIM_HEAD))),
+                nn.ConvTranspose2d(ci, ci, 4, 2, 1)]))
+        default_out = channels * (2 if learned_variance else 1)
+        self.out_dim = out_dim if out_dim is not None else default_out
+        if resnet_block_order == 'bn_act_conv':
+            tail = [nn.GroupNorm(g, dim), nn.SiLU(), nn.Conv2d(dim, self.out_dim, 1)]
+        else:
+            tail = [nn.Conv2d(dim, self.out_dim, 1)]
+        self.final_conv = nn.Sequential(_ResnetBlock(dim, dim, None, g), *tail)
+
+        self._handle = None
+        self._weights_version = None
+        self._workspace = None
+        self._ws_key = None
+
+    # ---- native handle -------------------------------------------------------------------------------
+    def _cfg(self) -> N.DmnUnetCfg:
+        c = N.DmnUnetCfg()
+        c.dim = self.dim
+        c.n_mults = len(self.dim_mults)
+        for i, m in enumerate(self.dim_mults):
+            c.dim_mults[i] = int(m)
+        c.channels = self.channels
+        c.out_dim = self.out_dim
+        c.groups = self.resnet_block_groups
+        c.heads, c.dim_head = self.HEADS, self.DIM_HEAD
+        c.tail_norm = 1 if self.resnet_block_order == 'bn_act_conv' else 0
+        c.with_time_emb = 1
+        c.dtype = N.BF16 if self.compute_dtype == "bf16" else N.F32
+        return c
+
+    def _version(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def native_handle(self) -> int:
+        """Creates the DmnUnet handle / repacks the weights when parameters changed."""
+        lib = N.lib()
+        if self._handle is None:
+            h = C.c_void_p()
+            cfg = self._cfg()
+            N.check(lib.dmn_unet_create(C.byref(cfg), C.byref(h)))
+            self._handle = h
+        ver = self._version()
+        if ver != self._weights_version:
+            params = {k: v.detach().to("cpu", torch.float32).contiguous().numpy() for k, v in self.state_dict().items()}
+            descs, keep = N.make_tensor_descs(params)
+            N.check(lib.dmn_unet_load_weights(self._handle, descs, len(params)))
+            del keep
+            self._weights_version = ver
+        return self._handle
+
+    def set_compute_dtype(self, compute_dtype: str):
+        if compute_dtype not in ("bf16", "fp32"):
+            raise ValueError("compute_dtype must be 'bf16' or 'fp32'")
+        if compute_dtype != self.compute_dtype:
+            self.release()
+            self.compute_dtype = compute_dtype
+        return self
+
+    def release(self):
+        if self._handle is not None:
+            torch.cuda.synchronize()
+            N.lib().dmn_unet_destroy(self._handle)
+        self._handle = None
+        self._weights_version = None
+        self._workspace = None
+        self._ws_key = None
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                N.lib().dmn_unet_destroy(self._handle)
+        except Exception:
+            pass
+
+    def workspace(self, B, H, W, device, sampling=False) -> torch.Tensor:
+        key = (B, H, W, str(device), sampling)
+        if self._ws_key != key:
+            lib = N.lib()
+            n = C.c_size_t()
+            fn = lib.dmn_sample_workspace_bytes if sampling else lib.dmn_unet_workspace_bytes
+            N.check(fn(self.native_handle(), B, H, W, C.byref(n)))
+            self._workspace = torch.empty(n.value, dtype=torch.uint8, device=device)
+            self._ws_key = key
+        return self._workspace
+
+    # ---- forward -----------------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor, time: torch.Tensor, classes=None) -> torch.Tensor:
+        if not x.is_cuda:
+            raise RuntimeError("Unet.forward runs only on an MI355X device tensor (no CPU implementation)")
+        if x.dim() != 4 or x.size(1) != self.channels:
+            raise ValueError(f"expected [B, {self.channels}, H, W], got {tuple(x.shape)}")
+        B, _, H, W = x.shape
+        x = x.contiguous().float()
+        if time.dim() != 1 or time.numel() != B:
+            raise ValueError("time must have shape [B]")
+        if time.is_floating_point():
+            t, is_float = time.to(device=x.device, dtype=torch.float32).contiguous(), 1
+        else:
+            t, is_float = time.to(device=x.device, dtype=torch.int64).contiguous(), 0
+        handle = self.native_handle()
+        ws = self.workspace(B, H, W, x.device)
+        out = torch.empty((B, self.out_dim, H, W), dtype=torch.float32, device=x.device)
+        N.check(N.lib().dmn_unet_forward(handle, x.data_ptr(), t.data_ptr(), is_float, out.data_ptr(), B, H, W,
+                                         ws.data_ptr(), ws.numel(), N.current_stream_handle(x.device)))
+        return out

@@ -1,0 +1,124 @@
+/* C-ABI of libdmn_hip.so: the MI355X (gfx950) implementation of the DDPM / score-SDE denoising hot path
+ * of titu1994/diffusion_model_nemo. Plain pointers and sizes only; no framework types.
+ *
+ * The reference has no native seam: its "plugin API" for this path is Hydra `_target_` instantiation of
+ * Python classes (diffusion_model_nemo/models/ddpm.py:27-29). The Python mirror of those classes in
+ * `diffusion_model_nemo_amd/` binds the entry points below through ctypes; each declaration cites the
+ * reference code it replaces (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative DmnStatus; dmn_last_error() describes the failure
+ *     (thread-local). No exception crosses this boundary.
+ *   - device pointers are borrowed for the duration of the call (asynchronously, on `stream`); the library
+ *     never frees or retains them, except the packed-weight copy owned by a DmnUnet handle.
+ *   - images are NCHW float32 (the reference's layout); `dtype` selects the INTERNAL activation/weight
+ *     type: 0 = float32 (exact-f32 MFMA, parity mode), 1 = bfloat16 (bf16 MFMA, fp32 accumulate).
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*); no hidden synchronisation.
+ */
+#ifndef DMN_H
+#define DMN_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMN_MAX_MULTS 8
+#define DMN_TABLE_COLS 12
+
+typedef struct DmnUnet DmnUnet;
+
+/* Constructor arguments of Unet (diffusion_model_nemo/modules/unet.py:14-29) for use_convnext=False. */
+typedef struct {
+    int dim;                       /* base width */
+    int n_mults;
+    int dim_mults[DMN_MAX_MULTS];
+    int channels;                  /* image channels (<= 4) */
+    int out_dim;                   /* channels * (learned_variance ? 2 : 1) unless overridden (<= 8) */
+    int groups;                    /* resnet_block_groups */
+    int heads, dim_head;           /* attention geometry: 4 x 32 in the reference (parts/mha.py:8,34) */
+    int tail_norm;                 /* 1: resnet_block_order == 'bn_act_conv' => GN+SiLU before the last 1x1 */
+    int with_time_emb;
+    int dtype;                     /* 0 f32, 1 bf16 */
+} DmnUnetCfg;
+
+/* One parameter of the reference state_dict: HOST float32 data, contiguous, PyTorch shape order. */
+typedef struct {
+    const char* name;              /* e.g. "downs.0.0.block1.proj.weight" */
+    const float* data;
+    int ndim;
+    int64_t shape[4];
+} DmnTensorDesc;
+
+const char* dmn_last_error(void);
+const char* dmn_version(void);
+
+/* ---- U-Net: replaces Unet.__init__/forward (modules/unet.py:14-120,131-168) ------------------------------ */
+int dmn_unet_create(const DmnUnetCfg* cfg, DmnUnet** out);
+void dmn_unet_destroy(DmnUnet* u);
+/* Packs the reference's parameters (names as in Unet.state_dict()) into the device layout. Synchronous. */
+int dmn_unet_load_weights(DmnUnet* u, const DmnTensorDesc* params, int n_params);
+int dmn_unet_workspace_bytes(const DmnUnet* u, int B, int H, int W, size_t* bytes);
+/* eps = Unet(x, t).  t: [B] int64 (t_is_float = 0) or float32 (1), device memory. out: [B][out_dim][H][W]. */
+int dmn_unet_forward(DmnUnet* u, const float* x, const void* t, int t_is_float, float* out, int B, int H, int W,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- samplers ------------------------------------------------------------------------------------------------
+ * `table` is a DEVICE array [nsteps][DMN_TABLE_COLS] float32, one row per executed step in execution order,
+ * built on the host from the reference's schedule formulas (gaussian_diffusion.py:44-83; sde_lib/).
+ * Row layout: see diffusion_model_nemo_amd/csrc/dmn_sampler.h.
+ * Noise: Philox4x32-10 + Box-Muller keyed by (seed, step id, stream, img_offset + b, element); pass `noise`
+ * (device [B][C][H][W]) to inject a draw instead (single-step entry points only). */
+
+/* One ancestral step: GaussianDiffusion.p_sample given the network output (gaussian_diffusion.py:157-167,
+ * 125-154,118-123,91-101) or LearnedGaussianDiffusion.p_mean_variance (learned_gaussian_diffusion.py:35-48). */
+int dmn_ddpm_step(const float* table, int row, const float* x, const float* model_out, const float* noise, float* x_out,
+                  int B, int C, int H, int W, int learned_variance, int pred_x0, uint64_t seed, int64_t img_offset,
+                  void* stream);
+
+/* GaussianDiffusion.p_sample_loop (gaussian_diffusion.py:171-189): x <- x_T (drawn here when draw_prior != 0)
+ * then nsteps x { eps = Unet(x, t); x = p_sample(...) }. `keep` (optional, device [nsteps][B*C*H*W]) receives x
+ * after every step. The step body is captured once into a hipGraph and replayed when use_graph != 0 and
+ * `stream` is not the null stream. */
+int dmn_ddpm_sample_loop(DmnUnet* u, const float* table, int nsteps, float* x, int B, int H, int W, int learned_variance,
+                         int pred_x0, int draw_prior, uint64_t seed, int64_t img_offset, float* keep, void* workspace,
+                         size_t workspace_bytes, void* stream, int use_graph);
+
+/* One predictor update as an affine map x_mean = a x + b net, x = x_mean + c z (rows 1..3 of the table):
+ * EulerMaruyamaPredictor / ReverseDiffusionPredictor / AncestralSamplingPredictor.update_fn
+ * (sde_predictors/) composed with the score adapter (loss/sde_loss/score_function_loss.py:48-91). */
+int dmn_sde_predictor_step(const float* table, int row, const float* x, const float* model_out, const float* noise,
+                           float* x_out, float* x_mean, int B, int C, int H, int W, uint64_t seed, int64_t img_offset,
+                           void* stream);
+/* One Langevin (use_norms=1, sde_correctors/langevin_corrector.py:26-33) or annealed-Langevin (use_norms=0,
+ * annealed_langevin_dynamics_corrector.py:34-39) inner step. scratch: >= dmn_sde_scratch_bytes(B, C, H, W). */
+int dmn_sde_corrector_step(const float* table, int row, const float* x, const float* model_out, const float* noise,
+                           float* x_out, int B, int C, int H, int W, float snr, int inner, int use_norms, uint64_t seed,
+                           int64_t img_offset, void* scratch, void* stream);
+size_t dmn_sde_scratch_bytes(int B, int C, int H, int W);
+
+/* PredictorCorrectorSampler.forward (sde_samplers/predictor_corrector_sampler.py:58-120): corrector then predictor
+ * per iteration. corrector: 0 none, 1 langevin, 2 ald. predictor: 0 none, 1 affine (table rows). `keep` receives
+ * x_mean (denoise != 0) or x after every iteration. prior_scale: sigma_max for VE, 1 for VP. */
+int dmn_pc_sample_loop(DmnUnet* u, const float* table, int nsteps, float* x, int B, int H, int W, int predictor,
+                       int corrector, int n_corrector_steps, float snr, int denoise, int draw_prior, float prior_scale,
+                       uint64_t seed, int64_t img_offset, float* keep, float* x_mean_out, void* workspace,
+                       size_t workspace_bytes, void* stream, int use_graph);
+int dmn_sample_workspace_bytes(const DmnUnet* u, int B, int H, int W, size_t* bytes);
+
+/* N(0,1) * scale into x[B][per] with the library's generator (prior draws; tests). */
+int dmn_fill_normal(float* x, int B, int per, uint64_t seed, uint32_t step, int64_t img_offset, float scale, void* stream);
+
+/* ---- single kernels, exported for unit parity tests -------------------------------------------------------------
+ * Activations NHWC in the internal dtype (float32 or bfloat16 bit patterns). Weights HOST float32 in PyTorch layout;
+ * these helpers pack + upload them per call (synchronous, test use only). */
+int dmn_test_conv2d(int dtype, const void* in0, const void* in1, int C0, int C1, int B, int H, int W, const float* w_host,
+                    const float* bias_host, int Cout, int kh, int kw, int stride, int pad, int transposed, void* out,
+                    const void* res, const float* pro_gamma_host, const float* pro_beta_host, const float* pro_tbias_dev,
+                    const float* pro_stats_dev, int pro_G, int pro_slots, int pro_silu, float* epi_stats_dev, int epi_G,
+                    int* epi_slots_out, int cfg_tile, int cfg_bn, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMN_H */

@@ -1,0 +1,193 @@
+"""Per-kernel parity of the HIP implicit-GEMM convolution (through the C-ABI test hook) against
+torch.nn.functional on the CPU in fp32. Tolerances: the f32 path is an exact-f32 fma chain in a different
+summation order than MKLDNN (abs 2e-5 * scale); the bf16 path rounds inputs/weights/outputs to bf16
+(abs 2e-2 * scale, the reference's own bf16-autocast error band)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import philox  # noqa: E402
+
+
+def _N():
+    from diffusion_model_nemo_amd import _native
+    return _native
+
+
+def rnd(shape, seed, scale=1.0):
+    return torch.from_numpy(philox.normal_like(tuple(shape), seed, 0, 9)) * scale
+
+
+def to_dev_nhwc(x_nchw, dtype):
+    t = x_nchw.permute(0, 2, 3, 1).contiguous().cuda()
+    return t.to(torch.bfloat16) if dtype == 1 else t
+
+
+def from_dev_nhwc(t):
+    return t.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def run_conv(dtype, x0, x1, w, b, stride, pad, transposed, res=None, pro=None, epi_G=0, tile=0, bn=0):
+    N = _N()
+    lib = N.lib()
+    B, C0, H, W = x0.shape
+    C1 = 0 if x1 is None else x1.shape[1]
+    if transposed:
+        Cout, kh, kw = w.shape[1], w.shape[2], w.shape[3]
+        Ho, Wo = 2 * H, 2 * W
+    else:
+        Cout, kh, kw = w.shape[0], w.shape[2], w.shape[3]
+        Ho = (H + 2 * pad - kh) // stride + 1
+        Wo = (W + 2 * pad - kw) // stride + 1
+    d0 = to_dev_nhwc(x0, dtype)
+    d1 = None if x1 is None else to_dev_nhwc(x1, dtype)
+    out = torch.zeros((B, Ho, Wo, Cout), device="cuda", dtype=torch.bfloat16 if dtype == 1 else torch.float32)
+    dres = None if res is None else to_dev_nhwc(res, dtype)
+    wn = np.ascontiguousarray(w.numpy(), dtype=np.float32)
+    bn_ = None if b is None else np.ascontiguousarray(b.numpy(), dtype=np.float32)
+    pg = pb = ptb = pst = None
+    pG = pslots = psilu = 0
+    if pro is not None:
+        pg = np.ascontiguousarray(pro["gamma"].numpy(), dtype=np.float32)
+        pb = np.ascontiguousarray(pro["beta"].numpy(), dtype=np.float32)
+        ptb = None if pro.get("tbias") is None else pro["tbias"].cuda().contiguous()
+        pst = pro["stats"].cuda().contiguous()
+        pG, pslots, psilu = pro["G"], pro["slots"], pro["silu"]
+    est = None
+    if epi_G:
+        est = torch.full((B * epi_G * 1024 * 2,), float("nan"), device="cuda", dtype=torch.float32)
+    slots = C.c_int(0)
+    torch.cuda.synchronize()
+    N.check(lib.dmn_test_conv2d(
+        dtype, d0.data_ptr(), None if d1 is None else d1.data_ptr(), C0, C1, B, H, W, wn.ctypes.data,
+        None if bn_ is None else bn_.ctypes.data, Cout, kh, kw, stride, pad, 1 if transposed else 0, out.data_ptr(),
+        None if dres is None else dres.data_ptr(), None if pg is None else pg.ctypes.data,
+        None if pb is None else pb.ctypes.data, None if ptb is None else ptb.data_ptr(),
+        None if pst is None else pst.data_ptr(), pG, pslots, psilu, None if est is None else est.data_ptr(), epi_G,
+        C.byref(slots), tile, bn, None))
+    torch.cuda.synchronize()
+    stats = None
+    if epi_G:
+        stats = est[: B * epi_G * slots.value * 2].cpu().reshape(B, epi_G, slots.value, 2).sum(2)
+    return from_dev_nhwc(out), stats
+
+
+def tol(dtype, ref):
+    scale = max(1.0, float(ref.abs().max()))
+    return (2e-5 if dtype == 0 else 2.5e-2) * scale
+
+
+def q(x, dtype):
+    """what the kernel sees: inputs rounded to the activation dtype"""
+    return x.to(torch.bfloat16).float() if dtype == 1 else x
+
+
+# every (Cout, Cin) pair of the 3x3 convolutions of the 64x64 network, at small spatial sizes
+PAIRS_3X3 = [(32, 32), (64, 32), (64, 64), (32, 128), (128, 64), (128, 128), (64, 256), (256, 128), (256, 256), (128, 512)]
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("cout,cin", PAIRS_3X3)
+def test_conv3x3_all_channel_pairs(dtype, cout, cin):
+    B, H, W = 2, 8, 8
+    x = rnd((B, cin, H, W), 1)
+    w = rnd((cout, cin, 3, 3), 2, (1.0 / (9 * cin)) ** 0.5)
+    b = rnd((cout,), 3, 0.1)
+    ref = F.conv2d(q(x, dtype), q(w, dtype), b, padding=1)
+    got, _ = run_conv(dtype, x, None, w, b, 1, 1, False)
+    assert (got - ref).abs().max() <= tol(dtype, ref)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("tile,bn", [(16, 32), (16, 64), (8, 32), (8, 64)])
+@pytest.mark.parametrize("H,W", [(16, 16), (32, 16), (24, 40)])
+def test_conv3x3_tile_configs_and_ragged_edges(dtype, tile, bn, H, W):
+    B, cin, cout = 2, 32, 64
+    x = rnd((B, cin, H, W), 4)
+    w = rnd((cout, cin, 3, 3), 5, (1.0 / (9 * cin)) ** 0.5)
+    b = rnd((cout,), 6, 0.1)
+    ref = F.conv2d(q(x, dtype), q(w, dtype), b, padding=1)
+    got, stats = run_conv(dtype, x, None, w, b, 1, 1, False, epi_G=8, tile=tile, bn=bn)
+    assert (got - ref).abs().max() <= tol(dtype, ref)
+    g = ref.reshape(B, 8, -1)
+    ref_stats = torch.stack([g.sum(-1), (g * g).sum(-1)], dim=-1)
+    assert (stats - ref_stats).abs().max() <= 2e-3 * max(1.0, float(ref_stats.abs().max())) * (1 if dtype == 0 else 10)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_conv1x1_qkv_and_concat_sources(dtype):
+    B, H, W = 2, 8, 8
+    x0, x1 = rnd((B, 64, H, W), 7), rnd((B, 64, H, W), 8)
+    w = rnd((384, 128, 1, 1), 9, (1.0 / 128) ** 0.5)
+    ref = F.conv2d(torch.cat((q(x0, dtype), q(x1, dtype)), 1), q(w, dtype))
+    got, _ = run_conv(dtype, x0, x1, w, None, 1, 0, False)
+    assert (got - ref).abs().max() <= tol(dtype, ref)
+    # 3x3 over two sources (decoder block1 reads cat(x, skip))
+    w3 = rnd((64, 128, 3, 3), 10, (1.0 / (9 * 128)) ** 0.5)
+    b3 = rnd((64,), 11, 0.1)
+    ref = F.conv2d(torch.cat((q(x0, dtype), q(x1, dtype)), 1), q(w3, dtype), b3, padding=1)
+    got, _ = run_conv(dtype, x0, x1, w3, b3, 1, 1, False)
+    assert (got - ref).abs().max() <= tol(dtype, ref)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("C", [32, 128])
+def test_downsample_and_upsample(dtype, C):
+    B, H, W = 2, 16, 16
+    x = rnd((B, C, H, W), 12)
+    w = rnd((C, C, 4, 4), 13, (1.0 / (16 * C)) ** 0.5)
+    b = rnd((C,), 14, 0.1)
+    ref = F.conv2d(q(x, dtype), q(w, dtype), b, stride=2, padding=1)
+    got, _ = run_conv(dtype, x, None, w, b, 2, 1, False)
+    assert (got - ref).abs().max() <= tol(dtype, ref)
+    wt = rnd((C, C, 4, 4), 15, (1.0 / (4 * C)) ** 0.5)
+    ref = F.conv_transpose2d(q(x, dtype), q(wt, dtype), b, stride=2, padding=1)
+    got, _ = run_conv(dtype, x, None, wt, b, 2, 1, True)
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max() <= tol(dtype, ref)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("G,silu,use_tb", [(8, 1, True), (4, 1, False), (1, 0, False)])
+def test_conv_with_groupnorm_prologue_and_residual(dtype, G, silu, use_tb):
+    """conv(SiLU(GN(x)) + time_bias) + residual: Block2 of a ResnetBlock / the qkv projection behind PreNorm."""
+    B, Cn, H, W = 2, 64, 16, 16
+    x = rnd((B, Cn, H, W), 16) * 1.7 + 0.3
+    gamma, beta = 1 + 0.1 * rnd((Cn,), 17), 0.1 * rnd((Cn,), 18)
+    tb = rnd((B, Cn), 19, 0.3) if use_tb else None
+    w = rnd((64, Cn, 3, 3), 20, (1.0 / (9 * Cn)) ** 0.5)
+    b = rnd((64,), 21, 0.1)
+    res = rnd((B, 64, H, W), 22)
+    xq = q(x, dtype)
+    h = F.group_norm(xq, G, gamma, beta, eps=1e-5)
+    if silu:
+        h = F.silu(h)
+    if tb is not None:
+        h = h + tb[:, :, None, None]
+    ref = F.conv2d(q(h, dtype), q(w, dtype), b, padding=1) + q(res, dtype)
+    g = xq.reshape(B, G, -1)
+    # two slots per group: the consumer must add them
+    half = g.shape[-1] // 2
+    stats = torch.stack([torch.stack([g[..., :half].sum(-1), (g[..., :half] ** 2).sum(-1)], -1),
+                         torch.stack([g[..., half:].sum(-1), (g[..., half:] ** 2).sum(-1)], -1)], dim=2)
+    pro = dict(gamma=gamma, beta=beta, tbias=tb, stats=stats.contiguous(), G=G, slots=2, silu=silu)
+    got, _ = run_conv(dtype, x, None, w, b, 1, 1, False, res=res, pro=pro)
+    assert (got - ref).abs().max() <= tol(dtype, ref) * (1 if dtype == 0 else 2)
+
+
+def test_philox_matches_cpu_generator():
+    N = _N()
+    B, per = 3, 3 * 8 * 8 + 0
+    x = torch.empty((B, per), device="cuda", dtype=torch.float32)
+    N.check(N.lib().dmn_fill_normal(x.data_ptr(), B, per, 1234567890123, 17, 5, 1.0, None))
+    torch.cuda.synchronize()
+    ref = philox.normal(1234567890123, 17, 0, np.arange(B) + 5, per)
+    got = x.cpu().numpy()
+    # float64 Box-Muller rounded once: identical except for rare last-ulp differences of log/sincos
+    assert np.abs(got - ref).max() <= 1e-6
+    assert (got == ref).mean() > 0.99
