@@ -25,6 +25,8 @@ class Config(dict):
     def __getattr__(self, key):
         try:
             return self[key]
+        except MissingMandatoryValue:
+            raise
         except KeyError as e:
             raise AttributeError(key) from e
 

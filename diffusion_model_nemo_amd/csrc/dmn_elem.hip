@@ -35,16 +35,22 @@ __global__ void __launch_bounds__(kNormThreads) norm_apply_kernel(const NormAppl
     const bool want = a.epi.stats != nullptr;
     const int Go = want ? a.epi.G : 1;
     const int cpg_o = C / Go;
-    // A thread always visits the same channel offset when kNormThreads % vec_per_pix == 0, so it feeds
-    // one output group; otherwise (never for this network) fall back to group 0 bookkeeping per element.
-    float s = 0.f, ss = 0.f;
-    int my_group = 0;
+    // A thread always visits the same channel offset because kNormThreads % vec_per_pix == 0 (checked by the
+    // launcher), so the group of each of its quads is fixed.
+    // statistics are accumulated per 4-channel quad of the thread's 16-byte vector (a quad never straddles an
+    // output group because groups hold a multiple of 4 channels)
+    constexpr int NQ = PER / 4;
+    float s[NQ], ss[NQ];
+    int qgroup[NQ];
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) { s[k] = ss[k] = 0.f; qgroup[k] = 0; }
     for (int i = threadIdx.x; i < nvec; i += kNormThreads) {
         const int cb = (i % vec_per_pix) * PER;
         Vec16<T> v, r;
         v.v = *reinterpret_cast<const V*>(in + (size_t)i * PER);
         if (res) r.v = *reinterpret_cast<const V*>(res + (size_t)i * PER);
-        my_group = cb / cpg_o;
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) qgroup[k] = (cb + 4 * k) / cpg_o;
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
             float y = v.get(j) * sCoef[cb + j] + sCoef[C + cb + j];
@@ -53,8 +59,8 @@ __global__ void __launch_bounds__(kNormThreads) norm_apply_kernel(const NormAppl
             if (res) y += r.get(j);
             v.set(j, y);
             const float yr = v.get(j);  // statistics of the value the consumer will read
-            s += yr;
-            ss += yr * yr;
+            s[j / 4] += yr;
+            ss[j / 4] += yr * yr;
         }
         *reinterpret_cast<V*>(out + (size_t)i * PER) = v.v;
     }
@@ -65,8 +71,12 @@ __global__ void __launch_bounds__(kNormThreads) norm_apply_kernel(const NormAppl
         float* sAcc = sTmp;  // [4 waves][Go][2]
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
         for (int g = 0; g < Go; ++g) {
-            const float ms = (my_group == g) ? s : 0.f;
-            const float mss = (my_group == g) ? ss : 0.f;
+            float ms = 0.f, mss = 0.f;
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) {
+                ms += (qgroup[k] == g) ? s[k] : 0.f;
+                mss += (qgroup[k] == g) ? ss[k] : 0.f;
+            }
             const float ws = wave_sum(ms), wss = wave_sum(mss);
             if (lane == 0) {
                 sAcc[(wave * Go + g) * 2] = ws;
@@ -243,7 +253,7 @@ int launch_norm_apply(NormApplyArgs& a, hipStream_t s) {
     int Go = 1;
     if (a.epi.stats) {
         Go = a.epi.G;
-        DMN_REQUIRE(a.C % Go == 0 && (a.C / Go) % per == 0, DMN_ERR_INVALID, "norm_apply: output groups %d", Go);
+        DMN_REQUIRE(a.C % Go == 0 && (a.C / Go) % 4 == 0, DMN_ERR_INVALID, "norm_apply: output groups %d", Go);
         a.epi.slots = slots;
     }
     size_t tmp = 2 * (size_t)a.norm.G;

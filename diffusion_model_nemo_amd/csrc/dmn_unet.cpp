@@ -160,7 +160,7 @@ struct Arena {
     bool dry = false;
     std::vector<Blk> blks;
     void reset(void* b, size_t c, bool d) {
-        base = (char*)b;
+        base = d ? reinterpret_cast<char*>(4096) : (char*)b;   // dry run: offsets only, any non-null base
         cap = c;
         dry = d;
         high = 0;

@@ -1,0 +1,190 @@
+"""Host-side logic of the product package (no GPU needed): schedule constants, step tables, SDE coefficient
+tables, config loading / `_target_` instantiation, state_dict naming, and the C-ABI library's exported symbols."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+from oracle import ref_cpu as R
+from oracle.weights import unet_param_shapes
+
+
+def test_schedule_constants_match_reference():
+    from diffusion_model_nemo_amd.modules import GaussianDiffusion
+    g = load_golden("schedules")
+    for sched in ("cosine", "linear", "quadratic", "sigmoid"):
+        for Tn in (10, 1000):
+            gd = GaussianDiffusion(timesteps=Tn, schedule_name=sched)
+            for n in R.CONSTANT_NAMES:
+                np.testing.assert_allclose(getattr(gd, n).numpy(), g[f"{sched}_{Tn}_{n}"], rtol=3e-7, atol=1e-9)
+    gd = GaussianDiffusion(timesteps=50, schedule_name="linear",
+                           schedule_cfg={"linear": {"beta_start": 0.001, "beta_end": 0.05}})
+    for n in R.CONSTANT_NAMES:
+        np.testing.assert_allclose(getattr(gd, n).numpy(), g[f"linearcfg_50_{n}"], rtol=3e-7, atol=1e-9)
+    with pytest.raises(AssertionError):
+        GaussianDiffusion(timesteps=10, schedule_name="nope")
+
+
+def test_ddpm_step_table_rows_follow_execution_order():
+    from diffusion_model_nemo_amd.modules import GaussianDiffusion
+    gd = GaussianDiffusion(timesteps=10, schedule_name="linear")
+    tab = gd.step_table("cpu")
+    assert tab.shape == (10, 12)
+    assert tab[:, 0].tolist() == list(range(9, -1, -1))
+    assert torch.equal(tab[:, 3], gd.posterior_mean_coef1.flip(0))
+    assert tab[-1, 7] == 0 and bool((tab[:-1, 7] == 1).all())
+    assert torch.equal(tab[:, 6], torch.log(gd.betas).flip(0))
+
+
+def _affine_from_oracle(name, sde_o, t, x, z, score):
+    sfn = lambda a, b: score  # noqa: E731
+    return R.predictor_step(name, sde_o, sfn, x, t, z)
+
+
+@pytest.mark.parametrize("kind", ["ve", "vp"])
+@pytest.mark.parametrize("pred", ["euler_maruyama", "reverse_diffusion", "ancestral_sampling"])
+def test_sde_step_table_reproduces_reference_predictors(kind, pred):
+    """The affine coefficients (a, b, c) of the step table, applied on the CPU, equal the reference predictor
+    updates (golden) for both per-sample times."""
+    from diffusion_model_nemo_amd.modules import VESDE, VPSDE, PredictorCorrectorSampler
+    g = load_golden("sde_units")
+    sde = VESDE(0.01, 50.0, 1000) if kind == "ve" else VPSDE(0.1, 20.0, 1000)
+    s = PredictorCorrectorSampler(predictor=pred, corrector=None, snr=0.16)
+    s.update_sde(sde)
+    if kind == "vp" and pred == "ancestral_sampling":
+        with pytest.raises(AttributeError):
+            s.step_table()
+        return
+    t = torch.from_numpy(g["t"])
+    tab = s.step_table(times=t)
+    x, z, score = (torch.from_numpy(g[k]) for k in ("x", "z", "score"))
+    a, b, c, ss = (tab[:, i][:, None, None, None] for i in (1, 2, 3, 4))
+    net = score / ss
+    mean = a * x + b * net
+    xo = mean + c * z
+    sc = max(1.0, float(np.abs(g[f"{kind}_{pred}_x"]).max()))
+    assert float((mean - torch.from_numpy(g[f"{kind}_{pred}_mean"])).abs().max()) <= 3e-6 * sc
+    assert float((xo - torch.from_numpy(g[f"{kind}_{pred}_x"])).abs().max()) <= 3e-6 * sc
+
+
+def test_sde_tables_labels_and_errors():
+    from diffusion_model_nemo_amd.modules import VESDE, VPSDE, PredictorCorrectorSampler, subVPSDE
+    g = load_golden("sde_units")
+    ve, vp = VESDE(0.01, 50.0, 1000), VPSDE(0.1, 20.0, 1000)
+    np.testing.assert_allclose(ve.discrete_sigmas.numpy(), g["ve_discrete_sigmas"], rtol=3e-7)
+    np.testing.assert_allclose(vp.sqrt_1m_alphas_cumprod.numpy(), g["vp_sqrt_1m_alphas_cumprod"], rtol=3e-7)
+    tt, xx = torch.from_numpy(g["tt"]), torch.from_numpy(g["xx"])
+    for name, sde in (("ve", ve), ("vp", vp)):
+        d, gg = sde.sde(xx, tt)
+        m, sd = sde.marginal_prob(xx, tt)
+        f, G = sde.discretize(xx, tt)
+        for k, v in (("drift", d), ("diffusion", gg), ("mean", m), ("std", sd), ("f", f), ("G", G)):
+            np.testing.assert_allclose(v.numpy(), g[f"{name}_{k}"], rtol=2e-6, atol=5e-7)
+    s = PredictorCorrectorSampler(predictor="euler_maruyama", corrector="langevin", snr=0.16)
+    with pytest.raises(ValueError):
+        s.step_table()
+    s.update_sde(ve)
+    tab = s.step_table()
+    assert tab.shape == (1000, 12)
+    assert abs(float(tab[0, 0]) - 50.0) < 1e-3 and abs(float(tab[-1, 0]) - 0.01) < 1e-4   # label = sigma(t)
+    s.update_sde(vp)
+    tab = s.step_table()
+    assert abs(float(tab[0, 0]) - 999.0) < 1e-3 and float(tab[0, 4]) < 0                   # label = 999 t, score = -net/std
+    s.update_sde(subVPSDE())
+    with pytest.raises(AttributeError):
+        s.step_table()
+    with pytest.raises(ValueError):
+        PredictorCorrectorSampler(predictor="bogus", corrector=None, snr=0.1).update_sde(ve) or \
+            PredictorCorrectorSampler(predictor="bogus", corrector=None, snr=0.1)._validate()
+
+
+REFERENCE_STYLE_CFG = """
+name: "DDPM-UNet"
+model:
+  image_size: ???
+  timesteps: 1000
+  channels: 3
+  num_classes: null
+  diffusion_model:
+    _target_: diffusion_model_nemo.modules.Unet
+    input_dim: ${model.image_size}
+    dim: 32
+    channels: ${model.channels}
+    num_classes: ${model.num_classes}
+    dim_mults: [1, 2, 4, 8]
+    with_time_emb: True
+    resnet_block_order: 'bn_act_conv'
+    resnet_block_groups: 8
+    use_convnext: False
+    convnext_mult: 2
+    out_dim: null
+    dropout: 0.0
+  sampler:
+    _target_: diffusion_model_nemo.modules.GaussianDiffusion
+    timesteps: ${model.timesteps}
+    schedule_name: "cosine"
+    schedule_cfg:
+      cosine: {s: 0.008, min_clip: 0.0001, max_clip: 0.999}
+      linear: {beta_start: 0.0001, beta_end: 0.02}
+  loss:
+    _target_: diffusion_model_nemo.loss.DiffusionLoss
+    loss_type: "l2"
+    reduction: "mean"
+exp_manager:
+  name: ${name}
+"""
+
+
+def test_config_loading_and_target_instantiation(tmp_path):
+    from diffusion_model_nemo_amd.config import MissingMandatoryValue, load_config
+    from diffusion_model_nemo_amd.models import DDPM
+    from diffusion_model_nemo_amd.modules import GaussianDiffusion, Unet
+    p = tmp_path / "cfg.yaml"
+    p.write_text(REFERENCE_STYLE_CFG)
+    cfg = load_config(str(p))
+    with pytest.raises(MissingMandatoryValue):
+        _ = cfg.model.image_size
+    cfg = load_config(str(p), ["model.image_size=64", "model.timesteps=250"])
+    assert cfg.model.diffusion_model.input_dim == 64 and cfg.model.sampler.timesteps == 250
+    assert cfg.exp_manager.name == "DDPM-UNet"
+    m = DDPM.from_config_file(str(p), ["model.image_size=64"])
+    assert isinstance(m.diffusion_model, Unet) and isinstance(m.sampler, GaussianDiffusion)
+    assert m.sampler.timesteps == 1000 and m.image_size == 64
+    ref = {k: tuple(v) for k, v in unet_param_shapes().items()}
+    mine = {k: tuple(v.shape) for k, v in m.diffusion_model.state_dict().items()}
+    assert mine == ref
+    assert all(k.startswith(("diffusion_model.",)) for k in m.state_dict())
+    # runtime sampler swap keeps the network (abstract_diffusion_model.py:130-135)
+    m.change_sampler({"_target_": "diffusion_model_nemo.modules.LearnedGaussianDiffusion", "timesteps": 10,
+                      "schedule_name": "linear"})
+    assert type(m.sampler).__name__ == "LearnedGaussianDiffusion"
+
+
+def test_unsupported_configurations_fail_loudly():
+    from diffusion_model_nemo_amd.modules import Unet
+    with pytest.raises(NotImplementedError):
+        Unet(input_dim=32, dim=32, use_convnext=True)
+    with pytest.raises(NotImplementedError):
+        Unet(input_dim=32, dim=32, use_convnext=False, num_classes=10)
+    u = Unet(input_dim=32, dim=32, use_convnext=False)
+    with pytest.raises(RuntimeError):
+        u(torch.zeros(1, 3, 32, 32), torch.zeros(1, dtype=torch.long))   # no CPU path
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from diffusion_model_nemo_amd import _native
+    header = open(os.path.join(ROOT, "include", "dmn.h")).read()
+    declared = set(re.findall(r"\b(dmn_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_native.SIGNATURES), declared ^ set(_native.SIGNATURES)
+    lib = _native.lib()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.dmn_version()
+    # structure sizes agree with the C declarations (int fields only / pointer + int + 4 x int64)
+    assert ctypes.sizeof(_native.DmnUnetCfg) == 4 * (10 + 8)
+    assert ctypes.sizeof(_native.DmnTensorDesc) == 8 + 8 + 8 + 32

@@ -34,10 +34,13 @@ def test_schedules_match_reference():
         for Tn in (10, 1000):
             c = R.ddpm_constants(Tn, sched)
             for n in R.CONSTANT_NAMES:
-                np.testing.assert_array_equal(c[n].numpy(), g[f"{sched}_{Tn}_{n}"], err_msg=f"{sched} {Tn} {n}")
+                # same float32 operation order as the reference; libm/vector-width differences between host CPUs
+                # move single results by one ulp
+                np.testing.assert_allclose(c[n].numpy(), g[f"{sched}_{Tn}_{n}"], rtol=3e-7, atol=1e-9,
+                                           err_msg=f"{sched} {Tn} {n}")
     c = R.ddpm_constants(50, "linear", beta_start=0.001, beta_end=0.05)
     for n in R.CONSTANT_NAMES:
-        np.testing.assert_array_equal(c[n].numpy(), g[f"linearcfg_50_{n}"])
+        np.testing.assert_allclose(c[n].numpy(), g[f"linearcfg_50_{n}"], rtol=3e-7, atol=1e-9)
 
 
 def _rb_shapes(cin, cout, with_t):
@@ -99,8 +102,8 @@ def test_down_up_sinusoid():
     close(F.conv2d(T(g["down_x"]), w, b, stride=2, padding=1), g["down_y"], 2e-6, 1e-5)
     w, b = T(make_param("ups.9.3.weight", (32, 32, 4, 4))), T(make_param("ups.9.3.bias", (32,)))
     close(F.conv_transpose2d(T(g["up_x"]), w, b, stride=2, padding=1), g["up_y"], 2e-6, 1e-5)
-    close(R.sinusoidal_embedding(T(g["pe_t_long"]), 32), g["pe_long"], 0, 0)
-    close(R.sinusoidal_embedding(T(g["pe_t_float"]), 32), g["pe_float"], 0, 0)
+    close(R.sinusoidal_embedding(T(g["pe_t_long"]), 32), g["pe_long"], 1e-6, 0)
+    close(R.sinusoidal_embedding(T(g["pe_t_float"]), 32), g["pe_float"], 1e-6, 0)
 
 
 @pytest.mark.parametrize("tag,lv,groups,order", [
@@ -142,9 +145,9 @@ def test_p_sample_updates():
 def test_sde_units():
     g = load_golden("sde_units")
     ve, vp = R.VESDE(0.01, 50.0, 1000), R.VPSDE(0.1, 20.0, 1000)
-    np.testing.assert_array_equal(ve.discrete_sigmas.numpy(), g["ve_discrete_sigmas"])
-    np.testing.assert_array_equal(vp.betas.numpy(), g["vp_betas"])
-    np.testing.assert_array_equal(vp.sqrt_1m_alphas_cumprod.numpy(), g["vp_sqrt_1m_alphas_cumprod"])
+    np.testing.assert_allclose(ve.discrete_sigmas.numpy(), g["ve_discrete_sigmas"], rtol=3e-7)
+    np.testing.assert_allclose(vp.betas.numpy(), g["vp_betas"], rtol=3e-7)
+    np.testing.assert_allclose(vp.sqrt_1m_alphas_cumprod.numpy(), g["vp_sqrt_1m_alphas_cumprod"], rtol=3e-7)
     tt, xx = T(g["tt"]), T(g["xx"])
     for name, sde in (("ve", ve), ("vp", vp)):
         d, gg = sde.sde(xx, tt)
@@ -230,7 +233,7 @@ def test_ddpm_chain_1000_steps():
     noise = lambda step: T(philox.normal_like(shape, seed, step, 0 if step == T_ else 1))  # noqa: E731
     with torch.no_grad():
         out = R.ddpm_sample_chain(lambda x, t: R.unet_forward(p, x, t), c, shape, noise, keep=(999, 900, 500, 100, 0))
-    np.testing.assert_array_equal(out["x_T"].numpy(), g["x_T"])
+    np.testing.assert_allclose(out["x_T"].numpy(), g["x_T"], rtol=0, atol=1e-6)
     for i in (999, 900, 500, 100, 0):
         close(out[i], g[f"x_{i}"], 1e-4, 0)
 
