@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""Benchmark of the north-star workload: images/sec of 1000-step DDPM sampling with the 64x64x3 U-Net
+(dim=32, dim_mults=[1,2,4,8], 8.08 M parameters, random weights, cosine schedule), bf16 internal dtype,
+batch 64 per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" is one complete 1000-step sampling chain of one 64-image batch per GPU (x_T drawn on the device,
+1000 x {time MLP, U-Net, posterior update} replayed as a hipGraph, final images resident in HBM, gathered over
+RCCL when N > 1). Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+# work per image per network evaluation at 64x64 (measured with hooks on the reference network; MAC = 2 FLOP,
+# bf16 activations, each conv / linear / attention-matmul input read once and output written once)
+GFLOP_PER_IMG_EVAL = 2.6634
+ALG_BYTES_PER_IMG_EVAL = 17.3e6
+WEIGHT_BYTES = 16.2e6
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU")
+    ap.add_argument("--image-size", type=int, default=64)
+    ap.add_argument("--timesteps", type=int, default=1000)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-graph", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(image_size, timesteps, budget_s):
+    """The CPU oracle (a pinned port of the reference path) timed on this host: p_sample steps at B=4."""
+    from oracle import philox, ref_cpu as R
+    from oracle.weights import make_state_dict, unet_param_shapes
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    p = R.to_torch(make_state_dict(unet_param_shapes()))
+    c = R.ddpm_constants(timesteps, "cosine")
+    B = 4
+    shape = (B, 3, image_size, image_size)
+    x = torch.from_numpy(philox.normal_like(shape, 0, timesteps, 0))
+    n, t0 = 0, time.perf_counter()
+    with torch.no_grad():
+        while True:
+            i = timesteps - 1 - n
+            t = torch.full((B,), i, dtype=torch.long)
+            eps = R.unet_forward(p, x, t)
+            x = R.p_sample_update(c, x, t, eps, torch.from_numpy(philox.normal_like(shape, 0, i, 1)))
+            n += 1
+            el = time.perf_counter() - t0
+            if (el >= budget_s and n >= 3) or n >= timesteps:
+                break
+    sec_per_step = el / n
+    return {"value": B / (sec_per_step * timesteps), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"CPU oracle, B={B} {image_size}x{image_size}, {n} p_sample steps in {el:.1f}s "
+                      f"({sec_per_step * 1e3:.1f} ms/step), extrapolated x{timesteps}"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from diffusion_model_nemo_amd import _native as N
+    from diffusion_model_nemo_amd.modules import GaussianDiffusion, Unet
+    from diffusion_model_nemo_amd.parallel import gather_images
+
+    torch.manual_seed(1234)
+    unet = Unet(input_dim=a.image_size, dim=32, dim_mults=[1, 2, 4, 8], channels=3, resnet_block_groups=8,
+                use_convnext=False, dropout=0.0, compute_dtype=a.dtype).to(dev).eval()
+    gd = GaussianDiffusion(timesteps=a.timesteps, schedule_name="cosine")
+    B, S = a.batch, a.image_size
+    shape = (B, 3, S, S)
+
+    def one_sample(k):
+        x0 = gd.p_sample_loop(unet, shape, device=dev, seed=1000 + k, image_offset=rank * B, return_device_tensor=True,
+                               use_graph=not a.no_graph)
+        return gather_images(x0) if world > 1 else x0
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for k in range(a.warmup):
+        one_sample(-1 - k)
+    fence()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        out = one_sample(k)
+    fence()
+    el = time.perf_counter() - t0
+    assert torch.isfinite(out).all()
+    tmax = torch.tensor([el], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    el = float(tmax.item())
+
+    # device time of the last chain, from HIP events recorded on the loop's own stream
+    loop_ms = N.loop_last_ms(unet.native_handle())
+
+    if rank == 0:
+        imgs = world * B * a.steps
+        sec_per_eval = (loop_ms / 1e3) / a.timesteps
+        alg_bytes = B * ALG_BYTES_PER_IMG_EVAL + WEIGHT_BYTES
+        res = {
+            "metric": "images/sec, 1000-step DDPM sample, 64x64 U-Net",
+            "value": imgs / el, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.dtype, "data": "synthetic (Philox x_T and noise, random-init weights)",
+            "config": {"workload": f"{S}x{S}x3 DDPM U-Net (dim 32, mults 1-2-4-8), {a.timesteps}-step p_sample_loop, "
+                                   f"batch {B} per GPU", "global_batch": world * B, "parallelism": f"dp{world}",
+                       "graph": not a.no_graph},
+            "roofline": {"bound": "hbm", "achieved": alg_bytes / sec_per_eval / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg_bytes / sec_per_eval / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "one denoising step (captured graph: time MLP + U-Net + posterior update)",
+                         "launch_ms": sec_per_eval * 1e3,
+                         "tflops": B * GFLOP_PER_IMG_EVAL / sec_per_eval / 1e3},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(S, a.timesteps, a.cpu_seconds)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

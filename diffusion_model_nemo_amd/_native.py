@@ -45,6 +45,7 @@ SIGNATURES = {
     "dmn_pc_sample_loop": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _f, _u64, _i64, _vp, _vp, _vp,
                                 _sz, _vp, _i]),
     "dmn_sample_workspace_bytes": (_i, [_vp, _i, _i, _i, C.POINTER(_sz)]),
+    "dmn_loop_last_ms": (_i, [_vp, C.POINTER(_f)]),
     "dmn_fill_normal": (_i, [_vp, _i, _i, _u64, C.c_uint32, _i64, _f, _vp]),
     "dmn_test_conv2d": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp,
                              _vp, _vp, _i, _i, _i, _vp, _i, C.POINTER(_i), _i, _i, _vp]),
@@ -76,6 +77,12 @@ def lib():
 def check(rc: int):
     if rc != 0:
         raise DmnError(f"libdmn_hip error {rc}: {lib().dmn_last_error().decode()}")
+
+
+def loop_last_ms(handle) -> float:
+    ms = C.c_float()
+    check(lib().dmn_loop_last_ms(handle, C.byref(ms)))
+    return float(ms.value)
 
 
 def ptr(t) -> Optional[int]:

@@ -129,7 +129,25 @@ extern "C" int dmn_sample_workspace_bytes(const DmnUnet* u, int B, int H, int W,
 
 // Runs `body` nsteps times; when allowed, captures it once into a graph (cached on the handle) and replays it.
 template <typename Body>
+static int run_loop_inner(DmnUnet* u, const SampleKey& key, int nsteps, hipStream_t s, int use_graph, Body body);
+
+template <typename Body>
 static int run_loop(DmnUnet* u, const SampleKey& key, int nsteps, hipStream_t s, int use_graph, Body body) {
+    if (!u->ev_start) {
+        DMN_HIP_CHECK(hipEventCreate(&u->ev_start));
+        DMN_HIP_CHECK(hipEventCreate(&u->ev_stop));
+    }
+    u->ev_valid = false;
+    DMN_HIP_CHECK(hipEventRecord(u->ev_start, s));
+    int rc = run_loop_inner(u, key, nsteps, s, use_graph, body);
+    if (rc) return rc;
+    DMN_HIP_CHECK(hipEventRecord(u->ev_stop, s));
+    u->ev_valid = true;
+    return DMN_OK;
+}
+
+template <typename Body>
+static int run_loop_inner(DmnUnet* u, const SampleKey& key, int nsteps, hipStream_t s, int use_graph, Body body) {
     if (!use_graph || s == nullptr) {
         for (int i = 0; i < nsteps; ++i) {
             int rc = body();
@@ -230,6 +248,14 @@ extern "C" int dmn_pc_sample_loop(DmnUnet* u, const float* table, int nsteps, fl
         return launch_advance(lb.step_idx, s);
     };
     return run_loop(u, key, nsteps, s, use_graph, body);
+}
+
+extern "C" int dmn_loop_last_ms(DmnUnet* u, float* ms) {
+    DMN_REQUIRE(u && ms, DMN_ERR_INVALID, "dmn_loop_last_ms: null argument");
+    DMN_REQUIRE(u->ev_valid, DMN_ERR_INVALID, "dmn_loop_last_ms: no sampling loop has run on this handle");
+    DMN_HIP_CHECK(hipEventSynchronize(u->ev_stop));
+    DMN_HIP_CHECK(hipEventElapsedTime(ms, u->ev_start, u->ev_stop));
+    return DMN_OK;
 }
 
 // ---- per-kernel test hook ----------------------------------------------------------------------------------

@@ -644,6 +644,8 @@ extern "C" int dmn_unet_create(const DmnUnetCfg* cfg, DmnUnet** out) {
 extern "C" void dmn_unet_destroy(DmnUnet* u) {
     if (!u) return;
     if (u->graph_exec) (void)hipGraphExecDestroy(u->graph_exec);
+    if (u->ev_start) (void)hipEventDestroy(u->ev_start);
+    if (u->ev_stop) (void)hipEventDestroy(u->ev_stop);
     free_weights(u);
     delete u;
 }

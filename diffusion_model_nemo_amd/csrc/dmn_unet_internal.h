@@ -60,6 +60,9 @@ struct DmnUnet {
     // cached step graph of the sampling loops
     hipGraphExec_t graph_exec = nullptr;
     SampleKey graph_key = {};
+    // HIP events bracketing the last sampling loop on its stream (device time of the loop)
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool ev_valid = false;
 };
 
 int pack_conv(PackedConv& pc, int dtype, const float* w, const float* bias, int Cout, int Cin, int kh, int kw, int stride,

@@ -193,7 +193,8 @@ class GaussianDiffusion(AbstractDiffusionProcess):
 
     @torch.no_grad()
     def p_sample_loop(self, model, shape, device=None, use_tqdm=True, keep: str = "all", seed: Optional[int] = None,
-                      image_offset: int = 0, x_T: Optional[torch.Tensor] = None, return_device_tensor: bool = False):
+                      image_offset: int = 0, x_T: Optional[torch.Tensor] = None, return_device_tensor: bool = False,
+                      use_graph: bool = True):
         """Algorithm 2 of DDPM (gaussian_diffusion.py:171-189).
 
         Default return value as in the reference: a Python list of T CPU tensors mapped to [0, 1] by (x + 1) / 2.
@@ -214,7 +215,7 @@ class GaussianDiffusion(AbstractDiffusionProcess):
             x = x_T.to(device, torch.float32).contiguous().clone()
         else:
             x = torch.empty(shape, dtype=torch.float32, device=device)
-        hist = self._run_chain(model, x, 0, self.timesteps, x_T is None, keep, seed, image_offset)
+        hist = self._run_chain(model, x, 0, self.timesteps, x_T is None, keep, seed, image_offset, use_graph=use_graph)
         if return_device_tensor:
             return x
         if keep == "last":

@@ -1,0 +1,58 @@
+"""Batch-sharded sampling over the GPUs of one node: one process per GPU, a single RCCL all-gather at the end.
+
+Every operation of the denoising chain is per-image (GroupNorm and attention normalise inside an image, the
+posterior update is elementwise, the timestep is shared), so rank r simply samples images
+[r * B/world, (r + 1) * B/world) with the noise generator keyed by the GLOBAL image index; the result does not
+depend on the split. The reference samples on a single process (`@rank_zero_only`,
+diffusion_model_nemo/models/abstract_diffusion_model.py:107); its only multi-GPU path is Lightning DDP training.
+"""
+from typing import Callable, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(global_batch: int, rank: int, world: int) -> Tuple[int, int]:
+    """[start, stop) of the images owned by `rank`; the remainder goes to the lowest ranks."""
+    base, rem = divmod(global_batch, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def gather_images(local: torch.Tensor, group=None) -> torch.Tensor:
+    """All-gather equally sized per-rank image batches [b, C, H, W] into [world * b, C, H, W] (one collective)."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return local
+    local = local.contiguous()
+    out = torch.empty((world * local.shape[0], *local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local, group=group)
+    return out
+
+
+def gather_ragged(local: torch.Tensor, global_batch: int, group=None) -> torch.Tensor:
+    """All-gather when the global batch does not divide evenly: pad to the largest shard, gather once, trim."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if world == 1:
+        return local
+    sizes = [shard_range(global_batch, r, world) for r in range(world)]
+    biggest = max(b - a for a, b in sizes)
+    pad = biggest - local.shape[0]
+    if pad:
+        local = torch.cat([local, local.new_zeros((pad, *local.shape[1:]))], dim=0)
+    full = gather_images(local, group)
+    parts = [full[r * biggest: r * biggest + (b - a)] for r, (a, b) in enumerate(sizes)]
+    return torch.cat(parts, dim=0)
+
+
+def sharded_sample(sample_fn: Callable[[int, int], torch.Tensor], global_batch: int, group=None) -> torch.Tensor:
+    """`sample_fn(local_batch, image_offset)` -> this rank's final images [local_batch, C, H, W] on its device.
+    Returns the full [global_batch, C, H, W] tensor on every rank."""
+    if not dist.is_available() or not dist.is_initialized():
+        return sample_fn(global_batch, 0)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    start, stop = shard_range(global_batch, rank, world)
+    local = sample_fn(stop - start, start)
+    if global_batch % world == 0:
+        return gather_images(local, group)
+    return gather_ragged(local, global_batch, group)

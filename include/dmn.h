@@ -105,6 +105,9 @@ int dmn_pc_sample_loop(DmnUnet* u, const float* table, int nsteps, float* x, int
                        uint64_t seed, int64_t img_offset, float* keep, float* x_mean_out, void* workspace,
                        size_t workspace_bytes, void* stream, int use_graph);
 int dmn_sample_workspace_bytes(const DmnUnet* u, int B, int H, int W, size_t* bytes);
+/* Device time (HIP events on the loop's stream) of the last dmn_*_sample_loop call on this handle; waits for it.
+ * No counterpart in the reference: measurement hook used by bench.py. */
+int dmn_loop_last_ms(DmnUnet* u, float* ms);
 
 /* N(0,1) * scale into x[B][per] with the library's generator (prior draws; tests). */
 int dmn_fill_normal(float* x, int B, int per, uint64_t seed, uint32_t step, int64_t img_offset, float scale, void* stream);
