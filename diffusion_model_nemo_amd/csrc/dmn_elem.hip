@@ -106,10 +106,13 @@ __global__ void __launch_bounds__(kNormThreads) norm_apply_kernel(const NormAppl
 // device-resident step counter (so a captured graph can be replayed for every step).
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) time_mlp_kernel(const TimeArgs a) {
+    // grid (chunks, B): every workgroup recomputes the two small dense layers (20k MACs) and then produces its
+    // slice of the per-block biases. All matrix rows are read coalesced, one wave per output + butterfly sum.
     __shared__ float sE[64];
     __shared__ float sH[512];
     __shared__ float sT[512];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
     const int dim = a.dim, hid = 4 * a.dim, half = a.dim / 2;
     float label;
     if (a.t) {
@@ -123,25 +126,28 @@ __global__ void __launch_bounds__(256) time_mlp_kernel(const TimeArgs a) {
         sE[half + tid] = cosf(e);
     }
     __syncthreads();
-    for (int o = tid; o < hid; o += 256) {
-        float acc = 0.f;
+    for (int o = wave; o < hid; o += 4) {
         const float* w = a.w1 + (size_t)o * dim;
-        for (int k = 0; k < dim; ++k) acc = fmaf(sE[k], w[k], acc);
-        acc += a.b1[o];
-        sH[o] = 0.5f * acc * (1.0f + erff(acc * 0.70710678118654752440f));
-    }
-    __syncthreads();
-    for (int o = tid; o < hid; o += 256) {
         float acc = 0.f;
-        const float* w = a.w2 + (size_t)o * hid;
-        for (int k = 0; k < hid; ++k) acc = fmaf(sH[k], w[k], acc);
-        acc += a.b2[o];
-        sT[o] = silu_precise(acc);
+        for (int k = lane; k < dim; k += 64) acc = fmaf(sE[k], w[k], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            acc += a.b1[o];
+            sH[o] = 0.5f * acc * (1.0f + erff(acc * 0.70710678118654752440f));
+        }
     }
     __syncthreads();
-    // each wave computes outputs with a coalesced row read + wave reduction
-    const int wave = tid >> 6, lane = tid & 63;
-    for (int o = wave; o < a.nout; o += 4) {
+    for (int o = wave; o < hid; o += 4) {
+        const float* w = a.w2 + (size_t)o * hid;
+        float acc = 0.f;
+        for (int k = lane; k < hid; k += 64) acc = fmaf(sH[k], w[k], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) sT[o] = silu_precise(acc + a.b2[o]);
+    }
+    __syncthreads();
+    const int per = (a.nout + gridDim.x - 1) / gridDim.x;
+    const int o0 = blockIdx.x * per, o1 = min(o0 + per, a.nout);
+    for (int o = o0 + wave; o < o1; o += 4) {
         const float* w = a.wb + (size_t)o * hid;
         float acc = 0.f;
         for (int k = lane; k < hid; k += 64) acc = fmaf(sT[k], w[k], acc);
@@ -153,7 +159,7 @@ __global__ void __launch_bounds__(256) time_mlp_kernel(const TimeArgs a) {
 // ---------------------------------------------------------------------------------------------------
 // Ingest: init_conv 7x7 pad 3 (modules/unet.py:41,132) reading the reference's NCHW fp32 layout and
 // writing NHWC T. Cin is 3 (too thin for an MFMA K dimension): a direct fp32 VALU convolution with the
-// weights read through uniform (scalar) loads. 16x16 output pixels per workgroup, one pixel per thread.
+// weights ([Cin*49][Cout], transposed on the host) read through uniform (scalar) loads. 16x16 output pixels per workgroup, one pixel per thread.
 // ---------------------------------------------------------------------------------------------------
 template <typename T, int COUT>
 __global__ void __launch_bounds__(256) ingest_kernel(const IngestArgs a) {
@@ -181,9 +187,9 @@ __global__ void __launch_bounds__(256) ingest_kernel(const IngestArgs a) {
 #pragma unroll
             for (int kx = 0; kx < 7; ++kx) {
                 const float v = sIn[c][py + ky][px + kx];
-                const float* w = a.w + (c * 7 + ky) * 7 + kx;
+                const float* w = a.w + (size_t)((c * 7 + ky) * 7 + kx) * COUT;   // uniform address: scalar loads
 #pragma unroll
-                for (int o = 0; o < COUT; ++o) acc[o] = fmaf(v, w[(size_t)o * a.Cin * 49], acc[o]);
+                for (int o = 0; o < COUT; ++o) acc[o] = fmaf(v, w[o], acc[o]);
             }
     const int oy = ty * TS + py, ox = tx * TS + px;
     if (oy < a.H && ox < a.W) {
@@ -270,7 +276,7 @@ int launch_norm_apply(NormApplyArgs& a, hipStream_t s) {
 
 int launch_time_mlp(TimeArgs& a, hipStream_t s) {
     DMN_REQUIRE(a.dim <= 64 && a.dim % 2 == 0 && 4 * a.dim <= 512, DMN_ERR_LIMIT, "time_mlp: dim=%d exceeds 64", a.dim);
-    hipLaunchKernelGGL(time_mlp_kernel, dim3(a.B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(time_mlp_kernel, dim3(8, a.B), dim3(256), 0, s, a);
     DMN_HIP_CHECK(hipGetLastError());
     return DMN_OK;
 }

@@ -95,7 +95,7 @@ int launch_time_mlp(TimeArgs& a, hipStream_t s);
 struct IngestArgs {
     int dtype;
     const float* x;   // [B][Cin][H][W]
-    const float* w;   // [Cout][Cin][7][7]
+    const float* w;   // [Cin][7][7][Cout] (transposed from the PyTorch layout on the host)
     const float* bias;
     void* out;        // [B][H][W][Cout]
     int B, Cin, H, W, Cout;

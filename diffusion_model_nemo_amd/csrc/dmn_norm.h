@@ -9,18 +9,25 @@
 __device__ __forceinline__ void norm_coefs_to_lds(const NormIn& n, int b, int C, float* sCoef, float* sTmp) {
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
-    for (int g = tid; g < n.G; g += nthr) {
+    // one wave per group: lanes stride over the slots, then a fixed-order butterfly (deterministic)
+    const int wave = tid >> 6, lane = tid & 63, nwaves = nthr >> 6;
+    for (int g = wave; g < n.G; g += nwaves) {
         const float* p = n.stats + ((size_t)(b * n.G + g) * n.slots) * 2;
         float s = 0.f, ss = 0.f;
-        for (int i = 0; i < n.slots; ++i) {
-            s += p[2 * i];
-            ss += p[2 * i + 1];
+        for (int i = lane; i < n.slots; i += 64) {
+            const float2 v = *reinterpret_cast<const float2*>(p + 2 * i);
+            s += v.x;
+            ss += v.y;
         }
-        const float mean = s * n.inv_count;
-        float var = ss * n.inv_count - mean * mean;
-        var = var > 0.f ? var : 0.f;
-        sTmp[2 * g] = mean;
-        sTmp[2 * g + 1] = 1.0f / sqrtf(var + 1e-5f);
+        s = wave_sum(s);
+        ss = wave_sum(ss);
+        if (lane == 0) {
+            const float mean = s * n.inv_count;
+            float var = ss * n.inv_count - mean * mean;
+            var = var > 0.f ? var : 0.f;
+            sTmp[2 * g] = mean;
+            sTmp[2 * g + 1] = 1.0f / sqrtf(var + 1e-5f);
+        }
     }
     __syncthreads();
     const int cpg = C / n.G;

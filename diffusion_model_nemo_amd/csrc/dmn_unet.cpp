@@ -667,10 +667,14 @@ extern "C" int dmn_unet_load_weights(DmnUnet* u, const DmnTensorDesc* params, in
     for (int i = 0; i < c.n_mults; ++i) dims.push_back(dim * c.dim_mults[i]);
     std::vector<float> twb, tbb;
 
-    {   // ingest weights stay fp32 [Cout][Cin][7][7]
+    {   // ingest weights stay fp32, transposed to [Cin*49][Cout] so a tap's Cout weights are contiguous
         GETP(w, "init_conv.weight", dim, c.channels, 7, 7);
         GETP(b, "init_conv.bias", dim);
-        if ((rc = upload_f32(w->data, (size_t)dim * c.channels * 49, &u->init_w))) return rc;
+        const int taps = c.channels * 49;
+        std::vector<float> wt((size_t)dim * taps);
+        for (int o = 0; o < dim; ++o)
+            for (int k = 0; k < taps; ++k) wt[(size_t)k * dim + o] = w->data[(size_t)o * taps + k];
+        if ((rc = upload_f32(wt.data(), wt.size(), &u->init_w))) return rc;
         if ((rc = upload_f32(b->data, dim, &u->init_b))) return rc;
     }
     if (c.with_time_emb) {
