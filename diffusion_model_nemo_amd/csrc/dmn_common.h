@@ -29,7 +29,7 @@ template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return (__bf16)v; }
 
-__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 // The fp32 parity path uses the full-precision exponential so SiLU agrees with the reference's
 // ATen kernel to rounding; the bf16 path may use the fast one.
 __device__ __forceinline__ float silu_precise(float v) { return v / (1.0f + expf(-v)); }

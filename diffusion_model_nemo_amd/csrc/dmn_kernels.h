@@ -4,6 +4,8 @@
 #include "dmn_common.h"
 
 enum { DMN_F32 = 0, DMN_BF16 = 1 };
+// convolution shapes the implicit-GEMM kernel is specialised for
+enum { DMN_K3X3 = 0, DMN_K1X1 = 1, DMN_K4X4S2 = 2, DMN_KT2X2 = 3 };
 
 // ---- group-norm statistics passed between kernels -----------------------------------------------
 // A producer writes, for every (image, group), `slots` partial {sum, sum of squares} pairs, one per
@@ -42,13 +44,10 @@ struct ConvArgs {
     int Ho, Wo;           // tile-space output extent (for a transposed conv: the input extent)
     int out_H, out_W;     // extent of the output tensor
     int out_sy, out_sx;
-    int stride;
-    int ntaps;
-    signed char tap_dy[16], tap_dx[16];
-    int ext_y, ext_x;     // 1 + max tap offset
+    int kind;             // DMN_K3X3 / DMN_K1X1 / DMN_K4X4S2 / DMN_KT2X2 (fixes taps, extent and stride)
     int nphase;
     ConvPhase phase[4];
-    const void* w;        // packed [phase][Cin/kChunk][Cout][ntaps][kChunk]
+    const void* w;        // packed [phase][Cin/kChunk][ntaps][Cout][kChunk]
     const float* bias;    // [Cout] or nullptr
     void* out;            // [B][out_H][out_W][Cout]
     int Cout;

@@ -43,57 +43,59 @@ static int upload(const void* host, size_t bytes, void** dev) {
 static int upload_f32(const float* host, size_t n, float** dev) { return upload(host, n * 4, (void**)dev); }
 
 // w: [Cout][Cin][kh][kw] (or [Cin][Cout][4][4] when transposed). Packed layout per phase:
-// [Cin/kch][Cout][ntaps][kch], tap = ky*kw + kx (conv) or a*2+b (transposed phase).
+// [Cin/kch][ntaps][Cout][kch], tap = ky*kw + kx (conv) or a*2+b (transposed phase).
 int pack_conv(PackedConv& pc, int dtype, const float* w, const float* bias, int Cout, int Cin, int kh, int kw, int stride,
               int pad, bool transposed) {
     const int kch = dtype == DMN_F32 ? 16 : 32;
     DMN_REQUIRE(Cin % kch == 0, DMN_ERR_WEIGHTS, "conv weight: Cin=%d not a multiple of %d", Cin, kch);
     pc.Cin = Cin;
     pc.Cout = Cout;
-    pc.stride = transposed ? 1 : stride;
     pc.transposed = transposed;
+    pc.pad = pad;
     std::vector<float> packed;
     if (!transposed) {
+        if (kh == 3 && kw == 3 && stride == 1 && pad == 1) pc.kind = DMN_K3X3;
+        else if (kh == 1 && kw == 1 && stride == 1 && pad == 0) pc.kind = DMN_K1X1;
+        else if (kh == 4 && kw == 4 && stride == 2 && pad == 1) pc.kind = DMN_K4X4S2;
+        else {
+            dmn_set_error("conv %dx%d stride %d pad %d has no kernel specialisation", kh, kw, stride, pad);
+            return DMN_ERR_WEIGHTS;
+        }
+        pc.stride = stride;
         pc.ntaps = kh * kw;
-        pc.ext_y = kh;
-        pc.ext_x = kw;
+        pc.ext = kh;
         pc.nphase = 1;
         pc.phase[0] = ConvPhase{pad, pad, 0, 0, 0};
-        for (int t = 0; t < pc.ntaps; ++t) {
-            pc.tap_dy[t] = (signed char)(t / kw);
-            pc.tap_dx[t] = (signed char)(t % kw);
-        }
         packed.resize((size_t)Cin * Cout * pc.ntaps);
         for (int ch = 0; ch < Cin / kch; ++ch)
-            for (int o = 0; o < Cout; ++o)
-                for (int t = 0; t < pc.ntaps; ++t)
+            for (int t = 0; t < pc.ntaps; ++t)
+                for (int o = 0; o < Cout; ++o)
                     for (int k = 0; k < kch; ++k)
-                        packed[(((size_t)ch * Cout + o) * pc.ntaps + t) * kch + k] =
+                        packed[(((size_t)ch * pc.ntaps + t) * Cout + o) * kch + k] =
                             w[((size_t)o * Cin + ch * kch + k) * pc.ntaps + t];
     } else {
         DMN_REQUIRE(kh == 4 && kw == 4 && stride == 2 && pad == 1, DMN_ERR_WEIGHTS, "transposed conv: only 4x4 s2 p1");
+        pc.kind = DMN_KT2X2;
+        pc.stride = 1;
         pc.ntaps = 4;
-        pc.ext_y = pc.ext_x = 2;
+        pc.ext = 2;
         pc.nphase = 4;
-        for (int t = 0; t < 4; ++t) {
-            pc.tap_dy[t] = (signed char)(t / 2);
-            pc.tap_dx[t] = (signed char)(t % 2);
-        }
         const size_t per_phase = (size_t)Cin * Cout * 4;
         packed.resize(per_phase * 4);
         for (int ph = 0; ph < 4; ++ph) {
             const int py = ph / 2, px = ph % 2;
             pc.phase[ph] = ConvPhase{1 - py, 1 - px, py, px, (long long)(per_phase * ph)};
             for (int ch = 0; ch < Cin / kch; ++ch)
-                for (int o = 0; o < Cout; ++o)
-                    for (int t = 0; t < 4; ++t) {
-                        const int dy = t / 2, dx = t % 2;
-                        const int ky = py == 0 ? 3 - 2 * dy : 2 - 2 * dy;
-                        const int kx = px == 0 ? 3 - 2 * dx : 2 - 2 * dx;
+                for (int t = 0; t < 4; ++t) {
+                    // output row 2y+py receives input row y-1+dy through kernel row ky (oy = 2 iy - 1 + ky)
+                    const int dy = t / 2, dx = t % 2;
+                    const int ky = py == 0 ? 3 - 2 * dy : 2 - 2 * dy;
+                    const int kx = px == 0 ? 3 - 2 * dx : 2 - 2 * dx;
+                    for (int o = 0; o < Cout; ++o)
                         for (int k = 0; k < kch; ++k)
-                            packed[per_phase * ph + (((size_t)ch * Cout + o) * 4 + t) * kch + k] =
+                            packed[per_phase * ph + (((size_t)ch * 4 + t) * Cout + o) * kch + k] =
                                 w[(((size_t)(ch * kch + k) * Cout + o) * 4 + ky) * 4 + kx];
-                    }
+                }
         }
     }
     int rc;
@@ -122,12 +124,7 @@ void conv_args_from(const PackedConv& pc, int dtype, ConvArgs& a, int B, int H, 
     a.B = B;
     a.H = H;
     a.W = W;
-    a.stride = pc.stride;
-    a.ntaps = pc.ntaps;
-    memcpy(a.tap_dy, pc.tap_dy, sizeof(a.tap_dy));
-    memcpy(a.tap_dx, pc.tap_dx, sizeof(a.tap_dx));
-    a.ext_y = pc.ext_y;
-    a.ext_x = pc.ext_x;
+    a.kind = pc.kind;
     a.nphase = pc.nphase;
     for (int i = 0; i < 4; ++i) a.phase[i] = pc.phase[i];
     a.w = pc.w;
@@ -140,9 +137,8 @@ void conv_args_from(const PackedConv& pc, int dtype, ConvArgs& a, int B, int H, 
         a.out_W = 2 * W;
         a.out_sy = a.out_sx = 2;
     } else {
-        const int pad = pc.phase[0].pad_y;
-        a.Ho = (H + 2 * pad - pc.ext_y) / pc.stride + 1;
-        a.Wo = (W + 2 * pad - pc.ext_x) / pc.stride + 1;
+        a.Ho = (H + 2 * pc.pad - pc.ext) / pc.stride + 1;
+        a.Wo = (W + 2 * pc.pad - pc.ext) / pc.stride + 1;
         a.out_H = a.Ho;
         a.out_W = a.Wo;
         a.out_sy = a.out_sx = 1;

@@ -6,11 +6,10 @@
 #include "dmn_kernels.h"
 
 struct PackedConv {
-    void* w = nullptr;       // device, packed [phase][Cin/kch][Cout][ntaps][kch] in the network dtype
+    void* w = nullptr;       // device, packed [phase][Cin/kch][ntaps][Cout][kch] in the network dtype
     float* bias = nullptr;   // device fp32 [Cout] or nullptr
-    int Cin = 0, Cout = 0, stride = 1, ntaps = 0, ext_y = 0, ext_x = 0, nphase = 1;
+    int Cin = 0, Cout = 0, kind = 0, stride = 1, pad = 0, ntaps = 0, ext = 0, nphase = 1;
     bool transposed = false;
-    signed char tap_dy[16] = {0}, tap_dx[16] = {0};
     ConvPhase phase[4] = {};
 };
 
