@@ -12,6 +12,7 @@ namespace {
 // Grid: (chunks, B); every workgroup owns kPixPerWg consecutive pixels of one image.
 // ---------------------------------------------------------------------------------------------------
 constexpr int kNormThreads = 256;
+constexpr int kNormElems = 8192;   // elements per workgroup
 
 template <typename T>
 __global__ void __launch_bounds__(kNormThreads) norm_apply_kernel(const NormApplyArgs a, int pix_per_wg) {
@@ -22,8 +23,6 @@ __global__ void __launch_bounds__(kNormThreads) norm_apply_kernel(const NormAppl
     float* sTmp = sCoef + 3 * a.C;            // max(2*G_in, 2*4*G_out)
     const int b = blockIdx.y;
     const int C = a.C;
-    norm_coefs_to_lds(a.norm, b, C, sCoef, sTmp);
-
     const int vec_per_pix = C / PER;
     const int p0 = blockIdx.x * pix_per_wg;
     const int p1 = min(p0 + pix_per_wg, a.HW);
@@ -32,37 +31,62 @@ __global__ void __launch_bounds__(kNormThreads) norm_apply_kernel(const NormAppl
     const T* res = a.res ? static_cast<const T*>(a.res) + ((size_t)b * a.HW + p0) * C : nullptr;
     T* out = static_cast<T*>(a.out) + ((size_t)b * a.HW + p0) * C;
 
+    // issue every data load first (a workgroup owns at most kNormElems elements), then derive the
+    // normalisation coefficients while they are in flight
+    constexpr int NV = kNormElems / PER / kNormThreads;
+    V vin[NV], vres[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = threadIdx.x + j * kNormThreads;
+        if (i < nvec) {
+            vin[j] = *reinterpret_cast<const V*>(in + (size_t)i * PER);
+            if (res) vres[j] = *reinterpret_cast<const V*>(res + (size_t)i * PER);
+        }
+    }
+    norm_coefs_to_lds(a.norm, b, C, sCoef, sTmp);
+
     const bool want = a.epi.stats != nullptr;
     const int Go = want ? a.epi.G : 1;
     const int cpg_o = C / Go;
     // A thread always visits the same channel offset because kNormThreads % vec_per_pix == 0 (checked by the
-    // launcher), so the group of each of its quads is fixed.
-    // statistics are accumulated per 4-channel quad of the thread's 16-byte vector (a quad never straddles an
-    // output group because groups hold a multiple of 4 channels)
+    // launcher), so the group of each of its quads is fixed. Statistics are accumulated per 4-channel quad of
+    // the thread's 16-byte vector (a quad never straddles an output group: groups hold a multiple of 4 channels).
     constexpr int NQ = PER / 4;
     float s[NQ], ss[NQ];
     int qgroup[NQ];
+    const int cb = (threadIdx.x % vec_per_pix) * PER;
 #pragma unroll
-    for (int k = 0; k < NQ; ++k) { s[k] = ss[k] = 0.f; qgroup[k] = 0; }
-    for (int i = threadIdx.x; i < nvec; i += kNormThreads) {
-        const int cb = (i % vec_per_pix) * PER;
-        Vec16<T> v, r;
-        v.v = *reinterpret_cast<const V*>(in + (size_t)i * PER);
-        if (res) r.v = *reinterpret_cast<const V*>(res + (size_t)i * PER);
+    for (int k = 0; k < NQ; ++k) {
+        s[k] = ss[k] = 0.f;
+        qgroup[k] = (cb + 4 * k) / cpg_o;
+    }
+    float ca[PER], cbeta[PER], ct[PER];
 #pragma unroll
-        for (int k = 0; k < NQ; ++k) qgroup[k] = (cb + 4 * k) / cpg_o;
+    for (int e = 0; e < PER; ++e) {
+        ca[e] = sCoef[cb + e];
+        cbeta[e] = sCoef[C + cb + e];
+        ct[e] = sCoef[2 * C + cb + e];
+    }
 #pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            float y = v.get(j) * sCoef[cb + j] + sCoef[C + cb + j];
-            if (a.norm.silu) y = (sizeof(T) == 4) ? silu_precise(y) : silu_f(y);
-            y += sCoef[2 * C + cb + j];
-            if (res) y += r.get(j);
-            v.set(j, y);
-            const float yr = v.get(j);  // statistics of the value the consumer will read
-            s[j / 4] += yr;
-            ss[j / 4] += yr * yr;
+    for (int j = 0; j < NV; ++j) {
+        const int i = threadIdx.x + j * kNormThreads;
+        if (i < nvec) {
+            Vec16<T> v, r;
+            v.v = vin[j];
+            if (res) r.v = vres[j];
+#pragma unroll
+            for (int e = 0; e < PER; ++e) {
+                float y = v.get(e) * ca[e] + cbeta[e];
+                if (a.norm.silu) y = (sizeof(T) == 4) ? silu_precise(y) : silu_f(y);
+                y += ct[e];
+                if (res) y += r.get(e);
+                v.set(e, y);
+                const float yr = v.get(e);  // statistics of the value the consumer will read
+                s[e / 4] += yr;
+                ss[e / 4] += yr * yr;
+            }
+            *reinterpret_cast<V*>(out + (size_t)i * PER) = v.v;
         }
-        *reinterpret_cast<V*>(out + (size_t)i * PER) = v.v;
     }
     if (want) {
         // threads -> LDS per (group, thread) would be large; instead reduce with LDS atomics-free two-step:
@@ -106,13 +130,13 @@ __global__ void __launch_bounds__(kNormThreads) norm_apply_kernel(const NormAppl
 // device-resident step counter (so a captured graph can be replayed for every step).
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) time_mlp_kernel(const TimeArgs a) {
-    // grid (chunks, B): every workgroup recomputes the two small dense layers (20k MACs) and then produces its
-    // slice of the per-block biases. All matrix rows are read coalesced, one wave per output + butterfly sum.
+    // grid (chunks, rows): every workgroup recomputes the two small dense layers (20k MACs) and then produces
+    // its slice of the per-block biases. Weights are stored TRANSPOSED ([in][out]) so that thread o reads
+    // column o coalesced and all its loads are independent (the kernel is pure latency otherwise).
     __shared__ float sE[64];
     __shared__ float sH[512];
     __shared__ float sT[512];
     const int b = blockIdx.y, tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
     const int dim = a.dim, hid = 4 * a.dim, half = a.dim / 2;
     float label;
     if (a.t) {
@@ -126,33 +150,27 @@ __global__ void __launch_bounds__(256) time_mlp_kernel(const TimeArgs a) {
         sE[half + tid] = cosf(e);
     }
     __syncthreads();
-    for (int o = wave; o < hid; o += 4) {
-        const float* w = a.w1 + (size_t)o * dim;
+    for (int o = tid; o < hid; o += 256) {
         float acc = 0.f;
-        for (int k = lane; k < dim; k += 64) acc = fmaf(sE[k], w[k], acc);
-        acc = wave_sum(acc);
-        if (lane == 0) {
-            acc += a.b1[o];
-            sH[o] = 0.5f * acc * (1.0f + erff(acc * 0.70710678118654752440f));
-        }
+#pragma unroll 16
+        for (int k = 0; k < dim; ++k) acc = fmaf(sE[k], a.w1[(size_t)k * hid + o], acc);
+        acc += a.b1[o];
+        sH[o] = 0.5f * acc * (1.0f + erff(acc * 0.70710678118654752440f));
     }
     __syncthreads();
-    for (int o = wave; o < hid; o += 4) {
-        const float* w = a.w2 + (size_t)o * hid;
+    for (int o = tid; o < hid; o += 256) {
         float acc = 0.f;
-        for (int k = lane; k < hid; k += 64) acc = fmaf(sH[k], w[k], acc);
-        acc = wave_sum(acc);
-        if (lane == 0) sT[o] = silu_precise(acc + a.b2[o]);
+#pragma unroll 16
+        for (int k = 0; k < hid; ++k) acc = fmaf(sH[k], a.w2[(size_t)k * hid + o], acc);
+        sT[o] = silu_precise(acc + a.b2[o]);
     }
     __syncthreads();
-    const int per = (a.nout + gridDim.x - 1) / gridDim.x;
-    const int o0 = blockIdx.x * per, o1 = min(o0 + per, a.nout);
-    for (int o = o0 + wave; o < o1; o += 4) {
-        const float* w = a.wb + (size_t)o * hid;
+    const int o = blockIdx.x * 256 + tid;
+    if (o < a.nout) {
         float acc = 0.f;
-        for (int k = lane; k < hid; k += 64) acc = fmaf(sT[k], w[k], acc);
-        acc = wave_sum(acc);
-        if (lane == 0) a.out[(size_t)b * a.nout + o] = acc + a.bb[o];
+#pragma unroll 16
+        for (int k = 0; k < hid; ++k) acc = fmaf(sT[k], a.wb[(size_t)k * a.nout + o], acc);
+        a.out[(size_t)b * a.nout + o] = acc + a.bb[o];
     }
 }
 
@@ -244,8 +262,8 @@ __global__ void __launch_bounds__(256) egress_kernel(const EgressArgs a) {
 
 int norm_apply_slots(int HW, int C) {
     // enough workgroups to fill the chip at batch 64 while keeping >= 8 KiB per workgroup
-    int pix = 8192 / C;
-    if (pix < 16) pix = 16;
+    int pix = kNormElems / C;
+    if (pix < 1) pix = 1;
     if (pix > HW) pix = HW;
     return (HW + pix - 1) / pix;
 }
@@ -253,7 +271,7 @@ int norm_apply_slots(int HW, int C) {
 int launch_norm_apply(NormApplyArgs& a, hipStream_t s) {
     const int per = a.dtype == DMN_F32 ? 4 : 8;
     DMN_REQUIRE(a.C % per == 0 && a.C % a.norm.G == 0, DMN_ERR_INVALID, "norm_apply: C=%d groups=%d", a.C, a.norm.G);
-    DMN_REQUIRE(kNormThreads % (a.C / per) == 0 || !a.epi.stats, DMN_ERR_INVALID, "norm_apply: C=%d not supported with statistics", a.C);
+    DMN_REQUIRE(kNormThreads % (a.C / per) == 0 && a.C <= kNormElems, DMN_ERR_INVALID, "norm_apply: C=%d must be a power-of-two multiple of %d", a.C, per);
     const int slots = norm_apply_slots(a.HW, a.C);
     const int pix = (a.HW + slots - 1) / slots;
     int Go = 1;
@@ -276,7 +294,7 @@ int launch_norm_apply(NormApplyArgs& a, hipStream_t s) {
 
 int launch_time_mlp(TimeArgs& a, hipStream_t s) {
     DMN_REQUIRE(a.dim <= 64 && a.dim % 2 == 0 && 4 * a.dim <= 512, DMN_ERR_LIMIT, "time_mlp: dim=%d exceeds 64", a.dim);
-    hipLaunchKernelGGL(time_mlp_kernel, dim3(8, a.B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(time_mlp_kernel, dim3((a.nout + 255) / 256, a.rows), dim3(256), 0, s, a);
     DMN_HIP_CHECK(hipGetLastError());
     return DMN_OK;
 }

@@ -80,11 +80,11 @@ struct TimeArgs {
     const float* table;     // optional [nsteps][table_cols]; label = table[*step_idx][label_col]
     const int* step_idx;
     int table_cols, label_col;
-    int B, dim;             // sinusoid width; hidden = 4*dim
+    int rows, dim;          // rows = B, or 1 when every sample shares the table label; hidden = 4*dim
     const float* freqs;     // [dim/2]
-    const float* w1; const float* b1;   // [4dim][dim]
-    const float* w2; const float* b2;   // [4dim][4dim]
-    const float* wb; const float* bb;   // concatenated per-block linears [nout][4dim], [nout]
+    const float* w1; const float* b1;   // transposed [dim][4dim]
+    const float* w2; const float* b2;   // transposed [4dim][4dim]
+    const float* wb; const float* bb;   // concatenated per-block linears, transposed [4dim][nout], [nout]
     int nout;
     float* out;             // [B][nout]
 };

@@ -399,8 +399,11 @@ int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float,
     f.ar.reset(ws, ws_bytes, dry);
 
     float* tb = nullptr;
+    int tb_rows = B;
     if (c.with_time_emb) {
-        tb = (float*)f.alloc((size_t)B * u->tb_total * 4);
+        // in the sampling loops every image shares the step's label: one row, broadcast with stride 0
+        tb_rows = (t == nullptr && table != nullptr) ? 1 : B;
+        tb = (float*)f.alloc((size_t)tb_rows * u->tb_total * 4);
         TimeArgs ta;
         memset(&ta, 0, sizeof(ta));
         ta.t = t;
@@ -409,7 +412,7 @@ int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float,
         ta.step_idx = step_idx;
         ta.table_cols = DMN_TABLE_COLS;
         ta.label_col = 0;
-        ta.B = B;
+        ta.rows = tb_rows;
         ta.dim = c.dim;
         ta.freqs = u->freqs;
         ta.w1 = u->tw1; ta.b1 = u->tb1;
@@ -419,7 +422,7 @@ int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float,
         ta.out = tb;
         if (f.ok() && !dry) f.run(launch_time_mlp(ta, s));
     }
-    const int tbs = u->tb_total;
+    const int tbs = tb_rows == 1 ? 0 : u->tb_total;
 
     Act cur = f.new_act(c.dim, H, W);
     {
@@ -678,9 +681,15 @@ extern "C" int dmn_unet_load_weights(DmnUnet* u, const DmnTensorDesc* params, in
         GETP(b1, "time_mlp.1.bias", td);
         GETP(w2, "time_mlp.3.weight", td, td);
         GETP(b2, "time_mlp.3.bias", td);
-        if ((rc = upload_f32(w1->data, (size_t)td * dim, &u->tw1))) return rc;
+        // dense layers are stored transposed ([in][out]) for the one-thread-per-output time kernel
+        std::vector<float> w1t((size_t)td * dim), w2t((size_t)td * td);
+        for (int o = 0; o < td; ++o) {
+            for (int k = 0; k < dim; ++k) w1t[(size_t)k * td + o] = w1->data[(size_t)o * dim + k];
+            for (int k = 0; k < td; ++k) w2t[(size_t)k * td + o] = w2->data[(size_t)o * td + k];
+        }
+        if ((rc = upload_f32(w1t.data(), w1t.size(), &u->tw1))) return rc;
         if ((rc = upload_f32(b1->data, td, &u->tb1))) return rc;
-        if ((rc = upload_f32(w2->data, (size_t)td * td, &u->tw2))) return rc;
+        if ((rc = upload_f32(w2t.data(), w2t.size(), &u->tw2))) return rc;
         if ((rc = upload_f32(b2->data, td, &u->tb2))) return rc;
         // exp(arange(half) * -(ln 1e4 / (half-1))) evaluated in float32 like the reference
         // (parts/positional_encoding.py:13-15)
@@ -727,7 +736,11 @@ extern "C" int dmn_unet_load_weights(DmnUnet* u, const DmnTensorDesc* params, in
     }
     u->tb_total = (int)tbb.size();
     if (u->tb_total > 0) {
-        if ((rc = upload_f32(twb.data(), twb.size(), &u->twb))) return rc;
+        std::vector<float> twbt(twb.size());
+        const int nout = u->tb_total;
+        for (int o = 0; o < nout; ++o)
+            for (int k = 0; k < td; ++k) twbt[(size_t)k * nout + o] = twb[(size_t)o * td + k];
+        if ((rc = upload_f32(twbt.data(), twbt.size(), &u->twb))) return rc;
         if ((rc = upload_f32(tbb.data(), tbb.size(), &u->tbb))) return rc;
     }
     u->loaded = true;
