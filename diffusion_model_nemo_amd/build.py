@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libdmn_hip.so")
-SOURCES = ["dmn_conv.hip", "dmn_elem.hip", "dmn_attn.hip", "dmn_sampler.hip", "dmn_unet.cpp", "dmn_api.cpp"]
+SOURCES = ["dmn_conv.hip", "dmn_elem.hip", "dmn_attn.hip", "dmn_linattn.hip", "dmn_sampler.hip", "dmn_unet.cpp", "dmn_api.cpp"]
 ARCH = "gfx950"
 
 

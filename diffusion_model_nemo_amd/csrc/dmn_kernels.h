@@ -124,6 +124,26 @@ struct LinAttnArgs {
 int launch_linear_attention(LinAttnArgs& a, hipStream_t s);
 int linear_attention_splits(int n);
 
+// fused linear attention: GroupNorm(1)(x) -> to_qkv -> softmaxes -> context -> to_out + bias, plus GroupNorm(1)
+// statistics of the result. 4 heads of 32 channels; C in {32, 64, 128, 256}.
+struct LinAttnFusedArgs {
+    int dtype;
+    const void* x;        // [B][n][C]
+    void* y;              // [B][n][C]  to_out(...) + bias, before its GroupNorm
+    NormIn norm;          // PreNorm statistics / affine of x
+    const void *wq, *wk, *wv;   // [128/16][C/kChunk][64 lanes][16 B] fragment order
+    const void* wo;       // [C/16][128/kChunk][64][16 B], k in accumulator-operand order
+    const float* bias;    // [C] to_out bias
+    float* ctx_part;      // workspace [B][4][splits][32*32 + 64]
+    float* y_stats;       // [B][1][slices][2]
+    int B, n, C;
+    int slice1, splits;   // pass 1: workgroup slice in pixels (multiple of 32)
+    int tpw, slices;      // pass 2: workgroup slice = 64*tpw pixels
+};
+bool linattn_fused_supported(int C, int heads, int dim_head);
+void linattn_fused_plan(int n, int B, int C, int dtype, int* slice1, int* splits, int* tpw, int* slices);
+int launch_linattn_fused(LinAttnFusedArgs& a, hipStream_t s);
+
 // softmax attention core on qkv [B][n][3*hidden] -> out [B][n][hidden]
 struct AttnArgs {
     int dtype;

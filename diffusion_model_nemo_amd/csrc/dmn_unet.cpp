@@ -319,10 +319,54 @@ static Act resblock(Fwd& f, const ResBlockW& w, Act& x, Act* x2, const float* tb
     return out;
 }
 
+static Act lin_attn_tail(Fwd& f, const AttnW& w, Act& x, Act& y) {
+    Act out = f.new_act(x.C, x.H, x.W);
+    NormApplyArgs na;
+    memset(&na, 0, sizeof(na));
+    na.dtype = f.u->cfg.dtype;
+    na.in = y.p;
+    na.out = out.p;
+    na.res = x.p;
+    na.B = f.B;
+    na.HW = x.H * x.W;
+    na.C = x.C;
+    na.norm = norm_in(y, w.og, w.ob, f.B, 0, nullptr, 0);
+    if (f.ok() && !f.dry) f.run(launch_norm_apply(na, f.s));
+    f.free_act(y);
+    return out;
+}
+
 // Residual(PreNorm(dim, LinearAttention(dim))) (utils.py:68-93, parts/mha.py:44-59). x must carry GN(1) statistics.
 static Act lin_attn(Fwd& f, const AttnW& w, Act& x) {
     const DmnUnetCfg& c = f.u->cfg;
     const int hidden = c.heads * c.dim_head;
+    if (w.fq) {
+        LinAttnFusedArgs fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.dtype = c.dtype;
+        fa.x = x.p;
+        fa.norm = norm_in(x, w.ng, w.nb, f.B, 0, nullptr, 0);
+        fa.wq = w.fq;
+        fa.wk = w.fk;
+        fa.wv = w.fv;
+        fa.wo = w.fo;
+        fa.bias = w.out.bias;
+        fa.B = f.B;
+        fa.n = x.H * x.W;
+        fa.C = x.C;
+        linattn_fused_plan(fa.n, fa.B, fa.C, c.dtype, &fa.slice1, &fa.splits, &fa.tpw, &fa.slices);
+        Act y = f.new_act(x.C, x.H, x.W);
+        y.sG = 1;
+        y.sSlots = fa.slices;
+        y.stats = f.new_stats(1, fa.slices);
+        float* part = (float*)f.alloc((size_t)f.B * 4 * fa.splits * (32 * 32 + 64) * 4);
+        fa.y = y.p;
+        fa.y_stats = y.stats;
+        fa.ctx_part = part;
+        if (f.ok() && !f.dry) f.run(launch_linattn_fused(fa, f.s));
+        f.ar.release(part);
+        return lin_attn_tail(f, w, x, y);
+    }
     NormIn pn = norm_in(x, w.ng, w.nb, f.B, 0, nullptr, 0);
     Act qkv = do_conv(f, w.qkv, x, nullptr, &pn, nullptr, 0);
     Act la = f.new_act(hidden, x.H, x.W);
@@ -343,20 +387,7 @@ static Act lin_attn(Fwd& f, const AttnW& w, Act& x) {
     f.ar.release(part);
     Act y = do_conv(f, w.out, la, nullptr, nullptr, nullptr, 1);
     f.free_act(la);
-    Act out = f.new_act(x.C, x.H, x.W);
-    NormApplyArgs na;
-    memset(&na, 0, sizeof(na));
-    na.dtype = c.dtype;
-    na.in = y.p;
-    na.out = out.p;
-    na.res = x.p;
-    na.B = f.B;
-    na.HW = x.H * x.W;
-    na.C = x.C;
-    na.norm = norm_in(y, w.og, w.ob, f.B, 0, nullptr, 0);
-    if (f.ok() && !f.dry) f.run(launch_norm_apply(na, f.s));
-    f.free_act(y);
-    return out;
+    return lin_attn_tail(f, w, x, y);
 }
 
 // Residual(PreNorm(dim, Attention(dim))) (parts/mha.py:16-30)
@@ -566,6 +597,31 @@ static int load_resblock(const ParamMap& pm, DmnUnet* u, const std::string& pre,
     return DMN_OK;
 }
 
+// W: [rows][K] row-major. Output [rows/16][K/kch][64 lanes][per] where lane (q = lane>>4, r = lane&15) holds row
+// 16*tile + r and the k values kstep*kch + q*per + j; `acc_order` stores each 32-wide k block in the order an
+// accumulator-built operand presents it (bf16: pos -> 4*(pos>>3) + (pos&3) + 16*((pos>>2)&1); f32: identity).
+static int pack_fragments(int dtype, const float* W, int rows, int K, bool acc_order, void** dev) {
+    const int per = dtype == DMN_F32 ? 4 : 8, kch = dtype == DMN_F32 ? 16 : 32;
+    DMN_REQUIRE(rows % 16 == 0 && K % 32 == 0, DMN_ERR_WEIGHTS, "fragment packing: %dx%d", rows, K);
+    std::vector<float> p((size_t)rows * K);
+    size_t o = 0;
+    for (int rt = 0; rt < rows / 16; ++rt)
+        for (int ks = 0; ks < K / kch; ++ks)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < per; ++j) {
+                    int k = ks * kch + (lane >> 4) * per + j;
+                    if (acc_order && dtype != DMN_F32) {
+                        const int pos = k & 31;
+                        k = (k & ~31) + 4 * (pos >> 3) + (pos & 3) + 16 * ((pos >> 2) & 1);
+                    }
+                    p[o++] = W[(size_t)(rt * 16 + (lane & 15)) * K + k];
+                }
+    if (dtype == DMN_F32) return upload(p.data(), p.size() * 4, dev);
+    std::vector<uint16_t> h(p.size());
+    for (size_t i = 0; i < p.size(); ++i) h[i] = f32_to_bf16_rne(p[i]);
+    return upload(h.data(), h.size() * 2, dev);
+}
+
 static int load_attn(const ParamMap& pm, DmnUnet* u, const std::string& pre, int c, bool linear, AttnW& a) {
     const int dtype = u->cfg.dtype;
     const int hidden = u->cfg.heads * u->cfg.dim_head;
@@ -577,6 +633,16 @@ static int load_attn(const ParamMap& pm, DmnUnet* u, const std::string& pre, int
         if ((rc = load_conv(pm, dtype, pre + ".fn.fn.to_out.0", c, hidden, 1, 1, 0, true, false, a.out))) return rc;
         if ((rc = load_vec(pm, pre + ".fn.fn.to_out.1.weight", c, &a.og))) return rc;
         if ((rc = load_vec(pm, pre + ".fn.fn.to_out.1.bias", c, &a.ob))) return rc;
+        if (linattn_fused_supported(c, u->cfg.heads, u->cfg.dim_head)) {
+            const int64_t sq[] = {3 * hidden, c, 1, 1}, so[] = {c, hidden, 1, 1};
+            const DmnTensorDesc* wq = pm.get(pre + ".fn.fn.to_qkv.weight", 4, sq);
+            const DmnTensorDesc* wo = pm.get(pre + ".fn.fn.to_out.0.weight", 4, so);
+            if (!wq || !wo) return DMN_ERR_WEIGHTS;
+            if ((rc = pack_fragments(dtype, wq->data, hidden, c, false, &a.fq))) return rc;
+            if ((rc = pack_fragments(dtype, wq->data + (size_t)hidden * c, hidden, c, false, &a.fk))) return rc;
+            if ((rc = pack_fragments(dtype, wq->data + (size_t)2 * hidden * c, hidden, c, false, &a.fv))) return rc;
+            if ((rc = pack_fragments(dtype, wo->data, c, hidden, true, &a.fo))) return rc;
+        }
     } else {
         if ((rc = load_conv(pm, dtype, pre + ".fn.fn.to_out", c, hidden, 1, 1, 0, true, false, a.out))) return rc;
     }
@@ -598,6 +664,11 @@ static void free_attn(AttnW& a) {
     free_conv(a.out);
     float** v[] = {&a.ng, &a.nb, &a.og, &a.ob};
     for (auto p : v) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    void** f[] = {&a.fq, &a.fk, &a.fv, &a.fo};
+    for (auto p : f) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }

@@ -24,6 +24,8 @@ struct AttnW {
     float *ng = nullptr, *nb = nullptr;   // PreNorm GroupNorm(1)
     PackedConv qkv, out;
     float *og = nullptr, *ob = nullptr;   // LinearAttention's GroupNorm(1) after to_out
+    // fused linear attention: to_qkv rows (q | k | v) and to_out in MFMA fragment order, network dtype
+    void *fq = nullptr, *fk = nullptr, *fv = nullptr, *fo = nullptr;
 };
 
 struct LevelW {
