@@ -259,6 +259,11 @@ extern "C" int dmn_loop_last_ms(DmnUnet* u, float* ms) {
 }
 
 // ---- per-kernel test hook ----------------------------------------------------------------------------------
+extern "C" int dmn_test_set_conv_debug(long long* dev) {
+    conv_set_debug_buffer(dev);
+    return DMN_OK;
+}
+
 extern "C" int dmn_test_conv2d(int dtype, const void* in0, const void* in1, int C0, int C1, int B, int H, int W,
                                const float* w_host, const float* bias_host, int Cout, int kh, int kw, int stride, int pad,
                                int transposed, void* out, const void* res, const float* pro_gamma_host,

@@ -1,5 +1,6 @@
-// Implicit-GEMM convolution for gfx950 (CDNA4): NHWC activations, LDS-staged input halo tile and
-// weight slab, 16x16 MFMA (bf16 x32 or exact-f32 x4) with fp32 accumulation.
+// Implicit-GEMM convolution for gfx950 (CDNA4): NHWC activations, the input halo tile of ALL input channels
+// staged once in LDS, weights streamed from L2 straight into MFMA operand registers, 16x16 MFMA (bf16 x32 or
+// exact-f32 x4) with fp32 accumulation.
 //
 // One kernel template serves every convolution of the reference U-Net except the 3-channel 7x7 ingest
 // and the 3/6-channel tail:
@@ -14,10 +15,13 @@
 // the pixels the "B" operand, so each lane ends up with 4 CONSECUTIVE output channels of one pixel and the
 // NHWC store is an 8-byte (bf16) / 16-byte (f32) vector per lane.
 //
-// Pipeline per workgroup (256 threads, 4 waves): the K dimension is walked in channel chunks of 64 bytes
-// per pixel; while the MFMAs of chunk c run out of LDS, the global loads of chunk c+1 (input halo tile and
-// weight slab) are already in flight into registers and are written to LDS behind the next barrier. All tap
-// offsets, tile extents and per-thread staging slots are compile-time constants.
+// Per workgroup (256 threads, 4 waves): (1) the halo tile is loaded for a whole channel group (normally every
+// input channel), normalised + activated on the way (see Fusions) and written to LDS with a row pitch of
+// channel-bytes + 32, which keeps the 16-lane groups of ds_read_b128 on distinct banks; (2) ONE barrier; (3) a
+// barrier-free loop over (k-step, tap): the wave's weight fragments arrive from global memory in the exact
+// lane order of the MFMA A operand (the host packs them so) through a register ring that is refilled one
+// k-step ahead, the pixel fragments come from LDS. Channel groups only repeat (1)-(3) when the tile of all
+// channels would not fit in LDS (f32 parity mode, 512-channel decoder inputs).
 //
 // Fusions: GroupNorm + SiLU + time-embedding bias of the PREVIOUS Block applied while the input tile is
 // written to LDS (parts/convnext.py:35-41,81-85), bias, optional residual add, and partial GroupNorm
@@ -27,31 +31,32 @@
 
 namespace {
 
-constexpr int kRowBytes = 96;  // 64 data bytes + 32 pad: the 16-lane groups of a ds_read_b128 over consecutive rows
-                               // (slot = 6 * row + quarter mod 16) hit 16 distinct 16-byte slots of the 256-byte bank row
+constexpr int kRowPad = 32;    // bytes added to every LDS pixel row
+constexpr int kLdsSlack = 512; // fragment reads of skipped k-steps may run past the last row
 
 template <int KIND> struct KindTraits;
-template <> struct KindTraits<DMN_K3X3> { static constexpr int NTAPS = 9, EXT = 3, S = 1, KW = 3; };
-template <> struct KindTraits<DMN_K1X1> { static constexpr int NTAPS = 1, EXT = 1, S = 1, KW = 1; };
-template <> struct KindTraits<DMN_K4X4S2> { static constexpr int NTAPS = 16, EXT = 4, S = 2, KW = 4; };
-template <> struct KindTraits<DMN_KT2X2> { static constexpr int NTAPS = 4, EXT = 2, S = 1, KW = 2; };
+template <> struct KindTraits<DMN_K3X3> { static constexpr int NTAPS = 9, EXT = 3, S = 1, KW = 3, GK = 1; };
+template <> struct KindTraits<DMN_K1X1> { static constexpr int NTAPS = 1, EXT = 1, S = 1, KW = 1, GK = 4; };
+template <> struct KindTraits<DMN_K4X4S2> { static constexpr int NTAPS = 16, EXT = 4, S = 2, KW = 4, GK = 1; };
+template <> struct KindTraits<DMN_KT2X2> { static constexpr int NTAPS = 4, EXT = 2, S = 1, KW = 2, GK = 2; };
 
-template <typename T, int KIND, int TH, int TW, int BN, int WM, int WN>
+// PRO: 0 = input used as is, 1 = GroupNorm affine, 2 = GroupNorm affine + SiLU (+ time bias) while staging.
+template <typename T, int KIND, int TH, int TW, int BN, int WM, int WN, int PRO>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
     using KT = KindTraits<KIND>;
     static_assert(WM * WN == 4, "four waves per workgroup");
-    constexpr int NTAPS = KT::NTAPS, S = KT::S;
+    constexpr int NTAPS = KT::NTAPS, S = KT::S, GK = KT::GK, KW = KT::KW;
+    constexpr int E = NTAPS * GK;                   // ring entries: GK k-steps x all taps
     constexpr int BM = TH * TW;
     constexpr int MT = BM / (16 * WM);
     constexpr int NT = BN / (16 * WN);
     static_assert(MT >= 1 && NT >= 1, "tile too small for the wave grid");
+    constexpr int XB = MT <= 4 ? 2 : 1;             // pixel-fragment buffers (double buffering when cheap)
     constexpr int KCH = ElemTraits<T>::kChunk;
     constexpr int PER = ElemTraits<T>::kPer16B;
     constexpr int IH = (TH - 1) * S + KT::EXT, IW = (TW - 1) * S + KT::EXT;
-    constexpr int A_UNITS = IH * IW * 4;            // 16-byte staging units of the input tile per chunk
-    constexpr int W_UNITS = NTAPS * BN * 4;         // ... of the weight slab
-    constexpr int NUA = (A_UNITS + 255) / 256;
-    constexpr int NUW = (W_UNITS + 255) / 256;
+    constexpr int NPIX = IH * IW;
+    constexpr int SB = 6;                           // staging loads in flight per thread
     using V = decltype(Vec16<T>::v);
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -66,103 +71,78 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
     const ConvPhase P = a.phase[ph];
     const int iy0 = tile_y * TH * S - P.pad_y, ix0 = tile_x * TW * S - P.pad_x;
     const int Cin = a.C0 + a.C1;
+    const int CG = a.cg;                            // channels per staged group
+    const int KSG = CG / KCH, KS = Cin / KCH;       // k-steps per group / in total
+    const int lgu = a.lg_upp;                       // log2 of the 16-byte units per pixel row (<= 8)
+    const int rowB = CG * (int)sizeof(T) + kRowPad;
 
-    char* sA = smem;
-    char* sW = sA + IH * IW * kRowBytes;
-    float* sCoef = reinterpret_cast<float*>(sW + NTAPS * BN * kRowBytes);
-    const bool pro = a.pro.stats != nullptr;
-    float* sRed = sCoef + (pro ? 3 * Cin : 0);  // >= max(2*G, 2*WM*BN/4) floats
-
-    if (pro) norm_coefs_to_lds(a.pro, b, Cin, sCoef, sRed);
-
-    // ---- per-thread staging slots (fixed for the whole K loop) -------------------------------------
-    // input: unit u -> halo pixel (u >> 2), 16-byte part (u & 3) == (tid & 3)
-    int gpix[NUA];   // linear pixel index in the image batch, or -1 outside the image / beyond the tile
-#pragma unroll
-    for (int j = 0; j < NUA; ++j) {
-        const int u = tid + 256 * j;
-        const int pix = u >> 2;
-        const int ly = pix / IW, lx = pix - ly * IW;
-        const int gy = iy0 + ly, gx = ix0 + lx;
-        const bool ok = u < A_UNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        gpix[j] = ok ? (b * a.H + gy) * a.W + gx : -1;
+    const size_t wgid = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    // optional phase timestamps (tuning aid): [0] wall clock at start, [7] cycle counter at start, [1..4] cycle
+    // counter after set-up / staging / MFMA loop / epilogue, [5] wall clock at the end
+#define DMN_STAMP(i)                                                         \
+    if (a.dbg && tid == 0) {                                                 \
+        a.dbg[wgid * 8 + (i)] = (i) == 0 ? (long long)wall_clock64() : (long long)clock64(); \
+        if ((i) == 0) a.dbg[wgid * 8 + 7] = clock64();                       \
+        if ((i) == 4) a.dbg[wgid * 8 + 5] = wall_clock64();                  \
     }
-    const int part = tid & 3;
+    DMN_STAMP(0)
+    char* sX = smem;
+    float* sCoef = reinterpret_cast<float*>(smem + (size_t)NPIX * rowB + kLdsSlack);
+    float* sTmp = sCoef + (PRO ? 3 * Cin : 0);      // 2*G floats of normalisation scratch
+    float* sRed = sTmp + (PRO ? 2 * a.pro.G : 0);   // 2*WM*BN/4 floats of statistics scratch
 
-    V ra[NUA], rw[NUW];
-    const T* wphase = static_cast<const T*>(a.w) + P.w_off;
+    // ---- everything that only depends on the block index is requested first -------------------------------
+    // weight ring: fragment (ct, flat = ks*NTAPS + tap) is 64 lanes x 16 B, contiguous in flat
+    const T* wfrag[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int ct = n0 / 16 + wn * NT + nt;
+        wfrag[nt] = static_cast<const T*>(a.w) + P.w_off + ((size_t)ct * KS * NTAPS * 64 + lane) * PER;
+    }
+    V w[E][NT];
+    auto ring_fill = [&](int e, int ks0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            w[e][nt] = *reinterpret_cast<const V*>(wfrag[nt] + ((size_t)ks0 * NTAPS + e) * 64 * PER);
+    };
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+        if (GK == 1 || e / NTAPS < KSG) ring_fill(e, 0);
 
-    auto issue_loads = [&](int ch) {
-        const int c0 = ch * KCH;
-        const T* src;
-        int cs, Csrc;
-        if (c0 < a.C0) {
-            src = static_cast<const T*>(a.in0);
-            cs = c0;
-            Csrc = a.C0;
-        } else {
-            src = static_cast<const T*>(a.in1);
-            cs = c0 - a.C0;
-            Csrc = a.C1;
-        }
+    f32x4 bias[NT];
 #pragma unroll
-        for (int j = 0; j < NUA; ++j) {
-            // out-of-image slots read pixel 0 (always mapped) and are zeroed when written to LDS: no branch here
-            const int gp = gpix[j] < 0 ? 0 : gpix[j];
-            ra[j] = *reinterpret_cast<const V*>(src + (size_t)gp * Csrc + cs + part * PER);
-        }
-        // weight slab of this chunk: [tap][Cout][KCH]; the workgroup takes couts n0 .. n0+BN of every tap
-        const T* wsrc = wphase + (size_t)ch * NTAPS * a.Cout * KCH;
+    for (int nt = 0; nt < NT; ++nt) {
+        bias[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.bias) bias[nt] = *reinterpret_cast<const f32x4*>(a.bias + n0 + (wn * NT + nt) * 16 + lq * 4);
+    }
+
+    // tile staging: unit u = tid + 256*j is the 16-byte column `part` of halo pixel u >> lgu
+    const int part = tid & ((1 << lgu) - 1);
+    const int nunits = ((NPIX << lgu) + 255) >> 8;
+    V sr[SB];
+    unsigned smask = 0;                             // bit j: unit j of the batch lies inside the image
+    auto stage_issue = [&](int cg0, int j0) {
+        const int c = cg0 + part * PER;
+        const bool first = c < a.C0;
+        const T* src = static_cast<const T*>(first ? a.in0 : a.in1);
+        const int cs = first ? c : c - a.C0, Csrc = first ? a.C0 : a.C1;
+        smask = 0;
 #pragma unroll
-        for (int j = 0; j < NUW; ++j) {
-            const int u = tid + 256 * j;
-            if (NUW * 256 == W_UNITS || u < W_UNITS) {
-                const int row = u >> 2;
-                const int tap = row / BN, nl = row % BN;
-                rw[j] = *reinterpret_cast<const V*>(wsrc + ((size_t)tap * a.Cout + n0 + nl) * KCH + part * PER);
-            }
+        for (int j = 0; j < SB; ++j) {
+            const int pix = (tid + 256 * (j0 + j)) >> lgu;
+            const int ly = pix / IW, lx = pix - ly * IW;
+            const int gy = iy0 + ly, gx = ix0 + lx;
+            const bool in = pix < NPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            smask |= in ? 1u << j : 0u;
+            // slots outside the image read pixel 0 (always mapped) and are zeroed when written: no branch here
+            const unsigned off = in ? (unsigned)((b * a.H + gy) * a.W + gx) * (unsigned)Csrc + (unsigned)cs : (unsigned)cs;
+            sr[j] = *reinterpret_cast<const V*>(src + off);
         }
     };
+    stage_issue(0, 0);
 
-    auto write_lds = [&](int ch) {
-        float ca[PER], cb[PER], ct[PER];
-        if (pro) {
-            const int cbase = ch * KCH + part * PER;
-#pragma unroll
-            for (int e = 0; e < PER; ++e) {
-                ca[e] = sCoef[cbase + e];
-                cb[e] = sCoef[Cin + cbase + e];
-                ct[e] = sCoef[2 * Cin + cbase + e];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NUA; ++j) {
-            const int u = tid + 256 * j;
-            if (NUA * 256 == A_UNITS || u < A_UNITS) {
-                Vec16<T> v;
-                v.v = ra[j];
-                const bool inside = gpix[j] >= 0;
-                if (pro) {
-#pragma unroll
-                    for (int e = 0; e < PER; ++e) {
-                        float y = v.get(e) * ca[e] + cb[e];
-                        if (a.pro.silu) y = (sizeof(T) == 4) ? silu_precise(y) : silu_f(y);
-                        v.set(e, inside ? y + ct[e] : 0.f);
-                    }
-                } else if (!inside) {
-#pragma unroll
-                    for (int e = 0; e < PER; ++e) v.set(e, 0.f);
-                }
-                *reinterpret_cast<V*>(sA + (u >> 2) * kRowBytes + part * 16) = v.v;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NUW; ++j) {
-            const int u = tid + 256 * j;
-            if (NUW * 256 == W_UNITS || u < W_UNITS)
-                *reinterpret_cast<V*>(sW + (u >> 2) * kRowBytes + part * 16) = rw[j];
-        }
-    };
+    if (PRO) norm_coefs_to_lds(a.pro, b, Cin, sCoef, sTmp);
+    DMN_STAMP(1)
 
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -170,156 +150,194 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // per-lane LDS byte offsets of the fragments (before the compile-time tap offset)
-    int xoff[MT], woff[NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int p = (wm * MT + mt) * 16 + l15;
-        xoff[mt] = (((p / TW) * S) * IW + (p % TW) * S) * kRowBytes + lq * 16;
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) woff[nt] = ((wn * NT + nt) * 16 + l15) * kRowBytes + lq * 16;
-
-    const int nchunks = Cin / KCH;
-    issue_loads(0);
-    write_lds(0);
-    __syncthreads();
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const bool more = ch + 1 < nchunks;
-        if (more) issue_loads(ch + 1);
+    for (int cg0 = 0; cg0 < Cin; cg0 += CG) {
+        if (cg0) {
+            __syncthreads();                        // every wave is done with the previous group's tile
+            stage_issue(cg0, 0);
+        }
+        // ---- write the tile of channels [cg0, cg0 + CG) ----------------------------------------------------
         {
-            // software-pipelined over the taps: the fragments of tap t+1 are read while tap t multiplies
-            constexpr int KW = KT::KW;
-            Vec16<T> wf[2][NT], xf[2][MT];
-            auto load_frags = [&](int t, int buf) {
-                const int toff = ((t / KW) * IW + (t % KW)) * kRowBytes;   // an immediate after unrolling
+            const int c = cg0 + part * PER;
+            float ca[PER], cb[PER], ct[PER];
+            if (PRO) {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    wf[buf][nt].v = *reinterpret_cast<const V*>(sW + t * BN * kRowBytes + woff[nt]);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) xf[buf][mt].v = *reinterpret_cast<const V*>(sA + xoff[mt] + toff);
-            };
-            load_frags(0, 0);
-#pragma unroll
-            for (int t = 0; t < NTAPS; ++t) {
-                if (t + 1 < NTAPS) load_frags(t + 1, (t + 1) & 1);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) mma_step(wf[t & 1][nt], xf[t & 1][mt], acc[mt][nt]);
+                for (int e = 0; e < PER; ++e) {
+                    ca[e] = sCoef[c + e];
+                    cb[e] = sCoef[Cin + c + e];
+                    ct[e] = sCoef[2 * Cin + c + e];
+                }
             }
-        }
-        if (more) {
-            __syncthreads();
-            write_lds(ch + 1);
-            __syncthreads();
-        }
-    }
-
-    // ---- epilogue: bias, residual, statistics, NHWC store ---------------------------------------------
-    const bool want_stats = a.epi.stats != nullptr;
-    float ssum[NT], ssq[NT];
+            for (int j0 = 0; j0 < nunits; j0 += SB) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) ssum[nt] = ssq[nt] = 0.f;
-    T* outp = static_cast<T*>(a.out);
-    const T* resp = static_cast<const T*>(a.res);
-    float bias[NT][4];
+                for (int j = 0; j < SB; ++j) {
+                    const int pix = (tid + 256 * (j0 + j)) >> lgu;
+                    const bool in = (smask >> j) & 1u;
+                    Vec16<T> v;
+                    v.v = sr[j];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int n = n0 + (wn * NT + nt) * 16 + lq * 4;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bias[nt][r] = a.bias ? a.bias[n + r] : 0.f;
-    }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int p = (wm * MT + mt) * 16 + l15;
-        const int oyt = tile_y * TH + p / TW, oxt = tile_x * TW + p % TW;
-        const bool valid = oyt < a.Ho && oxt < a.Wo;
-        const int oy = oyt * a.out_sy + P.out_oy, ox = oxt * a.out_sx + P.out_ox;
-        const size_t obase = ((size_t)(b * a.out_H + oy) * a.out_W + ox) * a.Cout;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int n = n0 + (wn * NT + nt) * 16 + lq * 4;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[mt][nt][r] + bias[nt][r];
-            if (valid) {
-                if (want_stats) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        ssum[nt] += v[r];
-                        ssq[nt] += v[r] * v[r];
+                    for (int e = 0; e < PER; ++e) {
+                        float y = v.get(e);
+                        if (PRO) {
+                            y = y * ca[e] + cb[e];
+                            if (PRO == 2) y = ((sizeof(T) == 4) ? silu_precise(y) : silu_f(y)) + ct[e];
+                        }
+                        v.set(e, in ? y : 0.f);
                     }
+                    if (pix < NPIX) *reinterpret_cast<V*>(sX + pix * rowB + part * 16) = v.v;
                 }
-                if (resp) {
-                    if constexpr (sizeof(T) == 4) {
-                        const f32x4 rv = *reinterpret_cast<const f32x4*>(resp + obase + n);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += rv[r];
-                    } else {
-                        const bf16x4 rv = *reinterpret_cast<const bf16x4*>(resp + obase + n);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
-                    }
-                }
-                if constexpr (sizeof(T) == 4) {
-                    *reinterpret_cast<f32x4*>(outp + obase + n) = f32x4{v[0], v[1], v[2], v[3]};
-                } else {
-                    bf16x4 o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (__bf16)v[r];
-                    *reinterpret_cast<bf16x4*>(outp + obase + n) = o;
-                }
-            }
-        }
-    }
-    if (want_stats) {
-        // reduce over the 16 pixel lanes; lane (lane&15)==0 of each quarter holds the sums of a 4-channel quad
-        __syncthreads();   // sRed may alias the normalisation scratch read above by slower waves
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) {
-                ssum[nt] += __shfl_xor(ssum[nt], o, 64);
-                ssq[nt] += __shfl_xor(ssq[nt], o, 64);
-            }
-            if (l15 == 0) {
-                const int quad = (wn * NT + nt) * 4 + lq;  // local quad index in [0, BN/4)
-                sRed[(wm * (BN / 4) + quad) * 2] = ssum[nt];
-                sRed[(wm * (BN / 4) + quad) * 2 + 1] = ssq[nt];
+                if (j0 + SB < nunits) stage_issue(cg0, j0 + SB);
             }
         }
         __syncthreads();
-        const int G = a.epi.G;
-        const int cpg = a.Cout / G;
-        const int ngl = cpg >= BN ? 1 : BN / cpg;      // groups this workgroup touches
-        const int qpg = (cpg >= BN ? BN : cpg) / 4;    // quads per touched group inside this workgroup
-        const int sub = cpg > BN ? cpg / BN : 1;       // workgroups (along N) sharing one group
-        if (tid < ngl) {
-            float s = 0.f, ss = 0.f;
-            for (int w = 0; w < WM; ++w)
-                for (int q = 0; q < qpg; ++q) {
-                    s += sRed[(w * (BN / 4) + tid * qpg + q) * 2];
-                    ss += sRed[(w * (BN / 4) + tid * qpg + q) * 2 + 1];
+        DMN_STAMP(2)
+
+        // ---- MFMA loop over this group's k-steps, no barriers ------------------------------------------
+        // per-lane LDS byte offsets of the pixel fragments (before tap and k-step offsets)
+        int xoff[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int p = (wm * MT + mt) * 16 + l15;
+            xoff[mt] = (((p / TW) * S) * IW + (p % TW) * S) * rowB + lq * 16;
+        }
+        const int ksbase = cg0 / KCH;
+        for (int ksl = 0; ksl < KSG; ksl += GK) {
+            // k-step the ring is refilled for: the next iteration's, possibly in the next channel group
+            const bool wrap = ksl + GK >= KSG;
+            const int nksl = wrap ? 0 : ksl + GK;
+            const int nks0 = wrap ? ksbase + KSG : ksbase + ksl + GK;
+            const bool more = nks0 < KS;
+            Vec16<T> xf[XB][MT];
+            auto load_x = [&](int e, int buf) {
+                const int dk = e / NTAPS, t = e % NTAPS;
+                const int toff = ((t / KW) * IW + (t % KW)) * rowB;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    xf[buf][mt].v = *reinterpret_cast<const V*>(sX + xoff[mt] + toff + (ksl + dk) * 64);
+            };
+            if (XB == 2) load_x(0, 0);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int dk = e / NTAPS;
+                if (XB == 2) {
+                    if (e + 1 < E) load_x(e + 1, (e + 1) & 1);
+                } else {
+                    load_x(e, 0);
                 }
-            const int g = n0 / cpg + tid;
-            const int slot = blockIdx.x * sub + (cpg > BN ? (n0 % cpg) / BN : 0);
-            float* dst = a.epi.stats + ((size_t)(b * G + g) * a.epi.slots + slot) * 2;
-            dst[0] = s;
-            dst[1] = ss;
+                if (GK == 1 || ksl + dk < KSG) {
+                    Vec16<T> wv[NT];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) wv[nt].v = w[e][nt];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) mma_step(wv[nt], xf[XB == 2 ? (e & 1) : 0][mt], acc[mt][nt]);
+                }
+                if (more && (GK == 1 || nksl + dk < KSG)) ring_fill(e, nks0);
+                __builtin_amdgcn_sched_barrier(0);   // keep later taps' LDS reads from piling up in registers
+            }
         }
     }
+    {
+        DMN_STAMP(3)
+        // ---- epilogue: bias, residual, statistics, NHWC store ---------------------------------------------
+        const bool want_stats = a.epi.stats != nullptr;
+        float ssum[NT], ssq[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) ssum[nt] = ssq[nt] = 0.f;
+        T* outp = static_cast<T*>(a.out);
+        const T* resp = static_cast<const T*>(a.res);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int p = (wm * MT + mt) * 16 + l15;
+            const int oyt = tile_y * TH + p / TW, oxt = tile_x * TW + p % TW;
+            const bool valid = oyt < a.Ho && oxt < a.Wo;
+            const int oy = oyt * a.out_sy + P.out_oy, ox = oxt * a.out_sx + P.out_ox;
+            const size_t obase = ((size_t)(b * a.out_H + oy) * a.out_W + ox) * a.Cout;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = n0 + (wn * NT + nt) * 16 + lq * 4;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[mt][nt][r] + bias[nt][r];
+                if (valid) {
+                    if (want_stats) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            ssum[nt] += v[r];
+                            ssq[nt] += v[r] * v[r];
+                        }
+                    }
+                    if (resp) {
+                        if constexpr (sizeof(T) == 4) {
+                            const f32x4 rv = *reinterpret_cast<const f32x4*>(resp + obase + n);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += rv[r];
+                        } else {
+                            const bf16x4 rv = *reinterpret_cast<const bf16x4*>(resp + obase + n);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+                        }
+                    }
+                    if constexpr (sizeof(T) == 4) {
+                        *reinterpret_cast<f32x4*>(outp + obase + n) = f32x4{v[0], v[1], v[2], v[3]};
+                    } else {
+                        bf16x4 o;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = (__bf16)v[r];
+                        *reinterpret_cast<bf16x4*>(outp + obase + n) = o;
+                    }
+                }
+            }
+        }
+        if (want_stats) {
+            // reduce over the 16 pixel lanes; lane (lane&15)==0 of each quarter holds the sums of a 4-channel quad
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) {
+                    ssum[nt] += __shfl_xor(ssum[nt], o, 64);
+                    ssq[nt] += __shfl_xor(ssq[nt], o, 64);
+                }
+                if (l15 == 0) {
+                    const int quad = (wn * NT + nt) * 4 + lq;  // local quad index in [0, BN/4)
+                    sRed[(wm * (BN / 4) + quad) * 2] = ssum[nt];
+                    sRed[(wm * (BN / 4) + quad) * 2 + 1] = ssq[nt];
+                }
+            }
+            __syncthreads();
+            const int G = a.epi.G;
+            const int cpg = a.Cout / G;
+            const int ngl = cpg >= BN ? 1 : BN / cpg;      // groups this workgroup touches
+            const int qpg = (cpg >= BN ? BN : cpg) / 4;    // quads per touched group inside this workgroup
+            const int sub = cpg > BN ? cpg / BN : 1;       // workgroups (along N) sharing one group
+            if (tid < ngl) {
+                float s = 0.f, ss = 0.f;
+                for (int w_ = 0; w_ < WM; ++w_)
+                    for (int q = 0; q < qpg; ++q) {
+                        s += sRed[(w_ * (BN / 4) + tid * qpg + q) * 2];
+                        ss += sRed[(w_ * (BN / 4) + tid * qpg + q) * 2 + 1];
+                    }
+                const int g = n0 / cpg + tid;
+                const int slot = blockIdx.x * sub + (cpg > BN ? (n0 % cpg) / BN : 0);
+                float* dst = a.epi.stats + ((size_t)(b * G + g) * a.epi.slots + slot) * 2;
+                dst[0] = s;
+                dst[1] = ss;
+            }
+        }
+    }
+    DMN_STAMP(4)
+#undef DMN_STAMP
 }
 
 struct TileCfg {
     int th, tw, bn;
 };
 
-template <typename T, int KIND, int TH, int TW, int BN, int WM, int WN>
+template <typename T, int KIND, int TH, int TW, int BN, int WM, int WN, int PRO>
 int launch_cfg(const ConvArgs& a, size_t lds, hipStream_t s) {
     const int tiles = ((a.Ho + TH - 1) / TH) * ((a.Wo + TW - 1) / TW);
     dim3 grid(tiles, a.Cout / BN, a.B * a.nphase);
-    hipLaunchKernelGGL((conv_igemm_kernel<T, KIND, TH, TW, BN, WM, WN>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, KIND, TH, TW, BN, WM, WN, PRO>), grid, dim3(256), lds, s, a);
     DMN_HIP_CHECK(hipGetLastError());
     return DMN_OK;
 }
@@ -350,78 +368,116 @@ TileCfg pick_cfg(const ConvArgs& a) {
     return c;
 }
 
-size_t lds_bytes(const ConvArgs& a, const TileCfg& c) {
+size_t tile_pixels(const ConvArgs& a, const TileCfg& c) {
     const int ext = kind_ext(a.kind), st = kind_stride(a.kind);
     const int IH = (c.th - 1) * st + ext, IW = (c.tw - 1) * st + ext;
-    size_t n = (size_t)IH * IW * kRowBytes + (size_t)kind_taps(a.kind) * c.bn * kRowBytes;
+    return (size_t)IH * IW;
+}
+
+size_t lds_bytes(const ConvArgs& a, const TileCfg& c, int cg) {
+    const size_t esz = a.dtype == DMN_F32 ? 4 : 2;
+    size_t n = tile_pixels(a, c) * (cg * esz + kRowPad) + kLdsSlack;
     const int Cin = a.C0 + a.C1;
     if (a.pro.stats) n += (size_t)3 * Cin * 4;
     size_t red = 2 * 4 * (c.bn / 4);
-    if (a.pro.stats && (size_t)2 * a.pro.G > red) red = 2 * a.pro.G;
+    if (a.pro.stats) red += 2 * a.pro.G;
     n += red * 4 + 64;
     return n;
 }
 
-template <typename T, int KIND>
+// channels staged per group: all of them when the tile fits, else the largest power-of-two fraction that does
+int pick_cg(const ConvArgs& a, const TileCfg& c) {
+    const int kch = a.dtype == DMN_F32 ? 16 : 32;
+    int cg = a.C0 + a.C1;
+    while (lds_bytes(a, c, cg) > 150 * 1024 && cg % 2 == 0 && (cg / 2) % kch == 0) cg /= 2;
+    return cg;
+}
+
+// wave grids per tile: 16x16 pixels -> 2x2 waves (8 pixel tiles per wave), 8x8 pixels -> all four waves share the
+// pixels and split the output channels when there are 64 of them
+template <typename T, int KIND, int PRO>
 int dispatch_tile(const ConvArgs& a, const TileCfg& c, size_t lds, hipStream_t s) {
-    if (c.th == 16 && c.bn == 32) return launch_cfg<T, KIND, 16, 16, 32, 4, 1>(a, lds, s);
-    if (c.th == 16 && c.bn == 64) return launch_cfg<T, KIND, 16, 16, 64, 4, 1>(a, lds, s);
-    if (c.th == 8 && c.bn == 32) return launch_cfg<T, KIND, 8, 8, 32, 2, 2>(a, lds, s);
-    if (c.th == 8 && c.bn == 64) return launch_cfg<T, KIND, 8, 8, 64, 2, 2>(a, lds, s);
-    dmn_set_error("conv: unsupported tile %dx%d / %d", c.th, c.tw, c.bn);
+    if constexpr (KIND != DMN_K4X4S2) {
+        if (c.th == 16 && c.bn == 32) return launch_cfg<T, KIND, 16, 16, 32, 2, 2, PRO>(a, lds, s);
+        if (c.th == 16 && c.bn == 64) return launch_cfg<T, KIND, 16, 16, 64, 2, 2, PRO>(a, lds, s);
+    }
+    if (c.th == 8 && c.bn == 32) return launch_cfg<T, KIND, 8, 8, 32, 2, 2, PRO>(a, lds, s);
+    if (c.th == 8 && c.bn == 64) return launch_cfg<T, KIND, 8, 8, 64, 1, 4, PRO>(a, lds, s);
+    dmn_set_error("conv: unsupported tile %dx%d / %d for kind %d", c.th, c.tw, c.bn, KIND);
     return DMN_ERR_INVALID;
 }
 
 template <typename T>
 int dispatch(const ConvArgs& a, const TileCfg& c, size_t lds, hipStream_t s) {
+    const int pro = a.pro.stats ? (a.pro.silu ? 2 : 1) : 0;
     switch (a.kind) {
-        case DMN_K3X3: return dispatch_tile<T, DMN_K3X3>(a, c, lds, s);
-        case DMN_K1X1: return dispatch_tile<T, DMN_K1X1>(a, c, lds, s);
-        case DMN_KT2X2: return dispatch_tile<T, DMN_KT2X2>(a, c, lds, s);
+        case DMN_K3X3:
+            if (pro == 0) return dispatch_tile<T, DMN_K3X3, 0>(a, c, lds, s);
+            if (pro == 1) return dispatch_tile<T, DMN_K3X3, 1>(a, c, lds, s);
+            return dispatch_tile<T, DMN_K3X3, 2>(a, c, lds, s);
+        case DMN_K1X1:
+            if (pro == 0) return dispatch_tile<T, DMN_K1X1, 0>(a, c, lds, s);
+            if (pro == 1) return dispatch_tile<T, DMN_K1X1, 1>(a, c, lds, s);
+            return dispatch_tile<T, DMN_K1X1, 2>(a, c, lds, s);
+        case DMN_KT2X2:
+            if (pro == 0) return dispatch_tile<T, DMN_KT2X2, 0>(a, c, lds, s);
+            break;
         case DMN_K4X4S2:
-            if (c.th == 8 && c.bn == 32) return launch_cfg<T, DMN_K4X4S2, 8, 8, 32, 2, 2>(a, lds, s);
-            if (c.th == 8 && c.bn == 64) return launch_cfg<T, DMN_K4X4S2, 8, 8, 64, 2, 2>(a, lds, s);
-            dmn_set_error("conv: the stride-2 kernel only has 8x8 pixel tiles");
+            if (pro == 0) return dispatch_tile<T, DMN_K4X4S2, 0>(a, c, lds, s);
+            break;
+        default:
+            dmn_set_error("conv: unknown kind %d", a.kind);
             return DMN_ERR_INVALID;
     }
-    dmn_set_error("conv: unknown kind %d", a.kind);
+    dmn_set_error("conv: input normalisation is only built for the 3x3 and 1x1 kernels");
     return DMN_ERR_INVALID;
 }
 
-template <typename T, int KIND, int TH, int TW, int BN, int WM, int WN>
+template <typename T, int KIND, int TH, int TW, int BN, int WM, int WN, int PRO>
 int set_attr() {
     // opt in to more than 64 KiB of dynamic LDS (done once at handle creation, never inside a stream capture)
-    DMN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, KIND, TH, TW, BN, WM, WN>),
+    DMN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, KIND, TH, TW, BN, WM, WN, PRO>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return DMN_OK;
 }
 
-template <typename T, int KIND>
+template <typename T, int KIND, int PRO>
 int set_attr_kind() {
     int rc;
-    if (KIND != DMN_K4X4S2) {
-        if ((rc = set_attr<T, KIND == DMN_K4X4S2 ? DMN_K3X3 : KIND, 16, 16, 32, 4, 1>())) return rc;
-        if ((rc = set_attr<T, KIND == DMN_K4X4S2 ? DMN_K3X3 : KIND, 16, 16, 64, 4, 1>())) return rc;
+    if constexpr (KIND != DMN_K4X4S2) {
+        if ((rc = set_attr<T, KIND, 16, 16, 32, 2, 2, PRO>())) return rc;
+        if ((rc = set_attr<T, KIND, 16, 16, 64, 2, 2, PRO>())) return rc;
     }
-    if ((rc = set_attr<T, KIND, 8, 8, 32, 2, 2>())) return rc;
-    if ((rc = set_attr<T, KIND, 8, 8, 64, 2, 2>())) return rc;
+    if ((rc = set_attr<T, KIND, 8, 8, 32, 2, 2, PRO>())) return rc;
+    if ((rc = set_attr<T, KIND, 8, 8, 64, 1, 4, PRO>())) return rc;
+    return DMN_OK;
+}
+
+template <typename T>
+int set_attr_all() {
+    int rc;
+    if ((rc = set_attr_kind<T, DMN_K3X3, 0>())) return rc;
+    if ((rc = set_attr_kind<T, DMN_K3X3, 1>())) return rc;
+    if ((rc = set_attr_kind<T, DMN_K3X3, 2>())) return rc;
+    if ((rc = set_attr_kind<T, DMN_K1X1, 0>())) return rc;
+    if ((rc = set_attr_kind<T, DMN_K1X1, 1>())) return rc;
+    if ((rc = set_attr_kind<T, DMN_K1X1, 2>())) return rc;
+    if ((rc = set_attr_kind<T, DMN_K4X4S2, 0>())) return rc;
+    if ((rc = set_attr_kind<T, DMN_KT2X2, 0>())) return rc;
     return DMN_OK;
 }
 
 }  // namespace
 
+static long long* g_conv_dbg = nullptr;
+void conv_set_debug_buffer(long long* dev) { g_conv_dbg = dev; }
+
 int conv_init_attributes() {
     static bool done = false;
     if (done) return DMN_OK;
     int rc;
-    if ((rc = set_attr_kind<float, DMN_K3X3>())) return rc;
-    if ((rc = set_attr_kind<float, DMN_K1X1>())) return rc;
-    if ((rc = set_attr_kind<float, DMN_K4X4S2>())) return rc;
-    if ((rc = set_attr_kind<float, DMN_KT2X2>())) return rc;
-    if ((rc = set_attr_kind<__bf16, DMN_K3X3>())) return rc;
-    if ((rc = set_attr_kind<__bf16, DMN_K1X1>())) return rc;
-    if ((rc = set_attr_kind<__bf16, DMN_K4X4S2>())) return rc;
-    if ((rc = set_attr_kind<__bf16, DMN_KT2X2>())) return rc;
+    if ((rc = set_attr_all<float>())) return rc;
+    if ((rc = set_attr_all<__bf16>())) return rc;
     done = true;
     return DMN_OK;
 }
@@ -450,7 +506,17 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
         DMN_REQUIRE(cpg >= c.bn ? cpg % c.bn == 0 : c.bn % cpg == 0, DMN_ERR_INVALID, "conv: group size %d vs tile %d", cpg, c.bn);
         a.epi.slots = conv_epi_slots(a);
     }
-    const size_t lds = lds_bytes(a, c);
+    a.dbg = g_conv_dbg;
+    a.cg = pick_cg(a, c);
+    const int upp = a.cg / (a.dtype == DMN_F32 ? 4 : 8);
+    DMN_REQUIRE(upp <= 256 && (upp & (upp - 1)) == 0, DMN_ERR_INVALID,
+                "conv: %d channels per staged group (need a power of two <= %d)", a.cg, a.dtype == DMN_F32 ? 1024 : 2048);
+    a.lg_upp = 0;
+    while ((1 << a.lg_upp) < upp) ++a.lg_upp;
+    DMN_REQUIRE((long long)a.B * a.H * a.W * (a.C0 > a.C1 ? a.C0 : a.C1) < (1ll << 31), DMN_ERR_LIMIT,
+                "conv: input tensor beyond 2^31 elements");
+    if (a.pro.stats) DMN_REQUIRE(Cin <= 1024, DMN_ERR_LIMIT, "conv: input normalisation limited to 1024 channels");
+    const size_t lds = lds_bytes(a, c, a.cg);
     DMN_REQUIRE(lds <= 160 * 1024, DMN_ERR_INVALID, "conv: LDS request %zu too large", lds);
     if (a.dtype == DMN_F32) return dispatch<float>(a, c, lds, s);
     return dispatch<__bf16>(a, c, lds, s);

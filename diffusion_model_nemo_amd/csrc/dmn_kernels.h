@@ -47,18 +47,21 @@ struct ConvArgs {
     int kind;             // DMN_K3X3 / DMN_K1X1 / DMN_K4X4S2 / DMN_KT2X2 (fixes taps, extent and stride)
     int nphase;
     ConvPhase phase[4];
-    const void* w;        // packed [phase][Cin/kChunk][ntaps][Cout][kChunk]
+    const void* w;        // packed [phase][Cout/16][Cin/kChunk][ntaps][64 lanes][16 B]: MFMA A-operand fragments
     const float* bias;    // [Cout] or nullptr
     void* out;            // [B][out_H][out_W][Cout]
     int Cout;
     NormIn pro;           // normalise + activate the input while staging it (in0 only)
     const void* res;      // optional residual added in the epilogue, same shape as out
     NormOut epi;          // statistics of the output after bias (taken before the residual add)
+    int cg, lg_upp;       // channels staged per group and log2 of its 16-byte units per pixel; set by the launcher
+    long long* dbg;       // optional [workgroups][8] phase timestamps (tuning aid; nullptr in production)
     int cfg_tile, cfg_bn; // 0 = choose automatically; otherwise force the pixel tile (8 or 16) / channel tile (32 or 64)
 };
 int launch_conv(ConvArgs& a, hipStream_t s);
 int conv_epi_slots(const ConvArgs& a);   // slots per (image, group) launch_conv will write
 int conv_init_attributes();
+void conv_set_debug_buffer(long long* dev);   // timestamps of every later launch_conv go here (nullptr: off)
 
 // out = [SiLU](GN(in)) [+ tbias] [+ res], optional statistics of `out`.
 struct NormApplyArgs {

@@ -5,10 +5,22 @@
 #pragma once
 #include "dmn_kernels.h"
 
-// sCoef: 3*C floats (a | b | tb). sTmp: 2*G floats of scratch. Ends with a __syncthreads().
+// sCoef: 3*C floats (a | b | tb). sTmp: 2*G floats of scratch. C <= 4 * blockDim.x. Ends with a __syncthreads().
+// The per-channel parameters are requested before the statistics are reduced, so the two global round trips overlap.
 __device__ __forceinline__ void norm_coefs_to_lds(const NormIn& n, int b, int C, float* sCoef, float* sTmp) {
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
+    float pg[4], pb[4], pt[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + i * nthr;
+        pg[i] = pb[i] = pt[i] = 0.f;
+        if (c < C) {
+            pg[i] = n.gamma[c];
+            pb[i] = n.beta[c];
+            if (n.tbias) pt[i] = n.tbias[(size_t)b * n.tb_stride + c];
+        }
+    }
     // one wave per group: lanes stride over the slots, then a fixed-order butterfly (deterministic)
     const int wave = tid >> 6, lane = tid & 63, nwaves = nthr >> 6;
     for (int g = wave; g < n.G; g += nwaves) {
@@ -31,12 +43,16 @@ __device__ __forceinline__ void norm_coefs_to_lds(const NormIn& n, int b, int C,
     }
     __syncthreads();
     const int cpg = C / n.G;
-    for (int c = tid; c < C; c += nthr) {
-        const int g = c / cpg;
-        const float aa = sTmp[2 * g + 1] * n.gamma[c];
-        sCoef[c] = aa;
-        sCoef[C + c] = n.beta[c] - sTmp[2 * g] * aa;
-        sCoef[2 * C + c] = n.tbias ? n.tbias[(size_t)b * n.tb_stride + c] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + i * nthr;
+        if (c < C) {
+            const int g = c / cpg;
+            const float aa = sTmp[2 * g + 1] * pg[i];
+            sCoef[c] = aa;
+            sCoef[C + c] = pb[i] - sTmp[2 * g] * aa;
+            sCoef[2 * C + c] = pt[i];
+        }
     }
     __syncthreads();
 }

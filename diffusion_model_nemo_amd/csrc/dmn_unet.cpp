@@ -43,11 +43,14 @@ static int upload(const void* host, size_t bytes, void** dev) {
 static int upload_f32(const float* host, size_t n, float** dev) { return upload(host, n * 4, (void**)dev); }
 
 // w: [Cout][Cin][kh][kw] (or [Cin][Cout][4][4] when transposed). Packed layout per phase:
-// [Cin/kch][ntaps][Cout][kch], tap = ky*kw + kx (conv) or a*2+b (transposed phase).
+// [Cout/16][Cin/kch][ntaps][64 lanes][per], tap = ky*kw + kx (conv) or a*2+b (transposed phase); lane
+// (q = lane>>4, r = lane&15) holds output channel 16*tile + r and input channels kstep*kch + q*per + j, i.e.
+// one wave-wide 16-byte load yields the MFMA A operand of a (16 cout x kch cin) block.
 int pack_conv(PackedConv& pc, int dtype, const float* w, const float* bias, int Cout, int Cin, int kh, int kw, int stride,
               int pad, bool transposed) {
-    const int kch = dtype == DMN_F32 ? 16 : 32;
-    DMN_REQUIRE(Cin % kch == 0, DMN_ERR_WEIGHTS, "conv weight: Cin=%d not a multiple of %d", Cin, kch);
+    const int kch = dtype == DMN_F32 ? 16 : 32, per = dtype == DMN_F32 ? 4 : 8;
+    DMN_REQUIRE(Cin % kch == 0 && Cout % 16 == 0, DMN_ERR_WEIGHTS, "conv weight: Cin=%d not a multiple of %d or Cout=%d not of 16",
+                Cin, kch, Cout);
     pc.Cin = Cin;
     pc.Cout = Cout;
     pc.transposed = transposed;
@@ -67,12 +70,13 @@ int pack_conv(PackedConv& pc, int dtype, const float* w, const float* bias, int 
         pc.nphase = 1;
         pc.phase[0] = ConvPhase{pad, pad, 0, 0, 0};
         packed.resize((size_t)Cin * Cout * pc.ntaps);
-        for (int ch = 0; ch < Cin / kch; ++ch)
-            for (int t = 0; t < pc.ntaps; ++t)
-                for (int o = 0; o < Cout; ++o)
-                    for (int k = 0; k < kch; ++k)
-                        packed[(((size_t)ch * pc.ntaps + t) * Cout + o) * kch + k] =
-                            w[((size_t)o * Cin + ch * kch + k) * pc.ntaps + t];
+        size_t o = 0;
+        for (int ct = 0; ct < Cout / 16; ++ct)
+            for (int ch = 0; ch < Cin / kch; ++ch)
+                for (int t = 0; t < pc.ntaps; ++t)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < per; ++j)
+                            packed[o++] = w[((size_t)(ct * 16 + (lane & 15)) * Cin + ch * kch + (lane >> 4) * per + j) * pc.ntaps + t];
     } else {
         DMN_REQUIRE(kh == 4 && kw == 4 && stride == 2 && pad == 1, DMN_ERR_WEIGHTS, "transposed conv: only 4x4 s2 p1");
         pc.kind = DMN_KT2X2;
@@ -85,17 +89,18 @@ int pack_conv(PackedConv& pc, int dtype, const float* w, const float* bias, int 
         for (int ph = 0; ph < 4; ++ph) {
             const int py = ph / 2, px = ph % 2;
             pc.phase[ph] = ConvPhase{1 - py, 1 - px, py, px, (long long)(per_phase * ph)};
-            for (int ch = 0; ch < Cin / kch; ++ch)
-                for (int t = 0; t < 4; ++t) {
-                    // output row 2y+py receives input row y-1+dy through kernel row ky (oy = 2 iy - 1 + ky)
-                    const int dy = t / 2, dx = t % 2;
-                    const int ky = py == 0 ? 3 - 2 * dy : 2 - 2 * dy;
-                    const int kx = px == 0 ? 3 - 2 * dx : 2 - 2 * dx;
-                    for (int o = 0; o < Cout; ++o)
-                        for (int k = 0; k < kch; ++k)
-                            packed[per_phase * ph + (((size_t)ch * 4 + t) * Cout + o) * kch + k] =
-                                w[(((size_t)(ch * kch + k) * Cout + o) * 4 + ky) * 4 + kx];
-                }
+            size_t o = per_phase * ph;
+            for (int ct = 0; ct < Cout / 16; ++ct)
+                for (int ch = 0; ch < Cin / kch; ++ch)
+                    for (int t = 0; t < 4; ++t) {
+                        // output row 2y+py receives input row y-1+dy through kernel row ky (oy = 2 iy - 1 + ky)
+                        const int dy = t / 2, dx = t % 2;
+                        const int ky = py == 0 ? 3 - 2 * dy : 2 - 2 * dy;
+                        const int kx = px == 0 ? 3 - 2 * dx : 2 - 2 * dx;
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < per; ++j)
+                                packed[o++] = w[(((size_t)(ch * kch + (lane >> 4) * per + j) * Cout + ct * 16 + (lane & 15)) * 4 + ky) * 4 + kx];
+                    }
         }
     }
     int rc;
@@ -285,16 +290,16 @@ static Act do_conv(Fwd& f, const PackedConv& pc, const Act& in0, const Act* in1,
 // ResnetBlock (parts/convnext.py:78-86). statsG > 0: also produce GroupNorm(statsG) statistics of the output.
 static Act resblock(Fwd& f, const ResBlockW& w, Act& x, Act* x2, const float* tb, int tb_stride, int statsG) {
     const int G = f.u->cfg.groups;
-    Act h1 = do_conv(f, w.c1, x, x2, nullptr, nullptr, G);
-    NormIn n1 = norm_in(h1, w.g1, w.b1, f.B, 1, w.tb_off >= 0 ? tb + w.tb_off : nullptr, tb_stride);
-    Act h2 = do_conv(f, w.c2, h1, nullptr, &n1, nullptr, G);
-    f.free_act(h1);
     Act r;
     const Act* resp = &x;
     if (w.has_res) {
         r = do_conv(f, w.res, x, x2, nullptr, nullptr, 0);
         resp = &r;
     }
+    Act h1 = do_conv(f, w.c1, x, x2, nullptr, nullptr, G);
+    NormIn n1 = norm_in(h1, w.g1, w.b1, f.B, 1, w.tb_off >= 0 ? tb + w.tb_off : nullptr, tb_stride);
+    Act h2 = do_conv(f, w.c2, h1, nullptr, &n1, nullptr, G);
+    f.free_act(h1);
     Act out = f.new_act(h2.C, h2.H, h2.W);
     NormApplyArgs na;
     memset(&na, 0, sizeof(na));

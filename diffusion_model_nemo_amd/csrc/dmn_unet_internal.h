@@ -6,7 +6,7 @@
 #include "dmn_kernels.h"
 
 struct PackedConv {
-    void* w = nullptr;       // device, packed [phase][Cin/kch][ntaps][Cout][kch] in the network dtype
+    void* w = nullptr;       // device, packed [phase][Cout/16][Cin/kch][ntaps][64][16 B] in the network dtype
     float* bias = nullptr;   // device fp32 [Cout] or nullptr
     int Cin = 0, Cout = 0, kind = 0, stride = 1, pad = 0, ntaps = 0, ext = 0, nphase = 1;
     bool transposed = false;

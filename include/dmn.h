@@ -115,6 +115,9 @@ int dmn_fill_normal(float* x, int B, int per, uint64_t seed, uint32_t step, int6
 /* ---- single kernels, exported for unit parity tests -------------------------------------------------------------
  * Activations NHWC in the internal dtype (float32 or bfloat16 bit patterns). Weights HOST float32 in PyTorch layout;
  * these helpers pack + upload them per call (synchronous, test use only). */
+/* Tuning aid: every later convolution launch writes per-workgroup phase timestamps [workgroups][8] (int64) to
+ * `dev` (device memory sized by the caller for the largest grid); NULL switches it off. */
+int dmn_test_set_conv_debug(long long* dev);
 int dmn_test_conv2d(int dtype, const void* in0, const void* in1, int C0, int C1, int B, int H, int W, const float* w_host,
                     const float* bias_host, int Cout, int kh, int kw, int stride, int pad, int transposed, void* out,
                     const void* res, const float* pro_gamma_host, const float* pro_beta_host, const float* pro_tbias_dev,

@@ -1,0 +1,77 @@
+"""Tuning aid (GPU): per-workgroup phase timestamps of the convolution kernel on the network's main shapes.
+
+usage: python tools/conv_phases.py [B]
+Prints, per shape, the median cycles spent in: coefficient set-up, tile staging, MFMA loop, epilogue, and the
+wall-clock span of the launch (first workgroup start to last workgroup end).
+"""
+import ctypes as C
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from diffusion_model_nemo_amd import _native as N  # noqa: E402
+
+
+def run(name, B, H, W, cin, cout, k, stride, pad, transposed, pro, epi_G, dtype=1, tile=0, bn=0, c1=0):
+    lib = N.lib()
+    g = torch.Generator().manual_seed(1)
+    tdt = torch.bfloat16 if dtype == 1 else torch.float32
+    x0 = torch.randn((B, H, W, cin - c1), generator=g).to(tdt).cuda()
+    x1 = torch.randn((B, H, W, c1), generator=g).to(tdt).cuda() if c1 else None
+    wshape = (cin, cout, k, k) if transposed else (cout, cin, k, k)
+    w = (torch.randn(wshape, generator=g) * (1.0 / (k * k * cin)) ** 0.5).numpy().astype(np.float32)
+    b = torch.randn((cout,), generator=g).numpy().astype(np.float32)
+    Ho, Wo = (2 * H, 2 * W) if transposed else ((H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1)
+    out = torch.zeros((B, Ho, Wo, cout), device="cuda", dtype=tdt)
+    pg = pb = pst = None
+    pG = 0
+    if pro:
+        pG = 8
+        pg = np.ones(cin, np.float32)
+        pb = np.zeros(cin, np.float32)
+        st = torch.zeros((B, pG, 1, 2))
+        st[..., 0] = 0.0
+        st[..., 1] = float(H * W * cin // pG)
+        pst = st.cuda()
+    est = torch.zeros((B * max(epi_G, 1) * 4096 * 2,), device="cuda") if epi_G else None
+    dbg = torch.zeros((1 << 16, 8), dtype=torch.int64, device="cuda")
+    slots = C.c_int(0)
+    N.check(lib.dmn_test_set_conv_debug(dbg.data_ptr()))
+    for _ in range(2):
+        dbg.zero_()
+        torch.cuda.synchronize()
+        N.check(lib.dmn_test_conv2d(
+            dtype, x0.data_ptr(), None if x1 is None else x1.data_ptr(), cin - c1, c1, B, H, W, w.ctypes.data, b.ctypes.data,
+            cout, k, k, stride, pad, 1 if transposed else 0, out.data_ptr(), None, None if pg is None else pg.ctypes.data,
+            None if pb is None else pb.ctypes.data, None, None if pst is None else pst.data_ptr(), pG, 1, 1,
+            None if est is None else est.data_ptr(), epi_G, C.byref(slots), tile, bn, None))
+        torch.cuda.synchronize()
+    N.check(lib.dmn_test_set_conv_debug(None))
+    d = dbg.cpu().numpy()
+    d = d[d[:, 0] != 0]
+    nwg = len(d)
+    ph = np.stack([d[:, 1] - d[:, 7], d[:, 2] - d[:, 1], d[:, 3] - d[:, 2], d[:, 4] - d[:, 3], d[:, 4] - d[:, 7]], 1)
+    wall = (d[:, 5].max() - d[:, 0].min()) / 100.0   # 100 MHz counter -> us
+    life = (d[:, 5] - d[:, 0]) / 100.0
+    cyc_per_us = np.median((d[:, 4] - d[:, 7]) / np.maximum(life, 0.01))
+    med = np.median(ph, 0)
+    starts = np.sort((d[:, 0] - d[:, 0].min()) / 100.0)
+    print(f"{name:34s} wgs={nwg:5d} span={wall:6.1f}us  wg life med={np.median(life):5.1f}us  cycles: coef={med[0]:6.0f} "
+          f"stage={med[1]:6.0f} mfma={med[2]:6.0f} epi={med[3]:6.0f} total={med[4]:6.0f}  (~{cyc_per_us:.0f} cyc/us) "
+          f"last start={starts[-1]:.1f}us")
+
+
+if __name__ == "__main__":
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    run("L0 3x3 32->32 64x64 pro+stats", B, 64, 64, 32, 32, 3, 1, 1, False, True, 8)
+    run("L0 3x3 32->32 64x64 plain", B, 64, 64, 32, 32, 3, 1, 1, False, False, 0)
+    run("L0 3x3 64->32 64x64 concat", B, 64, 64, 64, 32, 3, 1, 1, False, False, 8, c1=32)
+    run("L1 3x3 64->64 32x32 pro+stats", B, 32, 32, 64, 64, 3, 1, 1, False, True, 8)
+    run("L2 3x3 128->128 16x16 pro+stats", B, 16, 16, 128, 128, 3, 1, 1, False, True, 8)
+    run("L3 3x3 256->256 8x8 pro+stats", B, 8, 8, 256, 256, 3, 1, 1, False, True, 8)
+    run("L3 3x3 512->256 8x8 concat", B, 8, 8, 512, 256, 3, 1, 1, False, False, 8, c1=256)
+    run("L0 4x4s2 32->32 64x64", B, 64, 64, 32, 32, 4, 2, 1, False, False, 0)
+    run("L1 convT 64->64 32x32", B, 32, 32, 64, 64, 4, 2, 1, True, False, 0)
+    run("L0 1x1 64->32 64x64", B, 64, 64, 64, 32, 1, 1, 0, False, False, 0, c1=32)
