@@ -6,8 +6,12 @@ batch 64 per GPU.
     python bench.py --gpus N --steps K --warmup W
 
 One "step" is one complete 1000-step sampling chain of one 64-image batch per GPU (x_T drawn on the device,
-1000 x {time MLP, U-Net, posterior update} replayed as a hipGraph, final images resident in HBM, gathered over
-RCCL when N > 1). Prints ONE JSON line on rank 0.
+1000 x {time MLP, U-Net, posterior update} replayed as a hipGraph, final images gathered over RCCL when N > 1
+and copied to the host). Prints ONE JSON line on rank 0.
+
+`roofline` describes the kernel that takes the largest share of a denoising step (the level-0 3x3 convolution
+with fused GroupNorm + SiLU prologue): its duration is measured here with HIP events, its HBM traffic comes
+from the rocprofv3 counter passes summarised in profiles/ (null when that file is absent).
 """
 import argparse
 import json
@@ -26,6 +30,7 @@ GFLOP_PER_IMG_EVAL = 2.6634
 ALG_BYTES_PER_IMG_EVAL = 17.3e6
 WEIGHT_BYTES = 16.2e6
 HBM_PEAK_GBS = 8000.0
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_dominant_kernel_traffic.json")
 
 
 def parse():
@@ -99,7 +104,8 @@ def main():
     def one_sample(k):
         x0 = gd.p_sample_loop(unet, shape, device=dev, seed=1000 + k, image_offset=rank * B, return_device_tensor=True,
                                use_graph=not a.no_graph)
-        return gather_images(x0) if world > 1 else x0
+        x0 = gather_images(x0) if world > 1 else x0
+        return x0.cpu() if rank == 0 else x0   # final images on the host, as the reference returns them
 
     def fence():
         if dist is not None:
@@ -123,6 +129,20 @@ def main():
     # device time of the last chain, from HIP events recorded on the loop's own stream
     loop_ms = N.loop_last_ms(unet.native_handle())
 
+    # the dominant kernel by itself, HIP events on the stream it is launched on
+    import ctypes as C
+    k_ms, k_bytes = C.c_float(), C.c_double()
+    ws = unet.workspace(B, S, S, dev, sampling=True)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    N.check(N.lib().dmn_bench_dominant_kernel(unet.native_handle(), B, S, S, 200, ws.data_ptr(), ws.numel(), stream,
+                                              C.byref(k_ms), C.byref(k_bytes)))
+    traffic = None
+    if os.path.exists(TRAFFIC_FILE):
+        with open(TRAFFIC_FILE) as fh:
+            tj = json.load(fh)
+        if tj.get("batch") == B and tj.get("image_size") == S and tj.get("dtype") == a.dtype:
+            traffic = tj["hbm_bytes_per_launch"]
+
     if rank == 0:
         imgs = world * B * a.steps
         sec_per_eval = (loop_ms / 1e3) / a.timesteps
@@ -135,11 +155,17 @@ def main():
             "config": {"workload": f"{S}x{S}x3 DDPM U-Net (dim 32, mults 1-2-4-8), {a.timesteps}-step p_sample_loop, "
                                    f"batch {B} per GPU", "global_batch": world * B, "parallelism": f"dp{world}",
                        "graph": not a.no_graph},
-            "roofline": {"bound": "hbm", "achieved": alg_bytes / sec_per_eval / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg_bytes / sec_per_eval / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "one denoising step (captured graph: time MLP + U-Net + posterior update)",
-                         "launch_ms": sec_per_eval * 1e3,
-                         "tflops": B * GFLOP_PER_IMG_EVAL / sec_per_eval / 1e3},
+            "roofline": {"bound": "hbm", "achieved": k_bytes.value / (k_ms.value / 1e3) / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": k_bytes.value / (k_ms.value / 1e3) / 1e9 / HBM_PEAK_GBS,
+                         "traffic": traffic,
+                         "kernel": "conv_igemm_kernel<bf16, 3x3, 16x16 px, 32 cout, GN+SiLU prologue> "
+                                   f"[{B},{S},{S},32] -> [{B},{S},{S},32]",
+                         "algorithmic_bytes": k_bytes.value, "launch_us": k_ms.value * 1e3},
+            # the whole captured step (time MLP + U-Net + posterior update) against the same roof
+            "step": {"device_ms": sec_per_eval * 1e3, "algorithmic_bytes": alg_bytes,
+                     "achieved_GBs": alg_bytes / sec_per_eval / 1e9,
+                     "frac_of_hbm_peak": alg_bytes / sec_per_eval / 1e9 / HBM_PEAK_GBS,
+                     "tflops": B * GFLOP_PER_IMG_EVAL / sec_per_eval / 1e3},
         }
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(S, a.timesteps, a.cpu_seconds)

@@ -46,6 +46,7 @@ SIGNATURES = {
                                 _sz, _vp, _i]),
     "dmn_sample_workspace_bytes": (_i, [_vp, _i, _i, _i, C.POINTER(_sz)]),
     "dmn_loop_last_ms": (_i, [_vp, C.POINTER(_f)]),
+    "dmn_bench_dominant_kernel": (_i, [_vp, _i, _i, _i, _i, _vp, _sz, _vp, C.POINTER(_f), C.POINTER(C.c_double)]),
     "dmn_fill_normal": (_i, [_vp, _i, _i, _u64, C.c_uint32, _i64, _f, _vp]),
     "dmn_test_set_conv_debug": (_i, [_vp]),
     "dmn_test_conv2d": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp,

@@ -529,6 +529,60 @@ int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float,
     return f.rc;
 }
 
+// Times the kernel that dominates a denoising step -- the level-0 3x3 convolution with the fused GroupNorm +
+// SiLU + time-bias prologue and the statistics epilogue (block2.proj of downs.0.0) -- by itself: `iters`
+// back-to-back launches bracketed by HIP events on `stream`.
+extern "C" int dmn_bench_dominant_kernel(DmnUnet* u, int B, int H, int W, int iters, void* ws, size_t ws_bytes, void* stream,
+                                         float* avg_ms, double* alg_bytes) {
+    DMN_REQUIRE(u && u->loaded && ws && avg_ms && iters > 0 && B > 0, DMN_ERR_INVALID, "dmn_bench_dominant_kernel: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const ResBlockW& w = u->downs[0].rb[0];
+    const int G = u->cfg.groups, C = w.c2.Cin;
+    Fwd f;
+    f.u = u;
+    f.s = s;
+    f.B = B;
+    f.dry = false;
+    f.ar.reset(ws, ws_bytes, false);
+    Act x = f.new_act(C, H, W);
+    x.sG = G;
+    x.sSlots = 1;
+    x.stats = f.new_stats(G, 1);
+    float* tb = (float*)f.alloc((size_t)u->tb_total * 4 + 256);
+    if (!f.ok()) return f.rc;
+    // zero activations with statistics {sum 0, sum of squares = count}: mean 0, variance 1
+    DMN_HIP_CHECK(hipMemsetAsync(x.p, 0, (size_t)B * H * W * C * f.esz(), s));
+    DMN_HIP_CHECK(hipMemsetAsync(tb, 0, (size_t)u->tb_total * 4, s));
+    std::vector<float> st((size_t)B * G * 2);
+    for (size_t i = 0; i < st.size(); i += 2) {
+        st[i] = 0.f;
+        st[i + 1] = (float)(C / G) * H * W;
+    }
+    DMN_HIP_CHECK(hipMemcpyAsync(x.stats, st.data(), st.size() * 4, hipMemcpyHostToDevice, s));
+    DMN_HIP_CHECK(hipStreamSynchronize(s));
+    NormIn n1 = norm_in(x, w.g1, w.b1, B, 1, w.tb_off >= 0 ? tb + w.tb_off : nullptr, 0);
+    hipEvent_t e0, e1;
+    DMN_HIP_CHECK(hipEventCreate(&e0));
+    DMN_HIP_CHECK(hipEventCreate(&e1));
+    int rc = DMN_OK;
+    for (int i = 0; i < 3 + iters && rc == DMN_OK; ++i) {
+        if (i == 3) (void)hipEventRecord(e0, s);
+        Act h = do_conv(f, w.c2, x, nullptr, &n1, nullptr, G);
+        rc = f.rc;
+        f.free_act(h);
+    }
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_ms = ms / iters;
+    if (alg_bytes)
+        *alg_bytes = (double)B * H * W * (w.c2.Cin + w.c2.Cout) * f.esz() + (double)w.c2.Cin * w.c2.Cout * 9 * f.esz();
+    return rc;
+}
+
 // ---- weights ---------------------------------------------------------------------------------------------
 struct ParamMap {
     std::map<std::string, const DmnTensorDesc*> m;

@@ -108,6 +108,13 @@ int dmn_sample_workspace_bytes(const DmnUnet* u, int B, int H, int W, size_t* by
 /* Device time (HIP events on the loop's stream) of the last dmn_*_sample_loop call on this handle; waits for it.
  * No counterpart in the reference: measurement hook used by bench.py. */
 int dmn_loop_last_ms(DmnUnet* u, float* ms);
+/* Average duration (HIP events on `stream`) of `iters` back-to-back launches of the kernel that dominates a
+ * denoising step: the level-0 3x3 convolution of a ResnetBlock with its fused GroupNorm + SiLU + time-bias prologue
+ * and statistics epilogue (parts/convnext.py:35-41,81-85), on a [B, dim, H, W] activation. alg_bytes receives the
+ * algorithmic traffic of one launch (input + output + weights). workspace: >= dmn_unet_workspace_bytes(B, H, W).
+ * No counterpart in the reference: measurement hook used by bench.py. */
+int dmn_bench_dominant_kernel(DmnUnet* u, int B, int H, int W, int iters, void* workspace, size_t workspace_bytes,
+                              void* stream, float* avg_ms, double* alg_bytes);
 
 /* N(0,1) * scale into x[B][per] with the library's generator (prior draws; tests). */
 int dmn_fill_normal(float* x, int B, int per, uint64_t seed, uint32_t step, int64_t img_offset, float scale, void* stream);
