@@ -49,6 +49,7 @@ SIGNATURES = {
     "dmn_bench_dominant_kernel": (_i, [_vp, _i, _i, _i, _i, _vp, _sz, _vp, C.POINTER(_f), C.POINTER(C.c_double)]),
     "dmn_fill_normal": (_i, [_vp, _i, _i, _u64, C.c_uint32, _i64, _f, _vp]),
     "dmn_test_set_conv_debug": (_i, [_vp]),
+    "dmn_test_linattn": (_i, [_i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i), _vp, _sz, _vp]),
     "dmn_test_conv2d": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp,
                              _vp, _vp, _i, _i, _i, _vp, _i, C.POINTER(_i), _i, _i, _vp]),
 }

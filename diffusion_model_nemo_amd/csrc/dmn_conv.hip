@@ -471,6 +471,7 @@ int set_attr_all() {
 
 static long long* g_conv_dbg = nullptr;
 void conv_set_debug_buffer(long long* dev) { g_conv_dbg = dev; }
+long long* kernel_debug_buffer() { return g_conv_dbg; }
 
 int conv_init_attributes() {
     static bool done = false;

@@ -61,7 +61,8 @@ struct ConvArgs {
 int launch_conv(ConvArgs& a, hipStream_t s);
 int conv_epi_slots(const ConvArgs& a);   // slots per (image, group) launch_conv will write
 int conv_init_attributes();
-void conv_set_debug_buffer(long long* dev);   // timestamps of every later launch_conv go here (nullptr: off)
+void conv_set_debug_buffer(long long* dev);
+long long* kernel_debug_buffer();   // timestamps of every later launch_conv go here (nullptr: off)
 
 // out = [SiLU](GN(in)) [+ tbias] [+ res], optional statistics of `out`.
 struct NormApplyArgs {
@@ -135,13 +136,15 @@ struct LinAttnFusedArgs {
     void* y;              // [B][n][C]  to_out(...) + bias, before its GroupNorm
     NormIn norm;          // PreNorm statistics / affine of x
     const void *wq, *wk, *wv;   // [128/16][C/kChunk][64 lanes][16 B] fragment order
-    const void* wo;       // [C/16][128/kChunk][64][16 B], k in accumulator-operand order
+    const void* wo;       // [C/16][128/kChunk][64][16 B] fragment order
     const float* bias;    // [C] to_out bias
     float* ctx_part;      // workspace [B][4][splits][32*32 + 64]
+    void* ctxT;           // workspace [B][4][32][32] in the activation dtype: merged, scaled context, transposed
     float* y_stats;       // [B][1][slices][2]
     int B, n, C;
     int slice1, splits;   // pass 1: workgroup slice in pixels (multiple of 32)
     int tpw, slices;      // pass 2: workgroup slice = 64*tpw pixels
+    long long* dbg;       // optional phase timestamps [2][workgroups][8] (tuning aid; nullptr in production)
 };
 bool linattn_fused_supported(int C, int heads, int dim_head);
 void linattn_fused_plan(int n, int B, int C, int dtype, int* slice1, int* splits, int* tpw, int* slices);

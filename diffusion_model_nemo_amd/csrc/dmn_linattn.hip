@@ -20,6 +20,16 @@
 
 namespace {
 
+// optional phase timestamps (tuning aid): slot 0 wall clock at start, 7 cycle counter at start, 1..4 cycle counter at
+// the end of each phase, 5 wall clock at the end
+#define LA_STAMP(base, i)                                                                     \
+    if ((base) && threadIdx.x == 0) {                                                         \
+        long long* d_ = (base) + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;            \
+        d_[(i)] = (i) == 0 ? (long long)wall_clock64() : (long long)clock64();                 \
+        if ((i) == 0) d_[7] = clock64();                                                      \
+        if ((i) == 4) d_[5] = wall_clock64();                                                 \
+    }
+
 constexpr int kHeads = 4, kD = 32, kHidden = 128;
 constexpr int kPartStride = kD * kD + 2 * kD;
 
@@ -55,89 +65,144 @@ __device__ __forceinline__ decltype(Vec16<T>::v) load_frag(const T* base, int id
     return *reinterpret_cast<const V*>(base + ((size_t)idx * 64 + lane) * ElemTraits<T>::kPer16B);
 }
 
-// stage rows [p0, p0 + rows) of x[b] (C channels) into LDS, normalised with GroupNorm(1); rows >= n are zero
-template <typename T>
-__device__ __forceinline__ void stage_x(const LinAttnFusedArgs& a, int b, int p0, int rows, char* sX, int row_bytes,
-                                        const float* sCoef) {
-    constexpr int PER = ElemTraits<T>::kPer16B;
+// Stages rows [p0, p0 + rows) of x[b] (C channels) into LDS, normalised with GroupNorm(1); rows >= n become zero.
+// The first batch of loads is issued by `begin` before the normalisation coefficients exist, so its latency
+// overlaps the statistics round trip; `finish` applies the coefficients and writes everything.
+template <typename T, int C>
+struct XStager {
+    static constexpr int PER = ElemTraits<T>::kPer16B;
+    static constexpr int PARTS = C / PER;          // 16-byte units per pixel row; divides 256
+    static constexpr int SB = 8;
     using V = decltype(Vec16<T>::v);
-    const int C = a.C;
-    const int parts = C / PER;                 // 256 % parts == 0: a thread keeps its channel offset
-    const int part = threadIdx.x % parts;
-    float ca[PER], cb[PER];
+    V r[SB];
+    const T* x;
+    int p0, rows, n, part;
+    __device__ __forceinline__ void issue(int j0) {
 #pragma unroll
-    for (int e = 0; e < PER; ++e) {
-        ca[e] = sCoef[part * PER + e];
-        cb[e] = sCoef[C + part * PER + e];
-    }
-    const T* x = static_cast<const T*>(a.x) + (size_t)b * a.n * C;
-    const int units = rows * parts;
-    for (int u = threadIdx.x; u < units; u += 256) {
-        const int r = u / parts;
-        const int p = p0 + r;
-        Vec16<T> v;
-        if (p < a.n) {
-            v.v = *reinterpret_cast<const V*>(x + (size_t)p * C + part * PER);
-#pragma unroll
-            for (int e = 0; e < PER; ++e) v.set(e, v.get(e) * ca[e] + cb[e]);
-        } else {
-#pragma unroll
-            for (int e = 0; e < PER; ++e) v.set(e, 0.f);
+        for (int j = 0; j < SB; ++j) {
+            const int u = threadIdx.x + 256 * (j0 + j);
+            const int p = p0 + u / PARTS;
+            const bool ok = u < rows * PARTS && p < n;
+            r[j] = *reinterpret_cast<const V*>(x + (size_t)(ok ? p : 0) * C + part * PER);
         }
-        *reinterpret_cast<V*>(sX + (size_t)r * row_bytes + part * 16) = v.v;
     }
-}
+    __device__ __forceinline__ void begin(const void* xb, int b, int n_, int p0_, int rows_) {
+        x = static_cast<const T*>(xb) + (size_t)b * n_ * C;
+        n = n_;
+        p0 = p0_;
+        rows = rows_;
+        part = threadIdx.x % PARTS;
+        issue(0);
+    }
+    __device__ __forceinline__ void finish(char* sX, int row_bytes, const float* sCoef) {
+        float ca[PER], cb[PER];
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            ca[e] = sCoef[part * PER + e];
+            cb[e] = sCoef[C + part * PER + e];
+        }
+        const int units = rows * PARTS;
+        for (int j0 = 0; j0 * 256 < units; j0 += SB) {
+#pragma unroll
+            for (int j = 0; j < SB; ++j) {
+                const int u = threadIdx.x + 256 * (j0 + j);
+                const int row = u / PARTS;
+                const bool ok = p0 + row < n;
+                Vec16<T> v;
+                v.v = r[j];
+#pragma unroll
+                for (int e = 0; e < PER; ++e) v.set(e, ok ? v.get(e) * ca[e] + cb[e] : 0.f);
+                if (u < units) *reinterpret_cast<V*>(sX + (size_t)row * row_bytes + part * 16) = v.v;
+            }
+            if ((j0 + SB) * 256 < units) issue(j0 + SB);
+        }
+    }
+};
 
 // ------------------------------------------------------------------------------------------------------------
-// pass 1: grid (splits, B); slice = nsub * 128 pixels
+// pass 1: grid (splits, B); slice = a.slice1 pixels (multiple of 32); wave h owns head h
 // ------------------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int C>
 __global__ void __launch_bounds__(256) la_fused_ctx_kernel(const LinAttnFusedArgs a) {
-    constexpr int PER = ElemTraits<T>::kPer16B;
     constexpr int KCH = ElemTraits<T>::kChunk;
     constexpr int SUB = Sub<T>::N;
+    constexpr int KS = C / KCH;
+    constexpr bool WREG = KS <= 4;                 // projection weights of the head stay in registers
+    constexpr int WR = WREG ? KS : 1;
     using V = decltype(Vec16<T>::v);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int C = a.C, KS = C / KCH;
     const int row_bytes = C * (int)sizeof(T) + 32;
     const int slice = a.slice1;
-    float* sCoef = reinterpret_cast<float*>(smem);            // 3*C + 2
-    char* sX = smem + ((3 * C + 8) * 4 + 15) / 16 * 16;
+    float* sCoef = reinterpret_cast<float*>(smem);            // 3*C + 8
+    char* sX = smem + ((3 * C + 8) * 4 + 15) / 16 * 16;       // later reused for the merge factors
     const int split = blockIdx.x, b = blockIdx.y;
     const int lane = threadIdx.x & 63, h = threadIdx.x >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
     const int p0 = split * slice;
 
-    norm_coefs_to_lds(a.norm, b, C, sCoef, sCoef + 3 * C);
-    stage_x<T>(a, b, p0, slice, sX, row_bytes, sCoef);
-    __syncthreads();
-
+    LA_STAMP(a.dbg, 0)
     const T* wk = static_cast<const T*>(a.wk);   // fragment order [ct 0..7][ks][lane][PER]; head h owns ct 2h, 2h+1
     const T* wv = static_cast<const T*>(a.wv);
-    const int npt = slice / 16;                  // pixel tiles in the slice
-
-    // ---- sweep 1: per-channel maximum of k over the slice ------------------------------------------------
-    float mx[2] = {-INFINITY, -INFINITY};
-    for (int pt = 0; pt < npt; ++pt) {
-        f32x4 kacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        const char* xrow = sX + (size_t)(pt * 16 + l15) * row_bytes + lq * 16;
-        for (int ks = 0; ks < KS; ++ks) {
-            Vec16<T> xf;
-            xf.v = *reinterpret_cast<const V*>(xrow + ks * 64);
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-                Vec16<T> wf;
-                wf.v = load_frag<T>(wk, (2 * h + ct) * KS + ks, lane);
-                mma_step(xf, wf, kacc[ct]);       // D[px][cout]
-            }
-        }
+    Vec16<T> wkr[2][WR], wvr[2][WR];
+    if constexpr (WREG) {
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool valid = p0 + pt * 16 + lq * 4 + r < a.n;
-                mx[ct] = valid ? fmaxf(mx[ct], kacc[ct][r]) : mx[ct];
+            for (int ks = 0; ks < KS; ++ks) {
+                wkr[ct][ks].v = load_frag<T>(wk, (2 * h + ct) * KS + ks, lane);
+                wvr[ct][ks].v = load_frag<T>(wv, (2 * h + ct) * KS + ks, lane);
             }
+    }
+    XStager<T, C> st;
+    st.begin(a.x, b, a.n, p0, slice);
+    norm_coefs_to_lds(a.norm, b, C, sCoef, sCoef + 3 * C);
+    LA_STAMP(a.dbg, 1)
+    st.finish(sX, row_bytes, sCoef);
+    __syncthreads();
+    LA_STAMP(a.dbg, 2)
+
+    const int npt = slice / 16;                  // pixel tiles in the slice (even)
+    auto kfrag = [&](int ct, int ks) {
+        if constexpr (WREG) return wkr[ct][ks];
+        Vec16<T> f;
+        f.v = load_frag<T>(wk, (2 * h + ct) * KS + ks, lane);
+        return f;
+    };
+    auto vfrag = [&](int ct, int ks) {
+        if constexpr (WREG) return wvr[ct][ks];
+        Vec16<T> f;
+        f.v = load_frag<T>(wv, (2 * h + ct) * KS + ks, lane);
+        return f;
+    };
+
+    // ---- sweep 1: per-channel maximum of k over the slice ------------------------------------------------
+    float mx[2] = {-INFINITY, -INFINITY};
+    for (int pp = 0; pp < npt; pp += 2) {
+        f32x4 kacc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) kacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const Vec16<T> k0 = kfrag(0, ks), k1 = kfrag(1, ks);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                Vec16<T> xf;
+                xf.v = *reinterpret_cast<const V*>(sX + (size_t)((pp + i) * 16 + l15) * row_bytes + lq * 16 + ks * 64);
+                mma_step(xf, k0, kacc[i][0]);     // D[px][cout]
+                mma_step(xf, k1, kacc[i][1]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool valid = p0 + (pp + i) * 16 + lq * 4 + r < a.n;
+                    mx[ct] = valid ? fmaxf(mx[ct], kacc[i][ct][r]) : mx[ct];
+                }
     }
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
@@ -145,6 +210,7 @@ __global__ void __launch_bounds__(256) la_fused_ctx_kernel(const LinAttnFusedArg
         mx[ct] = fmaxf(mx[ct], __shfl_xor(mx[ct], 32, 64));
     }
 
+    LA_STAMP(a.dbg, 3)
     // ---- sweep 2: P = exp(k - max), Z = sum P, ctx += P^T V ------------------------------------------------
     f32x4 ctx[2][2];
 #pragma unroll
@@ -158,22 +224,17 @@ __global__ void __launch_bounds__(256) la_fused_ctx_kernel(const LinAttnFusedArg
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) kacc[i][j] = vacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int ks = 0; ks < KS; ++ks) {
-            Vec16<T> wkf[2], wvf[2];
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-                wkf[ct].v = load_frag<T>(wk, (2 * h + ct) * KS + ks, lane);
-                wvf[ct].v = load_frag<T>(wv, (2 * h + ct) * KS + ks, lane);
-            }
+        for (int ks = 0; ks < KS; ++ks) {
+            const Vec16<T> k0 = kfrag(0, ks), k1 = kfrag(1, ks), v0 = vfrag(0, ks), v1 = vfrag(1, ks);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 Vec16<T> xf;
                 xf.v = *reinterpret_cast<const V*>(sX + (size_t)((pp + i) * 16 + l15) * row_bytes + lq * 16 + ks * 64);
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct) {
-                    mma_step(xf, wkf[ct], kacc[i][ct]);
-                    mma_step(xf, wvf[ct], vacc[i][ct]);
-                }
+                mma_step(xf, k0, kacc[i][0]);
+                mma_step(xf, k1, kacc[i][1]);
+                mma_step(xf, v0, vacc[i][0]);
+                mma_step(xf, v1, vacc[i][1]);
             }
         }
 #pragma unroll
@@ -183,7 +244,7 @@ __global__ void __launch_bounds__(256) la_fused_ctx_kernel(const LinAttnFusedArg
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const bool valid = p0 + (pp + i) * 16 + lq * 4 + r < a.n;
-                    const float e = valid ? expf(kacc[i][ct][r] - mx[ct]) : 0.f;
+                    const float e = valid ? ((sizeof(T) == 4) ? expf(kacc[i][ct][r] - mx[ct]) : __expf(kacc[i][ct][r] - mx[ct])) : 0.f;
                     kacc[i][ct][r] = e;
                     zs[ct] += e;
                 }
@@ -204,24 +265,85 @@ __global__ void __launch_bounds__(256) la_fused_ctx_kernel(const LinAttnFusedArg
         zs[ct] += __shfl_xor(zs[ct], 16, 64);
         zs[ct] += __shfl_xor(zs[ct], 32, 64);
     }
-    float* dst = a.ctx_part + ((size_t)(b * kHeads + h) * a.splits + split) * kPartStride;
+    if (a.splits == 1) {
+        // the slice is the whole image: normalise, scale and transpose here. Row d of an accumulator tile needs
+        // 1 / Z[d], which lives in the lanes whose column index is d.
+        T* out = static_cast<T*>(a.ctxT) + ((size_t)b * kHeads + h) * kD * kD;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+        for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-        for (int et = 0; et < 2; ++et)
+            for (int r = 0; r < 4; ++r) {
+                const int d = dt * 16 + lq * 4 + r;
+                const float inv = 0.17677669529663687f / __shfl(zs[dt], lq * 4 + r, 64);
+                const int pos = sizeof(T) == 4 ? d : ((d & 15) >> 2) * 8 + (d >> 4) * 4 + (d & 3);   // inverse of perm32
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dst[(dt * 16 + lq * 4 + r) * kD + et * 16 + l15] = ctx[dt][et][r];
-    if (lq == 0) {
+                for (int et = 0; et < 2; ++et) out[(et * 16 + l15) * kD + pos] = from_f32<T>(ctx[dt][et][r] * inv);
+            }
+    } else {
+        float* dst = a.ctx_part + (((size_t)b * kHeads + h) * a.splits + split) * kPartStride;
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-            dst[kD * kD + ct * 16 + l15] = mx[ct];
-            dst[kD * kD + kD + ct * 16 + l15] = zs[ct];
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int et = 0; et < 2; ++et)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[(dt * 16 + lq * 4 + r) * kD + et * 16 + l15] = ctx[dt][et][r];
+        if (lq == 0) {
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                dst[kD * kD + ct * 16 + l15] = mx[ct];
+                dst[kD * kD + kD + ct * 16 + l15] = zs[ct];
+            }
         }
+    }
+    LA_STAMP(a.dbg, 4)
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// merge of the split partials (only launched when splits > 1): grid (B), one workgroup per image
+//   factor_s[d] = exp(m_s[d] - M[d]) * 32^-1/2 / sum_s Z_s[d] exp(m_s[d] - M[d]);  ctx^T = sum_s factor_s * ctx_s
+// ------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) la_merge_kernel(const LinAttnFusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sFac = reinterpret_cast<float*>(smem);             // [128][splits]
+    const int b = blockIdx.x, S = a.splits;
+    const float* part_b = a.ctx_part + (size_t)b * kHeads * S * kPartStride;
+    for (int hd = threadIdx.x; hd < kHidden; hd += 256) {
+        const float* base = part_b + (size_t)(hd >> 5) * S * kPartStride + kD * kD + (hd & 31);
+        float M = -INFINITY;
+        for (int s = 0; s < S; ++s) M = fmaxf(M, base[(size_t)s * kPartStride]);
+        float Z = 0.f;
+        for (int s = 0; s < S; ++s) {
+            const float f = expf(base[(size_t)s * kPartStride] - M);
+            sFac[hd * S + s] = f;
+            Z += base[(size_t)s * kPartStride + kD] * f;
+        }
+        const float inv = 0.17677669529663687f / Z;
+        for (int s = 0; s < S; ++s) sFac[hd * S + s] *= inv;
+    }
+    __syncthreads();
+    // ctx^T in operand order: row e, position pos holds ctx[d = perm32(pos)][e]
+    T* out = static_cast<T*>(a.ctxT) + (size_t)b * kHeads * kD * kD;
+    for (int i = threadIdx.x; i < kHeads * kD * kD / 4; i += 256) {
+        const int hh = i >> 8, d = (i >> 3) & 31, e4 = (i & 7) * 4;
+        const float* base = part_b + (size_t)hh * S * kPartStride + d * kD + e4;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < S; ++s) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)s * kPartStride);
+            const float f = sFac[(hh * kD + d) * S + s];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = fmaf(v[r], f, acc[r]);
+        }
+        const int pos = sizeof(T) == 4 ? d : ((d & 15) >> 2) * 8 + (d >> 4) * 4 + (d & 3);   // inverse of perm32
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(hh * kD + e4 + r) * kD + pos] = from_f32<T>(acc[r]);
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// pass 2: grid (slices, B); slice = 64 * tpw pixels, wave w owns pixel tiles w*tpw .. w*tpw + tpw-1
+// pass 2: grid (slices, B); slice = 64 * tpw pixels, processed in groups of 64 (four pixel tiles).
+//   phase A  wave h = head h:  Q_h = Wq_h x  ->  softmax over d  ->  out_h = ctx_h^T q_h  ->  LDS (k-major rows)
+//   phase B  waves split the output-channel tiles:  y = Wout out + bias  ->  store + statistics
 // ------------------------------------------------------------------------------------------------------------
 template <typename T, int C>
 __global__ void __launch_bounds__(256) la_fused_out_kernel(const LinAttnFusedArgs a) {
@@ -229,155 +351,193 @@ __global__ void __launch_bounds__(256) la_fused_out_kernel(const LinAttnFusedArg
     constexpr int KCH = ElemTraits<T>::kChunk;
     constexpr int SUB = Sub<T>::N;
     constexpr int KS = C / KCH;
+    constexpr int KO = kHidden / KCH;              // k-steps of to_out
     constexpr int YT = C / 16;
+    constexpr int YPW = YT >= 4 ? YT / 4 : 1;      // output-channel tiles per wave
+    constexpr int PTW = YT >= 4 ? 4 : YT;          // pixel tiles per wave in phase B (waves share a tile row when YT < 4)
+    constexpr bool QREG = KS <= 2;                 // Wq of the head stays in registers across pixel groups
+    constexpr int QR = QREG ? KS : 1;
     constexpr int CTX_ROW = kD * (int)sizeof(T) + 32;
+    constexpr int O_ROW = kHidden * (int)sizeof(T) + 32;
     using V = decltype(Vec16<T>::v);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int row_bytes = C * (int)sizeof(T) + 32;
     const int slice = 64 * a.tpw;
     float* sCoef = reinterpret_cast<float*>(smem);                         // 3*C + 8
     char* sCtx = smem + ((3 * C + 8) * 4 + 15) / 16 * 16;                  // [4][32 rows e][CTX_ROW]
-    float* sFac = reinterpret_cast<float*>(sCtx + kHeads * kD * CTX_ROW);  // [128][splits]
-    char* sX = reinterpret_cast<char*>(sFac) + ((kHidden * a.splits * 4 + 15) / 16) * 16;
+    char* sO = sCtx + kHeads * kD * CTX_ROW;                               // [64 px][O_ROW]
+    char* sX = sO + 64 * O_ROW;
     float* sRed = reinterpret_cast<float*>(sX + (size_t)slice * row_bytes);   // 8 floats
     const int b = blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
     const int p0 = blockIdx.x * slice;
+    long long* dbg2 = a.dbg ? a.dbg + (size_t)65536 * 8 : nullptr;
 
+    LA_STAMP(dbg2, 0)
+    // ---- requests that depend on nothing: weights, merged context, first pixels ------------------------------
+    const T* wq = static_cast<const T*>(a.wq);     // [ct 0..7][ks][lane][PER]; head h owns ct 2h, 2h+1
+    const T* wo = static_cast<const T*>(a.wo);     // [yt][ko][lane][PER]
+    Vec16<T> wqr[2][QR];
+    if constexpr (QREG) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) wqr[ct][ks].v = load_frag<T>(wq, (2 * wave + ct) * KS + ks, lane);
+    }
+    const int yt0 = YT >= 4 ? wave : wave % YT;    // this wave's tiles: yt0 + 4*i
+    const int ptb = YT >= 4 ? 0 : (wave / YT) * PTW;
+    Vec16<T> wor[YPW][KO];
+#pragma unroll
+    for (int i = 0; i < YPW; ++i)
+#pragma unroll
+        for (int ko = 0; ko < KO; ++ko) wor[i][ko].v = load_frag<T>(wo, (yt0 + 4 * i) * KO + ko, lane);
+    f32x4 bias[YPW];
+#pragma unroll
+    for (int i = 0; i < YPW; ++i) bias[i] = *reinterpret_cast<const f32x4*>(a.bias + (yt0 + 4 * i) * 16 + lq * 4);
+    constexpr int CU = kHeads * kD * kD / PER / 256;   // 16-byte units of ctx^T per thread
+    V cr[CU];
+    {
+        const T* cT = static_cast<const T*>(a.ctxT) + (size_t)b * kHeads * kD * kD;
+#pragma unroll
+        for (int j = 0; j < CU; ++j) cr[j] = *reinterpret_cast<const V*>(cT + (size_t)(tid + 256 * j) * PER);
+    }
+    XStager<T, C> st;
+    st.begin(a.x, b, a.n, p0, slice);
     norm_coefs_to_lds(a.norm, b, C, sCoef, sCoef + 3 * C);
-    stage_x<T>(a, b, p0, slice, sX, row_bytes, sCoef);
-
-    // ---- merge the split partials: factor_s[d] = exp(m_s[d] - M[d]) * 32^-1/2 / sum_s Z_s[d] exp(m_s[d] - M[d])
-    const float* part = a.ctx_part + (size_t)b * kHeads * a.splits * kPartStride;
-    for (int hd = tid; hd < kHidden; hd += 256) {
-        const int h = hd >> 5, d = hd & 31;
-        const float* base = part + (size_t)h * a.splits * kPartStride + kD * kD + d;
-        float M = -INFINITY;
-        for (int s = 0; s < a.splits; ++s) M = fmaxf(M, base[(size_t)s * kPartStride]);
-        float Z = 0.f;
-        for (int s = 0; s < a.splits; ++s) {
-            const float f = expf(base[(size_t)s * kPartStride] - M);
-            sFac[hd * a.splits + s] = f;
-            Z += base[(size_t)s * kPartStride + kD] * f;
-        }
-        const float inv = 0.17677669529663687f / Z;
-        for (int s = 0; s < a.splits; ++s) sFac[hd * a.splits + s] *= inv;
+    LA_STAMP(dbg2, 1)
+    st.finish(sX, row_bytes, sCoef);
+#pragma unroll
+    for (int j = 0; j < CU; ++j) {
+        const int u = tid + 256 * j;               // unit -> row (h*32 + e), 16-byte column
+        constexpr int UPR = kD / PER;
+        *reinterpret_cast<V*>(sCtx + (size_t)(u / UPR) * CTX_ROW + (u % UPR) * 16) = cr[j];
     }
     __syncthreads();
-    // ctx^T in operand order: row e, position pos holds ctx[d = perm32(pos)][e]
-    for (int i = tid; i < kHeads * kD * kD; i += 256) {
-        const int h = i >> 10, d = (i >> 5) & 31, e = i & 31;   // consecutive threads -> consecutive e (coalesced)
-        const float* base = part + (size_t)h * a.splits * kPartStride + d * kD + e;
-        float acc = 0.f;
-        for (int s = 0; s < a.splits; ++s) acc = fmaf(base[(size_t)s * kPartStride], sFac[(h * kD + d) * a.splits + s], acc);
-        int pos = 0;   // inverse of perm32
-        if (sizeof(T) == 4) pos = d;
-        else pos = ((d & 15) >> 2) * 8 + (d >> 4) * 4 + (d & 3);
-        *reinterpret_cast<T*>(sCtx + (size_t)(h * kD + e) * CTX_ROW + pos * sizeof(T)) = from_f32<T>(acc);
-    }
-    __syncthreads();
+    LA_STAMP(dbg2, 2)
 
-    const T* wq = static_cast<const T*>(a.wq);     // [ct 0..7][ks][lane][PER]
-    const T* wo = static_cast<const T*>(a.wo);     // [yt][h][sub][lane][PER], k in operand order
+    Vec16<T> cf[2][SUB];                           // A fragments of ctx_h^T
+#pragma unroll
+    for (int et = 0; et < 2; ++et)
+#pragma unroll
+        for (int sub = 0; sub < SUB; ++sub)
+            cf[et][sub].v = *reinterpret_cast<const V*>(sCtx + (size_t)(wave * kD + et * 16 + l15) * CTX_ROW + sub * 64 + lq * 16);
+
     float ssum = 0.f, ssq = 0.f;
     T* yout = static_cast<T*>(a.y) + (size_t)b * a.n * C;
-    for (int t = 0; t < a.tpw; ++t) {
-        const int ptile = wave * a.tpw + t;
-        const int px = p0 + ptile * 16 + l15;       // this lane's pixel (column)
-        // Q[cout][px] = Wq x
-        f32x4 q[8];
+    for (int g = 0; g < a.tpw; ++g) {
+        // ---- phase A: head `wave` on the four pixel tiles of the group ------------------------------------------
+        f32x4 q[4][2];
 #pragma unroll
-        for (int ct = 0; ct < 8; ++ct) q[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const char* xrow = sX + (size_t)(ptile * 16 + l15) * row_bytes + lq * 16;
+        for (int pt = 0; pt < 4; ++pt) q[pt][0] = q[pt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            Vec16<T> xf;
-            xf.v = *reinterpret_cast<const V*>(xrow + ks * 64);
+            Vec16<T> w0, w1;
+            if constexpr (QREG) {
+                w0 = wqr[0][ks];
+                w1 = wqr[1][ks];
+            } else {
+                w0.v = load_frag<T>(wq, (2 * wave) * KS + ks, lane);
+                w1.v = load_frag<T>(wq, (2 * wave + 1) * KS + ks, lane);
+            }
 #pragma unroll
-            for (int ct = 0; ct < 8; ++ct) {
-                Vec16<T> wf;
-                wf.v = load_frag<T>(wq, ct * KS + ks, lane);
-                mma_step(wf, xf, q[ct]);
+            for (int pt = 0; pt < 4; ++pt) {
+                Vec16<T> xf;
+                xf.v = *reinterpret_cast<const V*>(sX + (size_t)(g * 64 + pt * 16 + l15) * row_bytes + lq * 16 + ks * 64);
+                mma_step(w0, xf, q[pt][0]);       // D[cout][px]
+                mma_step(w1, xf, q[pt][1]);
             }
         }
-        // softmax over the 32 channels of each head (rows of tiles 2h, 2h+1; spread over the 4 lane quarters)
-        f32x4 o[8];
 #pragma unroll
-        for (int h = 0; h < kHeads; ++h) {
-            float m = q[2 * h][0];
+        for (int pt = 0; pt < 4; ++pt) {
+            // softmax over the 32 channels of the head: rows of the two tiles, spread over the 4 lane quarters
+            float m = q[pt][0][0];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) m = fmaxf(m, fmaxf(q[2 * h][r], q[2 * h + 1][r]));
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, fmaxf(q[pt][0][r], q[pt][1][r]));
             m = fmaxf(m, __shfl_xor(m, 16, 64));
             m = fmaxf(m, __shfl_xor(m, 32, 64));
             float s = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                q[2 * h][r] = expf(q[2 * h][r] - m);
-                q[2 * h + 1][r] = expf(q[2 * h + 1][r] - m);
-                s += q[2 * h][r] + q[2 * h + 1][r];
+                q[pt][0][r] = (sizeof(T) == 4) ? expf(q[pt][0][r] - m) : __expf(q[pt][0][r] - m);
+                q[pt][1][r] = (sizeof(T) == 4) ? expf(q[pt][1][r] - m) : __expf(q[pt][1][r] - m);
+                s += q[pt][0][r] + q[pt][1][r];
             }
             s += __shfl_xor(s, 16, 64);
             s += __shfl_xor(s, 32, 64);
             const float inv = 1.0f / s;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                q[2 * h][r] *= inv;
-                q[2 * h + 1][r] *= inv;
+                q[pt][0][r] *= inv;
+                q[pt][1][r] *= inv;
             }
             // out[e][px] = sum_d ctx[d][e] q[d][px]
-            o[2 * h] = o[2 * h + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
             for (int sub = 0; sub < SUB; ++sub) {
-                const Vec16<T> qb = acc_operand(q[2 * h], q[2 * h + 1], sub, (T*)nullptr);
-#pragma unroll
-                for (int et = 0; et < 2; ++et) {
-                    Vec16<T> cf;
-                    cf.v = *reinterpret_cast<const V*>(sCtx + (size_t)(h * kD + et * 16 + l15) * CTX_ROW + sub * 64 + lq * 16);
-                    mma_step(cf, qb, o[2 * h + et]);
-                }
+                const Vec16<T> qb = acc_operand(q[pt][0], q[pt][1], sub, (T*)nullptr);
+                mma_step(cf[0][sub], qb, o[0]);
+                mma_step(cf[1][sub], qb, o[1]);
             }
-        }
-        // y[c][px] = Wout out + bias
-        f32x4 y[YT];
+            // lane: pixel l15, channels e = et*16 + 4*lq .. +3 -> k-major row of the pixel
 #pragma unroll
-        for (int yt = 0; yt < YT; ++yt) y[yt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int h = 0; h < kHeads; ++h)
-#pragma unroll
-            for (int sub = 0; sub < SUB; ++sub) {
-                const Vec16<T> ob = acc_operand(o[2 * h], o[2 * h + 1], sub, (T*)nullptr);
-#pragma unroll
-                for (int yt = 0; yt < YT; ++yt) {
-                    Vec16<T> wf;
-                    wf.v = load_frag<T>(wo, (yt * kHeads + h) * SUB + sub, lane);
-                    mma_step(wf, ob, y[yt]);
-                }
-            }
-        const bool valid = px < a.n;
-#pragma unroll
-        for (int yt = 0; yt < YT; ++yt) {
-            const int c = yt * 16 + lq * 4;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = y[yt][r] + a.bias[c + r];
-            if (valid) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    ssum += v[r];
-                    ssq += v[r] * v[r];
-                }
+            for (int et = 0; et < 2; ++et) {
+                char* dstp = sO + (size_t)(pt * 16 + l15) * O_ROW + (wave * kD + et * 16 + lq * 4) * sizeof(T);
                 if constexpr (sizeof(T) == 4) {
-                    *reinterpret_cast<f32x4*>(yout + (size_t)px * C + c) = f32x4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(dstp) = o[et];
                 } else {
                     bf16x4 ov;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) ov[r] = (__bf16)v[r];
-                    *reinterpret_cast<bf16x4*>(yout + (size_t)px * C + c) = ov;
+                    for (int r = 0; r < 4; ++r) ov[r] = (__bf16)o[et][r];
+                    *reinterpret_cast<bf16x4*>(dstp) = ov;
                 }
             }
         }
+        __syncthreads();
+        // ---- phase B: y[c][px] = Wout out + bias for this wave's channel tiles ------------------------------------
+        f32x4 y[YPW][PTW];
+#pragma unroll
+        for (int i = 0; i < YPW; ++i)
+#pragma unroll
+            for (int pt = 0; pt < PTW; ++pt) y[i][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ko = 0; ko < KO; ++ko) {
+#pragma unroll
+            for (int pt = 0; pt < PTW; ++pt) {
+                Vec16<T> of;
+                of.v = *reinterpret_cast<const V*>(sO + (size_t)((ptb + pt) * 16 + l15) * O_ROW + ko * 64 + lq * 16);
+#pragma unroll
+                for (int i = 0; i < YPW; ++i) mma_step(wor[i][ko], of, y[i][pt]);
+            }
+        }
+#pragma unroll
+        for (int pt = 0; pt < PTW; ++pt) {
+            const int px = p0 + g * 64 + (ptb + pt) * 16 + l15;
+            if (px < a.n) {
+#pragma unroll
+                for (int i = 0; i < YPW; ++i) {
+                    const int c = (yt0 + 4 * i) * 16 + lq * 4;
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = y[i][pt][r] + bias[i][r];
+                        ssum += v[r];
+                        ssq += v[r] * v[r];
+                    }
+                    if constexpr (sizeof(T) == 4) {
+                        *reinterpret_cast<f32x4*>(yout + (size_t)px * C + c) = f32x4{v[0], v[1], v[2], v[3]};
+                    } else {
+                        bf16x4 ov;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ov[r] = (__bf16)v[r];
+                        *reinterpret_cast<bf16x4*>(yout + (size_t)px * C + c) = ov;
+                    }
+                }
+            }
+        }
+        if (g + 1 < a.tpw) __syncthreads();       // sO is rewritten by the next group
     }
+    LA_STAMP(dbg2, 3)
     // GroupNorm(1) partial statistics of y: one slot per workgroup
     ssum = wave_sum(ssum);
     ssq = wave_sum(ssq);
@@ -396,44 +556,47 @@ __global__ void __launch_bounds__(256) la_fused_out_kernel(const LinAttnFusedArg
         dst[0] = s;
         dst[1] = ss;
     }
+    LA_STAMP(dbg2, 4)
 }
 
 template <typename T, int C>
-int launch_out(const LinAttnFusedArgs& a, hipStream_t s) {
-    const int slice = 64 * a.tpw;
+int launch_pair(const LinAttnFusedArgs& a, hipStream_t s) {
     const size_t row = (size_t)C * sizeof(T) + 32;
-    const size_t lds = ((3 * C + 8) * 4 + 15) / 16 * 16 + (size_t)kHeads * kD * (kD * sizeof(T) + 32) +
-                       ((size_t)kHidden * a.splits * 4 + 15) / 16 * 16 + slice * row + 64;
-    DMN_REQUIRE(lds <= 160 * 1024, DMN_ERR_LIMIT, "linear attention: LDS request %zu too large", lds);
+    const size_t coef = ((3 * C + 8) * 4 + 15) / 16 * 16;
+    const size_t lds1 = coef + (size_t)a.slice1 * row + 64;
+    const size_t ldsm = (size_t)kHidden * a.splits * 4;
+    DMN_REQUIRE(ldsm <= 64 * 1024, DMN_ERR_LIMIT, "linear attention: %d splits", a.splits);
+    const int slice = 64 * a.tpw;
+    const size_t lds2 = coef + (size_t)kHeads * kD * (kD * sizeof(T) + 32) + 64 * ((size_t)kHidden * sizeof(T) + 32) +
+                        slice * row + 64;
+    DMN_REQUIRE(lds1 <= 160 * 1024 && lds2 <= 160 * 1024, DMN_ERR_LIMIT, "linear attention: LDS request %zu / %zu too large",
+                lds1, lds2);
     static bool attr = false;
     if (!attr) {
+        DMN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&la_fused_ctx_kernel<T, C>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         DMN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&la_fused_out_kernel<T, C>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    hipLaunchKernelGGL((la_fused_out_kernel<T, C>), dim3((a.n + slice - 1) / slice, a.B), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((la_fused_ctx_kernel<T, C>), dim3(a.splits, a.B), dim3(256), lds1, s, a);
+    DMN_HIP_CHECK(hipGetLastError());
+    if (a.splits > 1) {
+        hipLaunchKernelGGL(la_merge_kernel<T>, dim3(a.B), dim3(256), ldsm, s, a);
+        DMN_HIP_CHECK(hipGetLastError());
+    }
+    hipLaunchKernelGGL((la_fused_out_kernel<T, C>), dim3(a.slices, a.B), dim3(256), lds2, s, a);
     DMN_HIP_CHECK(hipGetLastError());
     return DMN_OK;
 }
 
 template <typename T>
 int launch_both(LinAttnFusedArgs& a, hipStream_t s) {
-    const size_t row = (size_t)a.C * sizeof(T) + 32;
-    const size_t lds1 = ((3 * a.C + 8) * 4 + 15) / 16 * 16 + (size_t)a.slice1 * row + 64;
-    DMN_REQUIRE(lds1 <= 160 * 1024, DMN_ERR_LIMIT, "linear attention: LDS request %zu too large", lds1);
-    static bool attr = false;
-    if (!attr) {
-        DMN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&la_fused_ctx_kernel<T>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-    }
-    hipLaunchKernelGGL(la_fused_ctx_kernel<T>, dim3(a.splits, a.B), dim3(256), lds1, s, a);
-    DMN_HIP_CHECK(hipGetLastError());
     switch (a.C) {
-        case 32: return launch_out<T, 32>(a, s);
-        case 64: return launch_out<T, 64>(a, s);
-        case 128: return launch_out<T, 128>(a, s);
-        case 256: return launch_out<T, 256>(a, s);
+        case 32: return launch_pair<T, 32>(a, s);
+        case 64: return launch_pair<T, 64>(a, s);
+        case 128: return launch_pair<T, 128>(a, s);
+        case 256: return launch_pair<T, 256>(a, s);
     }
     dmn_set_error("fused linear attention: C=%d not instantiated", a.C);
     return DMN_ERR_INVALID;
@@ -450,9 +613,16 @@ bool linattn_fused_supported(int C, int heads, int dim_head) {
 void linattn_fused_plan(int n, int B, int C, int dtype, int* slice1, int* splits, int* tpw, int* slices) {
     const int row = C * (dtype == DMN_F32 ? 4 : 2) + 32;
     int s1 = 512;
+    if (n <= 256 && (n + 31) / 32 * 32 * row <= 128 * 1024) {   // small images: one workgroup per image writes the merged context itself (no merge launch)
+        *slice1 = (n + 31) / 32 * 32;
+        *splits = 1;
+        s1 = 0;
+    }
     while (s1 > 32 && ((long long)((n + s1 - 1) / s1) * B < 256 || s1 * row > 72 * 1024 || s1 / 2 >= n)) s1 /= 2;
-    *slice1 = s1;
-    *splits = (n + s1 - 1) / s1;
+    if (s1) {
+        *slice1 = s1;
+        *splits = (n + s1 - 1) / s1;
+    }
     int t = 4;
     while (t > 1 && ((long long)((n + 64 * t - 1) / (64 * t)) * B < 512 || 64 * t * row > 72 * 1024)) t /= 2;
     *tpw = t;
@@ -465,6 +635,9 @@ int launch_linattn_fused(LinAttnFusedArgs& a, hipStream_t s) {
                     a.slices == (a.n + 64 * a.tpw - 1) / (64 * a.tpw),
                 DMN_ERR_INVALID, "fused linear attention: inconsistent plan");
     DMN_REQUIRE(a.norm.stats && a.norm.G == 1, DMN_ERR_INVALID, "fused linear attention: GroupNorm(1) statistics of x required");
+    DMN_REQUIRE(a.ctxT, DMN_ERR_INVALID, "fused linear attention: needs the merged-context buffer");
+    DMN_REQUIRE(a.slices <= 65535 && a.splits <= 65535, DMN_ERR_LIMIT, "fused linear attention: image too large");
+    a.dbg = kernel_debug_buffer();
     if (a.dtype == DMN_F32) return launch_both<float>(a, s);
     return launch_both<__bf16>(a, s);
 }

@@ -365,11 +365,14 @@ static Act lin_attn(Fwd& f, const AttnW& w, Act& x) {
         y.sSlots = fa.slices;
         y.stats = f.new_stats(1, fa.slices);
         float* part = (float*)f.alloc((size_t)f.B * 4 * fa.splits * (32 * 32 + 64) * 4);
+        void* ctxT = f.alloc((size_t)f.B * 4 * 32 * 32 * f.esz());
+        fa.ctxT = ctxT;
         fa.y = y.p;
         fa.y_stats = y.stats;
         fa.ctx_part = part;
         if (f.ok() && !f.dry) f.run(launch_linattn_fused(fa, f.s));
         f.ar.release(part);
+        f.ar.release(ctxT);
         return lin_attn_tail(f, w, x, y);
     }
     NormIn pn = norm_in(x, w.ng, w.nb, f.B, 0, nullptr, 0);
@@ -527,6 +530,53 @@ int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float,
     }
     if (high) *high = f.ar.high;
     return f.rc;
+}
+
+static int pack_fragments(int dtype, const float* W, int rows, int K, bool acc_order, void** dev);
+
+// Fused linear attention on caller-provided tensors (unit parity tests, tuning). Packs + uploads the weights per call.
+extern "C" int dmn_test_linattn(int dtype, const void* x, const float* x_stats, int B, int n, int C, const float* gamma_host,
+                                const float* beta_host, const float* wqkv_host, const float* wout_host,
+                                const float* bout_host, void* y, float* y_stats, int* slices_out, void* scratch,
+                                size_t scratch_bytes, void* stream) {
+    DMN_REQUIRE(x && x_stats && y && y_stats && scratch, DMN_ERR_INVALID, "dmn_test_linattn: null argument");
+    DMN_REQUIRE(linattn_fused_supported(C, 4, 32), DMN_ERR_INVALID, "dmn_test_linattn: C=%d unsupported", C);
+    LinAttnFusedArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    void *fq = nullptr, *fk = nullptr, *fv = nullptr, *fo = nullptr;
+    float *g = nullptr, *bt = nullptr, *bo = nullptr;
+    int rc;
+    if ((rc = pack_fragments(dtype, wqkv_host, 128, C, false, &fq))) return rc;
+    if ((rc = pack_fragments(dtype, wqkv_host + (size_t)128 * C, 128, C, false, &fk))) return rc;
+    if ((rc = pack_fragments(dtype, wqkv_host + (size_t)256 * C, 128, C, false, &fv))) return rc;
+    if ((rc = pack_fragments(dtype, wout_host, C, 128, false, &fo))) return rc;
+    if ((rc = upload_f32(gamma_host, C, &g)) || (rc = upload_f32(beta_host, C, &bt)) || (rc = upload_f32(bout_host, C, &bo))) return rc;
+    fa.dtype = dtype;
+    fa.x = x;
+    fa.y = y;
+    fa.norm.stats = x_stats;
+    fa.norm.G = 1;
+    fa.norm.slots = 1;
+    fa.norm.inv_count = 1.0f / ((float)C * n);
+    fa.norm.gamma = g;
+    fa.norm.beta = bt;
+    fa.wq = fq; fa.wk = fk; fa.wv = fv; fa.wo = fo;
+    fa.bias = bo;
+    fa.B = B; fa.n = n; fa.C = C;
+    linattn_fused_plan(n, B, C, dtype, &fa.slice1, &fa.splits, &fa.tpw, &fa.slices);
+    const size_t need = (size_t)B * 4 * fa.splits * (32 * 32 + 64) * 4;
+    DMN_REQUIRE(scratch_bytes >= need, DMN_ERR_WORKSPACE, "dmn_test_linattn: scratch %zu < %zu", scratch_bytes, need);
+    fa.ctx_part = (float*)scratch;
+    fa.y_stats = y_stats;
+    if (slices_out) *slices_out = fa.slices;
+    void* ctxT = nullptr;
+    DMN_HIP_CHECK(hipMalloc(&ctxT, (size_t)B * 4 * 32 * 32 * 4));
+    fa.ctxT = ctxT;
+    rc = launch_linattn_fused(fa, (hipStream_t)stream);
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    void* fr[] = {fq, fk, fv, fo, g, bt, bo, ctxT};
+    for (void* q : fr) (void)hipFree(q);
+    return rc;
 }
 
 // Times the kernel that dominates a denoising step -- the level-0 3x3 convolution with the fused GroupNorm +
@@ -700,7 +750,7 @@ static int load_attn(const ParamMap& pm, DmnUnet* u, const std::string& pre, int
             if ((rc = pack_fragments(dtype, wq->data, hidden, c, false, &a.fq))) return rc;
             if ((rc = pack_fragments(dtype, wq->data + (size_t)hidden * c, hidden, c, false, &a.fk))) return rc;
             if ((rc = pack_fragments(dtype, wq->data + (size_t)2 * hidden * c, hidden, c, false, &a.fv))) return rc;
-            if ((rc = pack_fragments(dtype, wo->data, c, hidden, true, &a.fo))) return rc;
+            if ((rc = pack_fragments(dtype, wo->data, c, hidden, false, &a.fo))) return rc;
         }
     } else {
         if ((rc = load_conv(pm, dtype, pre + ".fn.fn.to_out", c, hidden, 1, 1, 0, true, false, a.out))) return rc;

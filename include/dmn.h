@@ -122,8 +122,16 @@ int dmn_fill_normal(float* x, int B, int per, uint64_t seed, uint32_t step, int6
 /* ---- single kernels, exported for unit parity tests -------------------------------------------------------------
  * Activations NHWC in the internal dtype (float32 or bfloat16 bit patterns). Weights HOST float32 in PyTorch layout;
  * these helpers pack + upload them per call (synchronous, test use only). */
-/* Tuning aid: every later convolution launch writes per-workgroup phase timestamps [workgroups][8] (int64) to
- * `dev` (device memory sized by the caller for the largest grid); NULL switches it off. */
+/* Fused LinearAttention core (parts/mha.py:44-58 up to and including to_out.0) on x [B][n][C] normalised with
+ * GroupNorm(1) from x_stats = {sum, sum of squares} per image: y [B][n][C] = to_out.0(attention) + bias, and the
+ * per-slice {sum, sum of squares} of y in y_stats [B][*slices_out][2]. wqkv [384][C], wout [C][128] HOST float32.
+ * scratch: device, >= B * 4 * ceil(n / 32) * 1088 * 4 bytes. */
+int dmn_test_linattn(int dtype, const void* x, const float* x_stats, int B, int n, int C, const float* gamma_host,
+                     const float* beta_host, const float* wqkv_host, const float* wout_host, const float* bout_host,
+                     void* y, float* y_stats, int* slices_out, void* scratch, size_t scratch_bytes, void* stream);
+/* Tuning aid: every later convolution / fused linear-attention launch writes per-workgroup phase timestamps (int64,
+ * 8 per workgroup; the second linear-attention kernel writes at workgroup offset 65536) to `dev`, device memory of
+ * at least 2 * 65536 * 8 int64; NULL switches it off. */
 int dmn_test_set_conv_debug(long long* dev);
 int dmn_test_conv2d(int dtype, const void* in0, const void* in1, int C0, int C1, int B, int H, int W, const float* w_host,
                     const float* bias_host, int Cout, int kh, int kw, int stride, int pad, int transposed, void* out,

@@ -191,3 +191,51 @@ def test_philox_matches_cpu_generator():
     # float64 Box-Muller rounded once: identical except for rare last-ulp differences of log/sincos
     assert np.abs(got - ref).max() <= 1e-6
     assert (got == ref).mean() > 0.99
+
+
+# ---- fused linear attention against the oracle (parts/mha.py:44-59) ---------------------------------------------
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("n_side,cch", [(16, 32), (8, 64), (4, 128), (8, 256), (32, 32)])
+def test_fused_linear_attention_matches_oracle(dtype, n_side, cch):
+    from oracle import ref_cpu as R
+    N = _N()
+    lib = N.lib()
+    B, n = 3, n_side * n_side
+    x = rnd((B, cch, n_side, n_side), 11)
+    gamma, beta = 1.0 + 0.1 * rnd((cch,), 12), 0.1 * rnd((cch,), 13)
+    p = {"a.to_qkv.weight": rnd((384, cch, 1, 1), 14, cch ** -0.5) * 2.0,
+         "a.to_out.0.weight": rnd((cch, 128, 1, 1), 15, 128 ** -0.5), "a.to_out.0.bias": 0.1 * rnd((cch,), 16),
+         "a.to_out.1.weight": torch.ones(cch), "a.to_out.1.bias": torch.zeros(cch)}
+    xq = q(x, dtype)
+    xn = F.group_norm(xq, 1, gamma, beta, eps=1e-5)
+    # reference value of to_out.0(...) before its GroupNorm: undo nothing, recompute the pieces
+    qkv = F.conv2d(xn, q(p["a.to_qkv.weight"], dtype))
+    qq, kk, vv = (t.reshape(B, 4, 32, n) for t in qkv.chunk(3, dim=1))
+    ctx = torch.einsum("bhdn,bhen->bhde", kk.softmax(-1), vv)
+    o = torch.einsum("bhde,bhdn->bhen", ctx, qq.softmax(-2) * 32 ** -0.5).reshape(B, 128, n_side, n_side)
+    ref = F.conv2d(o, q(p["a.to_out.0.weight"], dtype), p["a.to_out.0.bias"])
+    assert torch.allclose(F.group_norm(ref, 1), R.linear_attention({k: (q(v, dtype) if "weight" in k and v.ndim == 4 else v)
+                                                                   for k, v in p.items()}, "a", xn), atol=1e-4)
+    xd = to_dev_nhwc(x, dtype)
+    xs = torch.stack([xq.sum((1, 2, 3)), (xq * xq).sum((1, 2, 3))], 1).contiguous().cuda()
+    y = torch.zeros((B, n_side, n_side, cch), device="cuda", dtype=torch.bfloat16 if dtype == 1 else torch.float32)
+    ystats = torch.full((B * 1024 * 2,), float("nan"), device="cuda")
+    scratch = torch.zeros((B * 4 * ((n + 31) // 32) * 1088,), device="cuda")
+    slices = C.c_int(0)
+    wqkv = np.ascontiguousarray(p["a.to_qkv.weight"].reshape(384, cch).numpy())
+    wout = np.ascontiguousarray(p["a.to_out.0.weight"].reshape(cch, 128).numpy())
+    bout = np.ascontiguousarray(p["a.to_out.0.bias"].numpy())
+    N.check(lib.dmn_test_linattn(dtype, xd.data_ptr(), xs.data_ptr(), B, n, cch, np.ascontiguousarray(gamma.numpy()).ctypes.data,
+                                 np.ascontiguousarray(beta.numpy()).ctypes.data, wqkv.ctypes.data, wout.ctypes.data,
+                                 bout.ctypes.data, y.data_ptr(), ystats.data_ptr(), C.byref(slices), scratch.data_ptr(),
+                                 scratch.numel() * 4, None))
+    torch.cuda.synchronize()
+    got = from_dev_nhwc(y)
+    assert (got - ref).abs().max() <= (5e-5 if dtype == 0 else 4e-2) * max(1.0, float(ref.abs().max()))
+    st = ystats[: B * slices.value * 2].reshape(B, slices.value, 2).sum(1).cpu()
+    gq = got.double()
+    want = torch.stack([gq.sum((1, 2, 3)), (gq * gq).sum((1, 2, 3))], 1)
+    if dtype == 0:
+        assert torch.allclose(st.double(), want, rtol=1e-4, atol=1e-2)
+    else:   # statistics are taken from the fp32 values before rounding to bf16
+        assert torch.allclose(st.double(), want, rtol=3e-2, atol=1.0)
