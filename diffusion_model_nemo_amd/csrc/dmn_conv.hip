@@ -46,7 +46,12 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
     using KT = KindTraits<KIND>;
     static_assert(WM * WN == 4, "four waves per workgroup");
     constexpr int NTAPS = KT::NTAPS, S = KT::S, GK = KT::GK, KW = KT::KW;
-    constexpr int E = NTAPS * GK;                   // ring entries: GK k-steps x all taps
+    constexpr int E = NTAPS * GK;                   // (k-step, tap) pairs per iteration of the k loop
+    // weight ring depth: the 16x16-pixel tiles run at high occupancy and only look RS fragments ahead (few
+    // registers, latency hidden by the other waves); the 8x8 tiles of the wide layers run one workgroup per CU
+    // and keep a whole iteration in flight
+    constexpr int RS = TH == 16 ? (NTAPS == 9 ? 3 : (E >= 4 ? 4 : E)) : E;
+    static_assert(E % RS == 0, "ring depth must divide the iteration");
     constexpr int BM = TH * TW;
     constexpr int MT = BM / (16 * WM);
     constexpr int NT = BN / (16 * WN);
@@ -99,15 +104,15 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
         const int ct = n0 / 16 + wn * NT + nt;
         wfrag[nt] = static_cast<const T*>(a.w) + P.w_off + ((size_t)ct * KS * NTAPS * 64 + lane) * PER;
     }
-    V w[E][NT];
-    auto ring_fill = [&](int e, int ks0) {
+    V w[RS][NT];
+    const int nflat = KS * NTAPS;                   // fragments per output-channel tile
+    auto ring_fill = [&](int slot, int flat) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-            w[e][nt] = *reinterpret_cast<const V*>(wfrag[nt] + ((size_t)ks0 * NTAPS + e) * 64 * PER);
+        for (int nt = 0; nt < NT; ++nt) w[slot][nt] = *reinterpret_cast<const V*>(wfrag[nt] + (size_t)flat * 64 * PER);
     };
 #pragma unroll
-    for (int e = 0; e < E; ++e)
-        if (GK == 1 || e / NTAPS < KSG) ring_fill(e, 0);
+    for (int e = 0; e < RS; ++e)
+        if (e < nflat) ring_fill(e, e);
 
     f32x4 bias[NT];
 #pragma unroll
@@ -201,11 +206,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
         }
         const int ksbase = cg0 / KCH;
         for (int ksl = 0; ksl < KSG; ksl += GK) {
-            // k-step the ring is refilled for: the next iteration's, possibly in the next channel group
-            const bool wrap = ksl + GK >= KSG;
-            const int nksl = wrap ? 0 : ksl + GK;
-            const int nks0 = wrap ? ksbase + KSG : ksbase + ksl + GK;
-            const bool more = nks0 < KS;
+            const int flat0 = (ksbase + ksl) * NTAPS; // fragment index of entry 0 of this iteration
             Vec16<T> xf[XB][MT];
             auto load_x = [&](int e, int buf) {
                 const int dk = e / NTAPS, t = e % NTAPS;
@@ -226,13 +227,13 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
                 if (GK == 1 || ksl + dk < KSG) {
                     Vec16<T> wv[NT];
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) wv[nt].v = w[e][nt];
+                    for (int nt = 0; nt < NT; ++nt) wv[nt].v = w[e % RS][nt];
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) mma_step(wv[nt], xf[XB == 2 ? (e & 1) : 0][mt], acc[mt][nt]);
                 }
-                if (more && (GK == 1 || nksl + dk < KSG)) ring_fill(e, nks0);
+                if (flat0 + e + RS < nflat) ring_fill(e % RS, flat0 + e + RS);   // the slot just consumed
                 __builtin_amdgcn_sched_barrier(0);   // keep later taps' LDS reads from piling up in registers
             }
         }
@@ -512,6 +513,7 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
     const int upp = a.cg / (a.dtype == DMN_F32 ? 4 : 8);
     DMN_REQUIRE(upp <= 256 && (upp & (upp - 1)) == 0, DMN_ERR_INVALID,
                 "conv: %d channels per staged group (need a power of two <= %d)", a.cg, a.dtype == DMN_F32 ? 1024 : 2048);
+    DMN_REQUIRE(a.cg == Cin || (a.cg / kch) % 4 == 0, DMN_ERR_INVALID, "conv: channel group %d too small for %d channels", a.cg, Cin);
     a.lg_upp = 0;
     while ((1 << a.lg_upp) < upp) ++a.lg_upp;
     DMN_REQUIRE((long long)a.B * a.H * a.W * (a.C0 > a.C1 ? a.C0 : a.C1) < (1ll << 31), DMN_ERR_LIMIT,

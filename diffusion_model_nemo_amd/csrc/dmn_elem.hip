@@ -217,6 +217,78 @@ __global__ void __launch_bounds__(256) ingest_kernel(const IngestArgs a) {
     }
 }
 
+// bf16 MFMA form of the ingest: the image tile is staged as [row][pixel][4 channels] bf16 (channel 3 = 0), so for
+// kernel row ky the 8 pixels x 4 channels to the right of an output pixel are 64 contiguous bytes = one k-step
+// (the eighth pixel meets zero weights). 7 k-steps per output tile instead of 147 scalar taps.
+template <int COUT>
+__global__ void __launch_bounds__(256) ingest_mfma_kernel(const IngestArgs a) {
+    constexpr int TS = 16, HALO = 3, IH = TS + 2 * HALO, RW = 24, NT = COUT / 16;
+    __shared__ __attribute__((aligned(16))) __bf16 sIn[IH * RW * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int tiles_x = (a.W + TS - 1) / TS;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
+    const int b = blockIdx.y;
+    const int y0 = ty * TS - HALO, x0 = tx * TS - HALO;
+    // weights first: 7 * NT fragments per wave, straight into registers
+    bf16x8 wf[NT][7];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky)
+            wf[nt][ky] = *reinterpret_cast<const bf16x8*>(static_cast<const __bf16*>(a.wfrag) + ((size_t)(nt * 7 + ky) * 64 + lane) * 8);
+    f32x4 bias[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bias[nt] = *reinterpret_cast<const f32x4*>(a.bias + nt * 16 + lq * 4);
+    for (int i = tid; i < IH * RW; i += 256) {
+        const int ly = i / RW, lx = i % RW;
+        const int gy = y0 + ly, gx = x0 + lx;
+        const bool in = lx < IH && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        bf16x4 v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float f = 0.f;
+            if (in && c < a.Cin) f = a.x[((size_t)(b * a.Cin + c) * a.H + gy) * a.W + gx];
+            v[c] = (__bf16)f;
+        }
+        *reinterpret_cast<bf16x4*>(&sIn[i * 4]) = v;
+    }
+    __syncthreads();
+    // wave w: output rows 4w .. 4w+3 (one 16-pixel tile each), all output channels
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[r][nt] = bias[nt];
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const __bf16* src = &sIn[(((wave * 4 + r) + ky) * RW + l15 + 2 * lq) * 4];   // 8-byte aligned
+            const bf16x4 lo = *reinterpret_cast<const bf16x4*>(src);
+            const bf16x4 hi = *reinterpret_cast<const bf16x4*>(src + 4);
+            const bf16x8 xv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][ky], xv, acc[r][nt], 0, 0, 0);
+        }
+    // lane: pixel l15 of the row, output channels 16*nt + 4*lq .. +3
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int oy = ty * TS + wave * 4 + r, ox = tx * TS + l15;
+        if (oy < a.H && ox < a.W) {
+            __bf16* dst = static_cast<__bf16*>(a.out) + ((size_t)(b * a.H + oy) * a.W + ox) * COUT;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                bf16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (__bf16)acc[r][nt][j];
+                *reinterpret_cast<bf16x4*>(dst + nt * 16 + lq * 4) = o;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Egress: final_conv tail (modules/unet.py:112-116): [GroupNorm(groups) -> SiLU ->] 1x1 conv to 3 or 6
 // channels, written in the reference's NCHW fp32 layout. One pixel per thread.
@@ -303,7 +375,10 @@ int launch_ingest(IngestArgs& a, hipStream_t s) {
     DMN_REQUIRE(a.Cin >= 1 && a.Cin <= 4, DMN_ERR_LIMIT, "ingest: Cin=%d (max 4)", a.Cin);
     dim3 grid(((a.H + 15) / 16) * ((a.W + 15) / 16), a.B);
 #define DMN_INGEST(T, N) hipLaunchKernelGGL((ingest_kernel<T, N>), grid, dim3(256), 0, s, a)
-    if (a.Cout == 32) {
+    if (a.dtype == DMN_BF16 && a.wfrag && (a.Cout == 32 || a.Cout == 64)) {
+        if (a.Cout == 32) hipLaunchKernelGGL(ingest_mfma_kernel<32>, grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(ingest_mfma_kernel<64>, grid, dim3(256), 0, s, a);
+    } else if (a.Cout == 32) {
         if (a.dtype == DMN_F32) DMN_INGEST(float, 32); else DMN_INGEST(__bf16, 32);
     } else if (a.Cout == 64) {
         if (a.dtype == DMN_F32) DMN_INGEST(float, 64); else DMN_INGEST(__bf16, 64);

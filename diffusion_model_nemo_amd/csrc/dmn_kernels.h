@@ -99,6 +99,7 @@ struct IngestArgs {
     int dtype;
     const float* x;   // [B][Cin][H][W]
     const float* w;   // [Cin][7][7][Cout] (transposed from the PyTorch layout on the host)
+    const void* wfrag;  // optional (bf16 only): MFMA A fragments [Cout/16][7 rows][64 lanes][8], k = 4*dx + ci
     const float* bias;
     void* out;        // [B][H][W][Cout]
     int B, Cin, H, W, Cout;

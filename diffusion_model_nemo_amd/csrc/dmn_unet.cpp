@@ -470,6 +470,7 @@ int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float,
         ia.dtype = c.dtype;
         ia.x = x;
         ia.w = u->init_w;
+        ia.wfrag = u->init_wfrag;
         ia.bias = u->init_b;
         ia.out = cur.p;
         ia.B = B; ia.Cin = c.channels; ia.H = H; ia.W = W; ia.Cout = c.dim;
@@ -795,6 +796,8 @@ static void free_weights(DmnUnet* u) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
+    if (u->init_wfrag) (void)hipFree(u->init_wfrag);
+    u->init_wfrag = nullptr;
     u->loaded = false;
 }
 
@@ -855,6 +858,22 @@ extern "C" int dmn_unet_load_weights(DmnUnet* u, const DmnTensorDesc* params, in
             for (int k = 0; k < taps; ++k) wt[(size_t)k * dim + o] = w->data[(size_t)o * taps + k];
         if ((rc = upload_f32(wt.data(), wt.size(), &u->init_w))) return rc;
         if ((rc = upload_f32(b->data, dim, &u->init_b))) return rc;
+        if (c.dtype == DMN_BF16) {
+            // MFMA form: per kernel row ky one k-step of 8 pixels x 4 channels (k = 4*dx + ci, zero for dx = 7 and
+            // ci >= channels), A-operand fragments [Cout/16][7][64 lanes][8]
+            std::vector<uint16_t> fr((size_t)(dim / 16) * 7 * 64 * 8);
+            size_t o = 0;
+            for (int ct = 0; ct < dim / 16; ++ct)
+                for (int ky = 0; ky < 7; ++ky)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int k = (lane >> 4) * 8 + j, dx = k >> 2, ci = k & 3;
+                            const int co = ct * 16 + (lane & 15);
+                            const float v = (dx < 7 && ci < c.channels) ? w->data[(((size_t)co * c.channels + ci) * 7 + ky) * 7 + dx] : 0.f;
+                            fr[o++] = f32_to_bf16_rne(v);
+                        }
+            if ((rc = upload(fr.data(), fr.size() * 2, &u->init_wfrag))) return rc;
+        }
     }
     if (c.with_time_emb) {
         GETP(w1, "time_mlp.1.weight", td, dim);

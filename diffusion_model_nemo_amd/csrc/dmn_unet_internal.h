@@ -58,6 +58,7 @@ struct DmnUnet {
     int tb_total = 0;
     // ingest / egress (fp32)
     float *init_w = nullptr, *init_b = nullptr, *tail_g = nullptr, *tail_b = nullptr, *tail_w = nullptr, *tail_bias = nullptr;
+    void* init_wfrag = nullptr;   // bf16 handles: ingest weights as MFMA fragments
     // cached step graph of the sampling loops
     hipGraphExec_t graph_exec = nullptr;
     SampleKey graph_key = {};
