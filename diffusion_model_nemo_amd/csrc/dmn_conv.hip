@@ -41,8 +41,11 @@ template <> struct KindTraits<DMN_K4X4S2> { static constexpr int NTAPS = 16, EXT
 template <> struct KindTraits<DMN_KT2X2> { static constexpr int NTAPS = 4, EXT = 2, S = 1, KW = 2, GK = 2; };
 
 // PRO: 0 = input used as is, 1 = GroupNorm affine, 2 = GroupNorm affine + SiLU (+ time bias) while staging.
-template <typename T, int KIND, int TH, int TW, int BN, int WM, int WN, int PRO>
+// RES: also apply a 1x1 convolution (w2, bias2 -> out2) to the same input tile -- the ResnetBlock shortcut
+// res_conv(x) beside block1.proj(x) (parts/convnext.py:76,79,86) -- sharing the staged tile; 3x3 kind only.
+template <typename T, int KIND, int TH, int TW, int BN, int WM, int WN, int PRO, bool RES>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
+    static_assert(!RES || KIND == DMN_K3X3, "the fused 1x1 shortcut rides on the 3x3 kernel");
     using KT = KindTraits<KIND>;
     static_assert(WM * WN == 4, "four waves per workgroup");
     constexpr int NTAPS = KT::NTAPS, S = KT::S, GK = KT::GK, KW = KT::KW;
@@ -119,6 +122,22 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
     for (int nt = 0; nt < NT; ++nt) {
         bias[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (a.bias) bias[nt] = *reinterpret_cast<const f32x4*>(a.bias + n0 + (wn * NT + nt) * 16 + lq * 4);
+    }
+    // fused shortcut: fragment (ct, ks) of the 1x1 weights, fetched one k-step ahead of its use at the centre tap
+    const T* w2frag[RES ? NT : 1];
+    V w2v[RES ? NT : 1];
+    f32x4 acc2[RES ? MT : 1][RES ? NT : 1];
+    if constexpr (RES) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int ct = n0 / 16 + wn * NT + nt;
+            w2frag[nt] = static_cast<const T*>(a.w2) + ((size_t)ct * KS * 64 + lane) * PER;
+            w2v[nt] = *reinterpret_cast<const V*>(w2frag[nt]);
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
     // tile staging: unit u = tid + 256*j is the 16-byte column `part` of halo pixel u >> lgu
@@ -232,6 +251,19 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) mma_step(wv[nt], xf[XB == 2 ? (e & 1) : 0][mt], acc[mt][nt]);
+                    if constexpr (RES) {
+                        if (e == 4) {   // centre tap: the pixel itself
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) {
+                                Vec16<T> w2;
+                                w2.v = w2v[nt];
+#pragma unroll
+                                for (int mt = 0; mt < MT; ++mt) mma_step(w2, xf[XB == 2 ? (e & 1) : 0][mt], acc2[mt][nt]);
+                                if (ksbase + ksl + 1 < KS)
+                                    w2v[nt] = *reinterpret_cast<const V*>(w2frag[nt] + (size_t)(ksbase + ksl + 1) * 64 * PER);
+                            }
+                        }
+                    }
                 }
                 if (flat0 + e + RS < nflat) ring_fill(e % RS, flat0 + e + RS);   // the slot just consumed
                 __builtin_amdgcn_sched_barrier(0);   // keep later taps' LDS reads from piling up in registers
@@ -290,6 +322,30 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
                 }
             }
         }
+        if constexpr (RES) {
+            T* out2 = static_cast<T*>(a.out2);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = n0 + (wn * NT + nt) * 16 + lq * 4;
+                const f32x4 b2 = *reinterpret_cast<const f32x4*>(a.bias2 + n);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int p = (wm * MT + mt) * 16 + l15;
+                    const int oyt = tile_y * TH + p / TW, oxt = tile_x * TW + p % TW;
+                    if (oyt < a.Ho && oxt < a.Wo) {
+                        const size_t o = ((size_t)(b * a.out_H + oyt) * a.out_W + oxt) * a.Cout + n;
+                        if constexpr (sizeof(T) == 4) {
+                            *reinterpret_cast<f32x4*>(out2 + o) = acc2[mt][nt] + b2;
+                        } else {
+                            bf16x4 ov;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) ov[r] = (__bf16)(acc2[mt][nt][r] + b2[r]);
+                            *reinterpret_cast<bf16x4*>(out2 + o) = ov;
+                        }
+                    }
+                }
+            }
+        }
         if (want_stats) {
             // reduce over the 16 pixel lanes; lane (lane&15)==0 of each quarter holds the sums of a 4-channel quad
 #pragma unroll
@@ -334,11 +390,11 @@ struct TileCfg {
     int th, tw, bn;
 };
 
-template <typename T, int KIND, int TH, int TW, int BN, int WM, int WN, int PRO>
+template <typename T, int KIND, int TH, int TW, int BN, int WM, int WN, int PRO, bool RES = false>
 int launch_cfg(const ConvArgs& a, size_t lds, hipStream_t s) {
     const int tiles = ((a.Ho + TH - 1) / TH) * ((a.Wo + TW - 1) / TW);
     dim3 grid(tiles, a.Cout / BN, a.B * a.nphase);
-    hipLaunchKernelGGL((conv_igemm_kernel<T, KIND, TH, TW, BN, WM, WN, PRO>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, KIND, TH, TW, BN, WM, WN, PRO, RES>), grid, dim3(256), lds, s, a);
     DMN_HIP_CHECK(hipGetLastError());
     return DMN_OK;
 }
@@ -366,6 +422,7 @@ TileCfg pick_cfg(const ConvArgs& a) {
         else c.th = c.tw = 8;
     }
     if (c.th == 8 && c.bn == 64 && blocks(c) < 256) c.bn = 32;
+    if (a.w2 && c.th == 16 && c.bn == 64) c.th = c.tw = 8;   // two accumulator sets: keep the per-wave tile small
     return c;
 }
 
@@ -409,8 +466,24 @@ int dispatch_tile(const ConvArgs& a, const TileCfg& c, size_t lds, hipStream_t s
 }
 
 template <typename T>
+int dispatch_fused_shortcut(const ConvArgs& a, const TileCfg& c, size_t lds, hipStream_t s) {
+    if (c.th == 16 && c.bn == 32) return launch_cfg<T, DMN_K3X3, 16, 16, 32, 2, 2, 0, true>(a, lds, s);
+    if (c.th == 8 && c.bn == 32) return launch_cfg<T, DMN_K3X3, 8, 8, 32, 2, 2, 0, true>(a, lds, s);
+    if (c.th == 8 && c.bn == 64) return launch_cfg<T, DMN_K3X3, 8, 8, 64, 1, 4, 0, true>(a, lds, s);
+    dmn_set_error("conv: no fused-shortcut kernel for tile %dx%d / %d", c.th, c.tw, c.bn);
+    return DMN_ERR_INVALID;
+}
+
+template <typename T>
 int dispatch(const ConvArgs& a, const TileCfg& c, size_t lds, hipStream_t s) {
     const int pro = a.pro.stats ? (a.pro.silu ? 2 : 1) : 0;
+    if (a.w2) {
+        if (a.kind != DMN_K3X3 || pro != 0) {
+            dmn_set_error("conv: the fused 1x1 shortcut needs a plain 3x3 convolution");
+            return DMN_ERR_INVALID;
+        }
+        return dispatch_fused_shortcut<T>(a, c, lds, s);
+    }
     switch (a.kind) {
         case DMN_K3X3:
             if (pro == 0) return dispatch_tile<T, DMN_K3X3, 0>(a, c, lds, s);
@@ -434,10 +507,10 @@ int dispatch(const ConvArgs& a, const TileCfg& c, size_t lds, hipStream_t s) {
     return DMN_ERR_INVALID;
 }
 
-template <typename T, int KIND, int TH, int TW, int BN, int WM, int WN, int PRO>
+template <typename T, int KIND, int TH, int TW, int BN, int WM, int WN, int PRO, bool RES = false>
 int set_attr() {
     // opt in to more than 64 KiB of dynamic LDS (done once at handle creation, never inside a stream capture)
-    DMN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, KIND, TH, TW, BN, WM, WN, PRO>),
+    DMN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, KIND, TH, TW, BN, WM, WN, PRO, RES>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return DMN_OK;
 }
@@ -465,6 +538,9 @@ int set_attr_all() {
     if ((rc = set_attr_kind<T, DMN_K1X1, 2>())) return rc;
     if ((rc = set_attr_kind<T, DMN_K4X4S2, 0>())) return rc;
     if ((rc = set_attr_kind<T, DMN_KT2X2, 0>())) return rc;
+    if ((rc = set_attr<T, DMN_K3X3, 16, 16, 32, 2, 2, 0, true>())) return rc;
+    if ((rc = set_attr<T, DMN_K3X3, 8, 8, 32, 2, 2, 0, true>())) return rc;
+    if ((rc = set_attr<T, DMN_K3X3, 8, 8, 64, 1, 4, 0, true>())) return rc;
     return DMN_OK;
 }
 

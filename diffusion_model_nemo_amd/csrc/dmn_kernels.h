@@ -54,6 +54,9 @@ struct ConvArgs {
     NormIn pro;           // normalise + activate the input while staging it (in0 only)
     const void* res;      // optional residual added in the epilogue, same shape as out
     NormOut epi;          // statistics of the output after bias (taken before the residual add)
+    const void* w2;       // optional fused 1x1 convolution of the same input (3x3 kind, no input normalisation):
+    const float* bias2;   //   weights packed like `w` with one tap, bias [Cout],
+    void* out2;           //   output [B][out_H][out_W][Cout]
     int cg, lg_upp;       // channels staged per group and log2 of its 16-byte units per pixel; set by the launcher
     long long* dbg;       // optional [workgroups][8] phase timestamps (tuning aid; nullptr in production)
     int cfg_tile, cfg_bn; // 0 = choose automatically; otherwise force the pixel tile (8 or 16) / channel tile (32 or 64)

@@ -263,7 +263,8 @@ static NormIn norm_in(const Act& a, const float* gamma, const float* beta, int B
 }
 
 // conv with optional: second source, input normalisation, residual, output statistics
-static Act do_conv(Fwd& f, const PackedConv& pc, const Act& in0, const Act* in1, const NormIn* pro, const Act* res, int epiG) {
+static Act do_conv(Fwd& f, const PackedConv& pc, const Act& in0, const Act* in1, const NormIn* pro, const Act* res, int epiG,
+                   const PackedConv* shortcut = nullptr, Act* shortcut_out = nullptr) {
     ConvArgs a;
     conv_args_from(pc, f.u->cfg.dtype, a, f.B, in0.H, in0.W);
     a.in0 = in0.p;
@@ -276,6 +277,12 @@ static Act do_conv(Fwd& f, const PackedConv& pc, const Act& in0, const Act* in1,
     Act out = f.new_act(pc.Cout, a.out_H, a.out_W);
     a.out = out.p;
     if (res) a.res = res->p;
+    if (shortcut) {   // 1x1 convolution of the same input, computed by the same launch
+        *shortcut_out = f.new_act(pc.Cout, a.out_H, a.out_W);
+        a.w2 = shortcut->w;
+        a.bias2 = shortcut->bias;
+        a.out2 = shortcut_out->p;
+    }
     if (epiG > 0) {
         a.epi.G = epiG;
         out.sG = epiG;
@@ -292,11 +299,8 @@ static Act resblock(Fwd& f, const ResBlockW& w, Act& x, Act* x2, const float* tb
     const int G = f.u->cfg.groups;
     Act r;
     const Act* resp = &x;
-    if (w.has_res) {
-        r = do_conv(f, w.res, x, x2, nullptr, nullptr, 0);
-        resp = &r;
-    }
-    Act h1 = do_conv(f, w.c1, x, x2, nullptr, nullptr, G);
+    if (w.has_res) resp = &r;   // res_conv(x) comes out of block1's launch (same input tile)
+    Act h1 = do_conv(f, w.c1, x, x2, nullptr, nullptr, G, w.has_res ? &w.res : nullptr, w.has_res ? &r : nullptr);
     NormIn n1 = norm_in(h1, w.g1, w.b1, f.B, 1, w.tb_off >= 0 ? tb + w.tb_off : nullptr, tb_stride);
     Act h2 = do_conv(f, w.c2, h1, nullptr, &n1, nullptr, G);
     f.free_act(h1);
