@@ -12,9 +12,10 @@ namespace {
 // Grid: (chunks, B); every workgroup owns kPixPerWg consecutive pixels of one image.
 // ---------------------------------------------------------------------------------------------------
 constexpr int kNormThreads = 256;
-constexpr int kNormElems = 8192;   // elements per workgroup
+constexpr int kNormElems = 8192;        // elements per workgroup for large tensors ...
+constexpr int kNormElemsSmall = 2048;   // ... and when that would leave most CUs without a workgroup
 
-template <typename T>
+template <typename T, int ELEMS>
 __global__ void __launch_bounds__(kNormThreads) norm_apply_kernel(const NormApplyArgs a, int pix_per_wg) {
     constexpr int PER = ElemTraits<T>::kPer16B;
     using V = decltype(Vec16<T>::v);
@@ -33,7 +34,7 @@ __global__ void __launch_bounds__(kNormThreads) norm_apply_kernel(const NormAppl
 
     // issue every data load first (a workgroup owns at most kNormElems elements), then derive the
     // normalisation coefficients while they are in flight
-    constexpr int NV = kNormElems / PER / kNormThreads;
+    constexpr int NV = ELEMS / PER / kNormThreads;
     V vin[NV], vres[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
@@ -332,9 +333,12 @@ __global__ void __launch_bounds__(256) egress_kernel(const EgressArgs a) {
 
 }  // namespace
 
-int norm_apply_slots(int HW, int C) {
-    // enough workgroups to fill the chip at batch 64 while keeping >= 8 KiB per workgroup
-    int pix = kNormElems / C;
+static int norm_apply_elems(int B, int HW, int C) {
+    return (long long)B * HW * C / kNormElems >= 1024 ? kNormElems : kNormElemsSmall;
+}
+
+int norm_apply_slots(int B, int HW, int C) {
+    int pix = norm_apply_elems(B, HW, C) / C;
     if (pix < 1) pix = 1;
     if (pix > HW) pix = HW;
     return (HW + pix - 1) / pix;
@@ -343,8 +347,9 @@ int norm_apply_slots(int HW, int C) {
 int launch_norm_apply(NormApplyArgs& a, hipStream_t s) {
     const int per = a.dtype == DMN_F32 ? 4 : 8;
     DMN_REQUIRE(a.C % per == 0 && a.C % a.norm.G == 0, DMN_ERR_INVALID, "norm_apply: C=%d groups=%d", a.C, a.norm.G);
-    DMN_REQUIRE(kNormThreads % (a.C / per) == 0 && a.C <= kNormElems, DMN_ERR_INVALID, "norm_apply: C=%d must be a power-of-two multiple of %d", a.C, per);
-    const int slots = norm_apply_slots(a.HW, a.C);
+    DMN_REQUIRE(kNormThreads % (a.C / per) == 0 && a.C <= kNormElemsSmall, DMN_ERR_INVALID, "norm_apply: C=%d must be a power-of-two multiple of %d", a.C, per);
+    const int slots = norm_apply_slots(a.B, a.HW, a.C);
+    const bool small = norm_apply_elems(a.B, a.HW, a.C) == kNormElemsSmall;
     const int pix = (a.HW + slots - 1) / slots;
     int Go = 1;
     if (a.epi.stats) {
@@ -356,10 +361,13 @@ int launch_norm_apply(NormApplyArgs& a, hipStream_t s) {
     if ((size_t)8 * Go > tmp) tmp = 8 * Go;
     const size_t lds = (3 * (size_t)a.C + tmp) * 4;
     dim3 grid(slots, a.B);
-    if (a.dtype == DMN_F32)
-        hipLaunchKernelGGL(norm_apply_kernel<float>, grid, dim3(kNormThreads), lds, s, a, pix);
-    else
-        hipLaunchKernelGGL(norm_apply_kernel<__bf16>, grid, dim3(kNormThreads), lds, s, a, pix);
+    if (a.dtype == DMN_F32) {
+        if (small) hipLaunchKernelGGL((norm_apply_kernel<float, kNormElemsSmall>), grid, dim3(kNormThreads), lds, s, a, pix);
+        else hipLaunchKernelGGL((norm_apply_kernel<float, kNormElems>), grid, dim3(kNormThreads), lds, s, a, pix);
+    } else {
+        if (small) hipLaunchKernelGGL((norm_apply_kernel<__bf16, kNormElemsSmall>), grid, dim3(kNormThreads), lds, s, a, pix);
+        else hipLaunchKernelGGL((norm_apply_kernel<__bf16, kNormElems>), grid, dim3(kNormThreads), lds, s, a, pix);
+    }
     DMN_HIP_CHECK(hipGetLastError());
     return DMN_OK;
 }

@@ -78,7 +78,7 @@ struct NormApplyArgs {
     NormOut epi;
 };
 int launch_norm_apply(NormApplyArgs& a, hipStream_t s);
-int norm_apply_slots(int HW, int C);
+int norm_apply_slots(int B, int HW, int C);
 
 // time path: sinusoid -> Linear -> GELU -> Linear -> SiLU -> all per-block Linear(4*dim, Cout_i)
 struct TimeArgs {

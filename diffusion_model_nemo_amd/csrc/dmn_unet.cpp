@@ -317,7 +317,7 @@ static Act resblock(Fwd& f, const ResBlockW& w, Act& x, Act* x2, const float* tb
     na.norm = norm_in(h2, w.g2, w.b2, f.B, 1, nullptr, 0);
     if (statsG > 0) {
         out.sG = statsG;
-        out.sSlots = norm_apply_slots(na.HW, na.C);
+        out.sSlots = norm_apply_slots(na.B, na.HW, na.C);
         out.stats = f.new_stats(statsG, out.sSlots);
         na.epi.stats = out.stats;
         na.epi.G = statsG;
