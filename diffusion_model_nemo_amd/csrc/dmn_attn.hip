@@ -175,15 +175,21 @@ __global__ void __launch_bounds__(256) linattn_out_kernel(const LinAttnArgs a) {
     }
 }
 
-// softmax attention; grid (heads, B, query blocks of 256); K/V of a 128-key chunk in LDS; online softmax
+// softmax attention; grid (heads, B, query blocks); K/V of a 128-key chunk in LDS; online softmax.
+// A workgroup serves 256 / parts queries; the `parts` threads of a query (parts = 1, 2 or 4, chosen so that small
+// images still use every thread) walk interleaved keys and merge their (max, sum, accumulator) through LDS.
 template <typename T>
-__global__ void __launch_bounds__(256) attention_kernel(const AttnArgs a) {
+__global__ void __launch_bounds__(256) attention_kernel(const AttnArgs a, int parts) {
     constexpr int KC = 128;   // keys per LDS chunk
-    __shared__ float sK[KC][kD + 4];
-    __shared__ float sV[KC][kD + 4];
+    constexpr int ROW = kD + 4;
+    __shared__ __attribute__((aligned(16))) float sKV[2 * KC * ROW];   // K rows, then V rows; reused for the merge
+    float(*sK)[ROW] = reinterpret_cast<float(*)[ROW]>(sKV);
+    float(*sV)[ROW] = reinterpret_cast<float(*)[ROW]>(sKV + KC * ROW);
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int hidden = a.heads * kD;
-    const int qi = blockIdx.z * 256 + tid;
+    const int qpw = 256 / parts;                  // queries per workgroup
+    const int ql = tid % qpw, part = tid / qpw;
+    const int qi = blockIdx.z * qpw + ql;
     const bool active = qi < a.n;
     const T* base = static_cast<const T*>(a.qkv) + (size_t)b * a.n * 3 * hidden;
     float q[kD], acc[kD];
@@ -211,7 +217,7 @@ __global__ void __launch_bounds__(256) attention_kernel(const AttnArgs a) {
             for (int j = 0; j < kD; ++j) { sK[tid][j] = kk[j]; sV[tid][j] = vv[j]; }
         }
         __syncthreads();
-        for (int j = 0; j < nk; ++j) {
+        for (int j = part; j < nk; j += parts) {
             float s = 0.f;
 #pragma unroll
             for (int c = 0; c < kD; c += 4) {
@@ -234,6 +240,31 @@ __global__ void __launch_bounds__(256) attention_kernel(const AttnArgs a) {
                 acc[c + 3] = fmaf(pj, vv[3], acc[c + 3] * alpha);
             }
             m = mn;
+        }
+    }
+    if (parts > 1) {
+        // merge the partial softmaxes of a query: rows of 35 floats (max, sum, 32 accumulators), odd pitch
+        constexpr int MR = kD + 3;
+        __syncthreads();
+        float* mine = sKV + (size_t)tid * MR;
+        mine[0] = m;
+        mine[1] = l;
+#pragma unroll
+        for (int j = 0; j < kD; ++j) mine[2 + j] = acc[j];
+        __syncthreads();
+        if (part != 0) return;
+        float M = m;
+        for (int p = 1; p < parts; ++p) M = fmaxf(M, sKV[(size_t)(p * qpw + ql) * MR]);
+        const float f0 = m == -INFINITY ? 0.f : expf(m - M);
+        l *= f0;
+#pragma unroll
+        for (int j = 0; j < kD; ++j) acc[j] *= f0;
+        for (int p = 1; p < parts; ++p) {
+            const float* o = sKV + (size_t)(p * qpw + ql) * MR;
+            const float f = o[0] == -INFINITY ? 0.f : expf(o[0] - M);
+            l = fmaf(o[1], f, l);
+#pragma unroll
+            for (int j = 0; j < kD; ++j) acc[j] = fmaf(o[2 + j], f, acc[j]);
         }
     }
     if (active) {
@@ -267,11 +298,13 @@ int launch_linear_attention(LinAttnArgs& a, hipStream_t s) {
 
 int launch_attention(AttnArgs& a, hipStream_t s) {
     DMN_REQUIRE(a.d == kD, DMN_ERR_INVALID, "attention: dim_head=%d (only 32)", a.d);
-    dim3 grid(a.heads, a.B, (a.n + 255) / 256);
+    const int parts = a.n <= 64 ? 4 : a.n <= 128 ? 2 : 1;
+    const int qpw = 256 / parts;
+    dim3 grid(a.heads, a.B, (a.n + qpw - 1) / qpw);
     if (a.dtype == DMN_F32)
-        hipLaunchKernelGGL(attention_kernel<float>, grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL(attention_kernel<float>, grid, dim3(256), 0, s, a, parts);
     else
-        hipLaunchKernelGGL(attention_kernel<__bf16>, grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL(attention_kernel<__bf16>, grid, dim3(256), 0, s, a, parts);
     DMN_HIP_CHECK(hipGetLastError());
     return DMN_OK;
 }
