@@ -38,7 +38,8 @@ extern "C" int dmn_ddpm_step(const float* table, int row, const float* x, const 
     DdpmStepArgs a;
     a.c = step_common(table, nullptr, row, x, model_out, noise, x_out, B, C, H * W, seed, img_offset, nullptr);
     a.learned_variance = learned_variance;
-    a.pred_x0 = pred_x0;
+    a.pred_x0 = pred_x0 & 1;
+    a.ddim = (pred_x0 >> 1) & 1;
     return launch_ddpm_step(a, (hipStream_t)stream);
 }
 
@@ -181,6 +182,7 @@ extern "C" int dmn_ddpm_sample_loop(DmnUnet* u, const float* table, int nsteps, 
                                     int learned_variance, int pred_x0, int draw_prior, uint64_t seed, int64_t img_offset,
                                     float* keep, void* workspace, size_t workspace_bytes, void* stream, int use_graph) {
     DMN_REQUIRE(u && table && x && workspace && nsteps > 0, DMN_ERR_INVALID, "dmn_ddpm_sample_loop: bad argument");
+    DMN_REQUIRE(!((pred_x0 & 2) && learned_variance), DMN_ERR_INVALID, "the DDIM update has no learned-variance form");
     DMN_REQUIRE(u->cfg.out_dim == u->cfg.channels * (learned_variance ? 2 : 1), DMN_ERR_INVALID,
                 "network emits %d channels, sampler expects %d", u->cfg.out_dim, u->cfg.channels * (learned_variance ? 2 : 1));
     hipStream_t s = (hipStream_t)stream;
@@ -197,7 +199,8 @@ extern "C" int dmn_ddpm_sample_loop(DmnUnet* u, const float* table, int nsteps, 
         DdpmStepArgs a;
         a.c = step_common(table, lb.step_idx, 0, x, lb.net, nullptr, x, B, C, H * W, seed, img_offset, keep);
         a.learned_variance = learned_variance;
-        a.pred_x0 = pred_x0;
+        a.pred_x0 = pred_x0 & 1;
+        a.ddim = (pred_x0 >> 1) & 1;
         if ((r = launch_ddpm_step(a, s))) return r;
         return launch_advance(lb.step_idx, s);
     };

@@ -6,6 +6,7 @@
 //   col 0  network time label (DDPM: t; VE: sigma(t); VP: 999 t)
 //   DDPM rows:  1 sqrt(1/acp)  2 sqrt(1/acp - 1)  3 posterior_mean_coef1  4 posterior_mean_coef2
 //               5 posterior_log_variance_clipped  6 log(beta)  7 nonzero mask (t != 0)
+//   DDIM rows:  1 sqrt(1 - a_t)  2 sqrt(a_t)  3 sqrt(a_next)  4 c1 (noise)  5 c2 (direction)
 //   SDE rows:   1 a  2 b  3 c  (x_mean = a x + b net, x = x_mean + c z)
 //               4 score scale (score = scale * net)  5 alpha (Langevin)  6 fixed corrector step (ALD)
 //   col 8  step id used to key the noise generator
@@ -29,6 +30,7 @@ struct DdpmStepArgs {
     StepCommon c;
     int learned_variance; // net has 2C channels: eps | v
     int pred_x0;          // objective == 'pred_x0'
+    int ddim;             // generalized (DDIM) update with the DDIM row layout
 };
 struct AffineStepArgs {
     StepCommon c;

@@ -46,6 +46,17 @@ __global__ void __launch_bounds__(256) ddpm_step_kernel(const DdpmStepArgs a) {
         const size_t mi = (size_t)b * mo_c * c.HW + e;
         const float x = c.x[xi];
         const float eps = c.net[mi];
+        if (a.ddim) {
+            // generalized_gaussian_diffusion.py:43-46,84-97; row: 1 sqrt(1-at) 2 sqrt(at) 3 sqrt(at_next) 4 c1 5 c2.
+            // With the pred_x0 objective the reference clamps the network output in place, so the direction term
+            // uses the clamped value too.
+            float x0 = a.pred_x0 ? eps : (x - eps * tr[1]) / tr[2];
+            x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+            const float xn = tr[3] * x0 + tr[4] * z[r] + tr[5] * (a.pred_x0 ? x0 : eps);
+            c.x_out[xi] = xn;
+            if (c.keep) c.keep[(size_t)row * c.keep_stride + xi] = xn;
+            continue;
+        }
         float x0 = a.pred_x0 ? eps : sra * x - srm1 * eps;
         x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
         const float mean = c1 * x0 + c2 * x;

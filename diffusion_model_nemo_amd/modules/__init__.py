@@ -3,6 +3,7 @@ from .diffusion_process import (AbstractDiffusionProcess, CosineSchedule, Linear
                                 SigmoidSchedule, cosine_beta_schedule, linear_beta_schedule, quadratic_beta_schedule,
                                 sigmoid_beta_schedule)
 from .gaussian_diffusion import GaussianDiffusion
+from .generalized_gaussian_diffusion import GeneralizedGaussianDiffusion
 from .learned_gaussian_diffusion import LearnedGaussianDiffusion
 from .sde_lib import SDE, VESDE, VPSDE, subVPSDE
 from .sde_samplers import PredictorCorrectorSampler, get_corrector, get_predictor
@@ -11,6 +12,6 @@ from .unet import Unet
 __all__ = [
     "AbstractDiffusionProcess", "CosineSchedule", "LinearSchedule", "QuadraticSchedule", "SigmoidSchedule",
     "cosine_beta_schedule", "linear_beta_schedule", "quadratic_beta_schedule", "sigmoid_beta_schedule",
-    "GaussianDiffusion", "LearnedGaussianDiffusion", "SDE", "VESDE", "VPSDE", "subVPSDE",
+    "GaussianDiffusion", "GeneralizedGaussianDiffusion", "LearnedGaussianDiffusion", "SDE", "VESDE", "VPSDE", "subVPSDE",
     "PredictorCorrectorSampler", "get_predictor", "get_corrector", "Unet",
 ]

@@ -24,6 +24,11 @@ def _fresh_seed() -> int:
 
 class GaussianDiffusion(AbstractDiffusionProcess):
     learned_variance = False
+    _step_flags = 0   # bits above bit 0 of the library's `pred_x0` argument (bit 1: generalized / DDIM update)
+
+    def step_labels(self):
+        """Timestep handed to the network in each row of the step table."""
+        return list(range(self.timesteps - 1, -1, -1))
 
     def __init__(self, timesteps: int, schedule_name: str, schedule_cfg: Optional[dict] = None,
                  objective: str = "pred_noise", class_conditional: bool = False):
@@ -163,7 +168,7 @@ class GaussianDiffusion(AbstractDiffusionProcess):
         tptr = table.data_ptr() + first_row * N.TABLE_COLS * 4
         hist = torch.empty((nsteps, B, Cc, H, W), dtype=torch.float32, device=dev) if keep == "all" else None
         lv = 1 if self.learned_variance else 0
-        pred_x0 = 0 if self.objective == 'pred_noise' else 1
+        pred_x0 = (0 if self.objective == 'pred_noise' else 1) | self._step_flags
         if isinstance(model, Unet):
             ws = model.workspace(B, H, W, dev, sampling=True)
             handle = model.native_handle()
@@ -181,9 +186,10 @@ class GaussianDiffusion(AbstractDiffusionProcess):
             stream = N.current_stream_handle(dev)
             if draw_prior:
                 N.check(N.lib().dmn_fill_normal(x.data_ptr(), B, Cc * H * W, seed, nsteps, image_offset, 1.0, stream))
+            labels = self.step_labels()
             for s in range(nsteps):
                 row = first_row + s
-                tval = self.timesteps - 1 - row
+                tval = labels[row]
                 net = model(x, torch.full((B,), tval, device=dev, dtype=torch.long)).contiguous().float()
                 N.check(N.lib().dmn_ddpm_step(table.data_ptr(), row, x.data_ptr(), net.data_ptr(), None, x.data_ptr(),
                                               B, Cc, H, W, lv, pred_x0, seed, image_offset, stream))

@@ -71,7 +71,9 @@ int dmn_unet_forward(DmnUnet* u, const float* x, const void* t, int t_is_float, 
  * (device [B][C][H][W]) to inject a draw instead (single-step entry points only). */
 
 /* One ancestral step: GaussianDiffusion.p_sample given the network output (gaussian_diffusion.py:157-167,
- * 125-154,118-123,91-101) or LearnedGaussianDiffusion.p_mean_variance (learned_gaussian_diffusion.py:35-48). */
+ * 125-154,118-123,91-101) or LearnedGaussianDiffusion.p_mean_variance (learned_gaussian_diffusion.py:35-48).
+ * pred_x0: bit 0 = objective 'pred_x0'; bit 1 = generalized (DDIM) update of GeneralizedGaussianDiffusion.p_sample
+ * (generalized_gaussian_diffusion.py:78-97) on a table with the DDIM row layout. Same meaning in the loop below. */
 int dmn_ddpm_step(const float* table, int row, const float* x, const float* model_out, const float* noise, float* x_out,
                   int B, int C, int H, int W, int learned_variance, int pred_x0, uint64_t seed, int64_t img_offset,
                   void* stream);

@@ -262,6 +262,51 @@ def ddpm_sample_chain(model_fn: Callable[[Tensor, Tensor], Tensor], c, shape, no
     return out
 
 
+def ddim_sequence(timesteps: int, ddim_timesteps: int):
+    """(t, t_next) pairs in execution order (generalized_gaussian_diffusion.py:111-113,121-123)."""
+    n = ddim_timesteps if ddim_timesteps > 0 else timesteps
+    stride = timesteps // n
+    seq = list(range(0, timesteps, stride))
+    nxt = [-1] + seq[:-1]
+    return list(zip(reversed(seq), reversed(nxt)))
+
+
+def ddim_step_coefs(betas: Tensor, t: int, t_next: int, eta: float) -> Dict[str, Tensor]:
+    """Scalars of one DDIM step in the reference's fp32 operation order
+    (generalized_gaussian_diffusion.py:43-46,84-94,105-108)."""
+    acp_ext = torch.cumprod(1.0 - torch.cat([torch.zeros(1), betas]), dim=0)
+    at, at_next = acp_ext[t + 1], acp_ext[t_next + 1]
+    c1 = eta * torch.sqrt((1.0 - at / at_next) * (1.0 - at_next) / (1.0 - at))
+    c2 = torch.sqrt((1.0 - at_next) - c1 ** 2)
+    return {"sqrt_one_minus_at": (1.0 - at).sqrt(), "sqrt_at": at.sqrt(), "sqrt_at_next": at_next.sqrt(), "c1": c1, "c2": c2}
+
+
+def ddim_sample_update(k: Dict[str, Tensor], x: Tensor, model_output: Tensor, noise: Tensor,
+                       objective: str = "pred_noise") -> Tensor:
+    """generalized_gaussian_diffusion.py:48-97. With objective 'pred_x0' the reference clamps the network output
+    in place, so the 'direction' term also uses the clamped tensor."""
+    if objective == "pred_noise":
+        x0 = ((x - model_output * k["sqrt_one_minus_at"]) / k["sqrt_at"]).clamp(-1.0, 1.0)
+    else:
+        x0 = model_output = model_output.clamp(-1.0, 1.0)
+    return k["sqrt_at_next"] * x0 + k["c1"] * noise + k["c2"] * model_output
+
+
+def ddim_sample_chain(model_fn: Callable[[Tensor, Tensor], Tensor], betas: Tensor, shape, noise_fn, eta: float = 0.0,
+                      ddim_timesteps: int = -1, objective: str = "pred_noise"):
+    """generalized_gaussian_diffusion.py:100-137 with injected noise: ``noise_fn(T)`` is the x_T draw and
+    ``noise_fn(t)`` the draw of the step at timestep t (drawn even when eta == 0). Returns the list of x after
+    every step, in model range."""
+    T = int(betas.shape[0])
+    x = noise_fn(T)
+    out = []
+    for t, t_next in ddim_sequence(T, ddim_timesteps):
+        tt = torch.full((shape[0],), t, dtype=torch.long)
+        x = ddim_sample_update(ddim_step_coefs(betas, t, t_next, eta), x, model_fn(x, tt), noise_fn(t), objective)
+        out.append(x.clone())
+    return out
+
+
 # ----------------------------------------------------------------------------------------------
 # Score-SDE (diffusion_model_nemo/modules/sde_lib/*.py, sde_predictors/*.py, sde_correctors/*.py,
 # sde_samplers/predictor_corrector_sampler.py, loss/sde_loss/score_function_loss.py:48-91)

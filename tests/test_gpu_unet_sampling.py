@@ -141,6 +141,33 @@ def test_improved_ddpm_chain_matches_reference_golden():
         assert mx <= 1e-4, (i, mx)
 
 
+@pytest.mark.parametrize("tag", ["eta0_s20", "eta05_s20", "x0_s10"])
+def test_ddim_chains_match_reference_golden(tag):
+    """GeneralizedGaussianDiffusion.p_sample_loop (generalized_gaussian_diffusion.py:100-137): every x_t of the chain."""
+    from diffusion_model_nemo_amd.modules import GeneralizedGaussianDiffusion
+    g = load_golden("chain_ddim_T1000_B2_32")
+    steps, eta, x0 = g[f"{tag}_meta"]
+    u = build_unet("fp32")
+    gd = GeneralizedGaussianDiffusion(timesteps=1000, schedule_name="cosine", objective="pred_x0" if x0 else "pred_noise",
+                                      eta=float(eta), ddim_timesteps=int(steps))
+    imgs = gd.p_sample_loop(u, (2, 3, 32, 32), device="cuda", seed=3)
+    want = g[f"{tag}_xs"]
+    assert len(imgs) == want.shape[0] == int(steps)
+    for i in range(int(steps)):
+        mx, _ = err(imgs[i] * 2 - 1, want[i])
+        assert mx <= 1e-4, (tag, i, mx)
+    # graph replay == eager launches, and a single generalized step through the step entry point
+    x_eager = gd.p_sample_loop(u, (2, 3, 32, 32), device="cuda", seed=3, use_graph=False, return_device_tensor=True)
+    assert torch.equal(((x_eager + 1) * 0.5).cpu(), imgs[-1])
+    t, t_next = gd.sequence()[0]
+    xT = T(g["x_T"]).cuda()
+    z = T(philox.normal_like((2, 3, 32, 32), 3, t, 1)).cuda()
+    x1, _ = gd.p_sample(u, xT, torch.full((2,), t, device="cuda"), torch.full((2,), t_next, device="cuda"), noise=z)
+    assert err(x1, want[0])[0] <= 1e-4
+    with pytest.raises(ValueError):
+        GeneralizedGaussianDiffusion(timesteps=10, schedule_name="linear", eta=1.5)
+
+
 def test_sampling_is_shard_invariant_and_graph_equals_eager():
     from diffusion_model_nemo_amd.modules import GaussianDiffusion
     u = build_unet("fp32")

@@ -263,3 +263,24 @@ def test_philox_known_answer_and_shard_invariance():
     np.testing.assert_array_equal(full[2:], part)
     big = philox.normal_like((64, 3, 32, 32), seed=9, step=1, stream=1)
     assert abs(float(big.mean())) < 0.01 and abs(float(big.std()) - 1.0) < 0.01
+
+
+def test_ddim_chains_match_reference(golden):
+    """GeneralizedGaussianDiffusion.p_sample_loop (generalized_gaussian_diffusion.py:100-137), three variants."""
+    g = golden("chain_ddim_T1000_B2_32")
+    p = R.to_torch(make_state_dict(unet_param_shapes()))
+    betas = R.beta_schedule("cosine", 1000)
+    shape = (2, 3, 32, 32)
+
+    def noise_fn(step):
+        return torch.from_numpy(philox.normal_like(shape, 3, step, 0 if step == 1000 else 1))
+
+    for tag in ("eta0_s20", "eta05_s20", "x0_s10"):
+        steps, eta, x0 = g[f"{tag}_meta"]
+        with torch.no_grad():
+            xs = R.ddim_sample_chain(lambda x, t: R.unet_forward(p, x, t), betas, shape, noise_fn, eta=float(eta),
+                                     ddim_timesteps=int(steps), objective="pred_x0" if x0 else "pred_noise")
+        want = torch.from_numpy(g[f"{tag}_xs"])
+        assert len(xs) == want.shape[0]
+        err = max(float((a - b).abs().max()) for a, b in zip(xs, want))
+        assert err <= 2e-5, (tag, err)

@@ -399,6 +399,29 @@ def gen_train(M, out):
     npz(out, "train_step", **arrays)
 
 
+def gen_ddim(M, out, seed=3):
+    """GeneralizedGaussianDiffusion (DDIM) chains, B=2 @ 32x32, T=1000 cosine: 20 strided steps with eta=0 and
+    eta=0.5, plus a pred_x0-objective chain of 10 steps; every x_t kept (model range)."""
+    B, T = 2, 1000
+    shape = (B, 3, 32, 32)
+    u = build_unet(M)
+    arrays = {}
+    for tag, steps, eta, objective in (("eta0_s20", 20, 0.0, "pred_noise"), ("eta05_s20", 20, 0.5, "pred_noise"),
+                                       ("x0_s10", 10, 0.3, "pred_x0")):
+        g = M.GeneralizedGaussianDiffusion(timesteps=T, schedule_name="cosine", objective=objective, eta=eta,
+                                           ddim_timesteps=steps)
+        stride = T // steps
+        seq = list(range(0, T, stride))
+        # the reference draws x_T, then one randn_like per step (also when eta == 0), keyed here by the timestep
+        plan = [(T, 0)] + [(i, 1) for i in reversed(seq)]
+        with NoiseInjector(plan, seed=seed), torch.no_grad():
+            imgs = g.p_sample_loop(u, shape, use_tqdm=False, device=torch.device("cpu"))
+        arrays[f"{tag}_xs"] = torch.stack(imgs) * 2.0 - 1.0
+        arrays[f"{tag}_meta"] = np.array([steps, eta, 1.0 if objective == "pred_x0" else 0.0], dtype=np.float64)
+    arrays["x_T"] = philox.normal_like(shape, seed, T, 0)
+    npz(out, "chain_ddim_T1000_B2_32", **arrays)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -411,7 +434,7 @@ def main():
     torch.set_num_threads(8)
     os.makedirs(args.out, exist_ok=True)
     jobs = dict(schedules=gen_schedules, blocks=gen_blocks, unet=gen_unet, p_sample=gen_psample,
-                sde=gen_sde, train=gen_train, chain=gen_chain)
+                sde=gen_sde, train=gen_train, chain=gen_chain, ddim=gen_ddim)
     for name, fn in jobs.items():
         if args.only and name not in args.only:
             continue
