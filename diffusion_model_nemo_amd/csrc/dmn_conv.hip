@@ -413,7 +413,7 @@ TileCfg pick_cfg(const ConvArgs& a) {
     auto blocks = [&](const TileCfg& t) {
         return (long long)((a.Ho + t.th - 1) / t.th) * ((a.Wo + t.tw - 1) / t.tw) * (a.Cout / t.bn) * a.B * a.nphase;
     };
-    const bool big = a.kind != DMN_K4X4S2 && a.Ho >= 16 && a.Wo >= 16;
+    const bool big = a.kind != DMN_K4X4S2 && a.Ho >= 32 && a.Wo >= 32;   // 16x16 images: four 8x8 tiles beat one big tile split over channels
     c.th = c.tw = big ? 16 : 8;
     c.bn = (a.Cout % 64 == 0 && a.kind != DMN_K4X4S2) ? 64 : 32;
     // prefer at least one workgroup per CU (256), two when a smaller channel tile gets there

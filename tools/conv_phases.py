@@ -65,6 +65,19 @@ def run(name, B, H, W, cin, cout, k, stride, pad, transposed, pro, epi_G, dtype=
 
 if __name__ == "__main__":
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    if len(sys.argv) > 2 and sys.argv[2] == "cfg":
+        for tile, bn in ((0, 0), (16, 32), (16, 64), (8, 32), (8, 64)):
+            print(f"--- tile {tile} bn {bn}")
+            run("L1 3x3 64->64 32x32 pro+stats", B, 32, 32, 64, 64, 3, 1, 1, False, True, 8, tile=tile, bn=bn)
+            run("L1 3x3 128->64 32x32 concat", B, 32, 32, 128, 64, 3, 1, 1, False, False, 8, c1=64, tile=tile, bn=bn)
+            run("L2 3x3 128->128 16x16 pro+stats", B, 16, 16, 128, 128, 3, 1, 1, False, True, 8, tile=tile, bn=bn)
+            run("L2 3x3 256->128 16x16 concat", B, 16, 16, 256, 128, 3, 1, 1, False, False, 8, c1=128, tile=tile, bn=bn)
+            run("L3 3x3 256->256 8x8 pro+stats", B, 8, 8, 256, 256, 3, 1, 1, False, True, 8, tile=tile, bn=bn)
+            if tile != 16:
+                run("L1 4x4s2 64->64 32x32", B, 32, 32, 64, 64, 4, 2, 1, False, False, 0, tile=tile, bn=bn)
+            run("L1 convT 64->64 32x32", B, 32, 32, 64, 64, 4, 2, 1, True, False, 0, tile=tile, bn=bn)
+            run("L2 convT 128->128 16x16", B, 16, 16, 128, 128, 4, 2, 1, True, False, 0, tile=tile, bn=bn)
+        sys.exit(0)
     run("L0 3x3 32->32 64x64 pro+stats", B, 64, 64, 32, 32, 3, 1, 1, False, True, 8)
     run("L0 3x3 32->32 64x64 plain", B, 64, 64, 32, 32, 3, 1, 1, False, False, 0)
     run("L0 3x3 64->32 64x64 concat", B, 64, 64, 64, 32, 3, 1, 1, False, False, 8, c1=32)
