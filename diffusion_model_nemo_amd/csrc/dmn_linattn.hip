@@ -177,6 +177,7 @@ __global__ void __launch_bounds__(256) la_fused_ctx_kernel(const LinAttnFusedArg
 
     // ---- sweep 1: per-channel maximum of k over the slice ------------------------------------------------
     float mx[2] = {-INFINITY, -INFINITY};
+#pragma unroll 2
     for (int pp = 0; pp < npt; pp += 2) {
         f32x4 kacc[2][2];
 #pragma unroll
@@ -218,6 +219,7 @@ __global__ void __launch_bounds__(256) la_fused_ctx_kernel(const LinAttnFusedArg
 #pragma unroll
         for (int j = 0; j < 2; ++j) ctx[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     float zs[2] = {0.f, 0.f};
+#pragma unroll 2
     for (int pp = 0; pp < npt; pp += 2) {        // 32 pixels = one bf16 k-step (two f32 k-steps)
         f32x4 kacc[2][2], vacc[2][2];             // [pixel tile of the pair][channel tile]
 #pragma unroll

@@ -21,19 +21,29 @@ __device__ __forceinline__ void norm_coefs_to_lds(const NormIn& n, int b, int C,
             if (n.tbias) pt[i] = n.tbias[(size_t)b * n.tb_stride + c];
         }
     }
-    // one wave per group: lanes stride over the slots, then a fixed-order butterfly (deterministic)
+    // Statistics: a wave reduces 64 / seg groups at once, seg lanes per group (seg = 16, 32 or 64 >= slots when
+    // possible), so the slot loads of all its groups are in flight together. Lanes stride over the slots, then a
+    // fixed-order butterfly inside the segment: deterministic.
     const int wave = tid >> 6, lane = tid & 63, nwaves = nthr >> 6;
-    for (int g = wave; g < n.G; g += nwaves) {
-        const float* p = n.stats + ((size_t)(b * n.G + g) * n.slots) * 2;
+    const int seg = n.slots <= 16 ? 16 : n.slots <= 32 ? 32 : 64;
+    const int gpw = 64 / seg;
+    const int sl = lane & (seg - 1);
+    for (int g0 = wave * gpw; g0 < n.G; g0 += nwaves * gpw) {
+        const int g = g0 + lane / seg;
         float s = 0.f, ss = 0.f;
-        for (int i = lane; i < n.slots; i += 64) {
-            const float2 v = *reinterpret_cast<const float2*>(p + 2 * i);
-            s += v.x;
-            ss += v.y;
+        if (g < n.G) {
+            const float* p = n.stats + ((size_t)(b * n.G + g) * n.slots) * 2;
+            for (int i = sl; i < n.slots; i += seg) {
+                const float2 v = *reinterpret_cast<const float2*>(p + 2 * i);
+                s += v.x;
+                ss += v.y;
+            }
         }
-        s = wave_sum(s);
-        ss = wave_sum(ss);
-        if (lane == 0) {
+        for (int o = seg >> 1; o > 0; o >>= 1) {
+            s += __shfl_xor(s, o, 64);
+            ss += __shfl_xor(ss, o, 64);
+        }
+        if (sl == 0 && g < n.G) {
             const float mean = s * n.inv_count;
             float var = ss * n.inv_count - mean * mean;
             var = var > 0.f ? var : 0.f;
