@@ -40,7 +40,10 @@ template <> struct KindTraits<DMN_K1X1> { static constexpr int NTAPS = 1, EXT = 
 template <> struct KindTraits<DMN_K4X4S2> { static constexpr int NTAPS = 16, EXT = 4, S = 2, KW = 4, GK = 1; };
 template <> struct KindTraits<DMN_KT2X2> { static constexpr int NTAPS = 4, EXT = 2, S = 1, KW = 2, GK = 2; };
 
-// PRO: 0 = input used as is, 1 = GroupNorm affine, 2 = GroupNorm affine + SiLU (+ time bias) while staging.
+// PRO: 0 = input used as is, 1 = GroupNorm affine, 2 = GroupNorm affine + SiLU (+ time bias) while staging,
+//      3 = the tail of the previous ResnetBlock, SiLU(GroupNorm(in0)) + pro_res (parts/convnext.py:85-86), applied
+//          while staging; the pixels of the tile proper are also written to pro_out, so the block output exists
+//          in memory for its other consumer (the next block's residual) without a launch of its own.
 // RES: also apply a 1x1 convolution (w2, bias2 -> out2) to the same input tile -- the ResnetBlock shortcut
 // res_conv(x) beside block1.proj(x) (parts/convnext.py:76,79,86) -- sharing the staged tile; 3x3 kind only.
 template <typename T, int KIND, int TH, int TW, int BN, int WM, int WN, int PRO, bool RES>
@@ -144,6 +147,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
     const int part = tid & ((1 << lgu) - 1);
     const int nunits = ((NPIX << lgu) + 255) >> 8;
     V sr[SB];
+    V sr2[PRO == 3 ? SB : 1];                       // residual operand of the fused block tail
     unsigned smask = 0;                             // bit j: unit j of the batch lies inside the image
     auto stage_issue = [&](int cg0, int j0) {
         const int c = cg0 + part * PER;
@@ -161,6 +165,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
             // slots outside the image read pixel 0 (always mapped) and are zeroed when written: no branch here
             const unsigned off = in ? (unsigned)((b * a.H + gy) * a.W + gx) * (unsigned)Csrc + (unsigned)cs : (unsigned)cs;
             sr[j] = *reinterpret_cast<const V*>(src + off);
+            if constexpr (PRO == 3) sr2[j] = *reinterpret_cast<const V*>(static_cast<const T*>(a.pro_res) + off);
         }
     };
     stage_issue(0, 0);
@@ -196,18 +201,28 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
                 for (int j = 0; j < SB; ++j) {
                     const int pix = (tid + 256 * (j0 + j)) >> lgu;
                     const bool in = (smask >> j) & 1u;
-                    Vec16<T> v;
+                    Vec16<T> v, r2;
                     v.v = sr[j];
+                    if constexpr (PRO == 3) r2.v = sr2[j];
 #pragma unroll
                     for (int e = 0; e < PER; ++e) {
                         float y = v.get(e);
                         if (PRO) {
                             y = y * ca[e] + cb[e];
                             if (PRO == 2) y = ((sizeof(T) == 4) ? silu_precise(y) : silu_f(y)) + ct[e];
+                            if constexpr (PRO == 3) y = ((sizeof(T) == 4) ? silu_precise(y) : silu_f(y)) + r2.get(e);
                         }
                         v.set(e, in ? y : 0.f);
                     }
                     if (pix < NPIX) *reinterpret_cast<V*>(sX + pix * rowB + part * 16) = v.v;
+                    if constexpr (PRO == 3) {
+                        // the tile's own pixels (not the halo) of the first channel slice materialise the block output
+                        const int ly = pix / IW, lx = pix - ly * IW;
+                        if (in && blockIdx.y == 0 && ly >= P.pad_y && ly < P.pad_y + TH && lx >= P.pad_x && lx < P.pad_x + TW) {
+                            const unsigned off = (unsigned)((b * a.H + iy0 + ly) * a.W + ix0 + lx) * (unsigned)a.C0 + (unsigned)c;
+                            *reinterpret_cast<V*>(static_cast<T*>(a.pro_out) + off) = v.v;
+                        }
+                    }
                 }
                 if (j0 + SB < nunits) stage_issue(cg0, j0 + SB);
             }
@@ -476,7 +491,14 @@ int dispatch_fused_shortcut(const ConvArgs& a, const TileCfg& c, size_t lds, hip
 
 template <typename T>
 int dispatch(const ConvArgs& a, const TileCfg& c, size_t lds, hipStream_t s) {
-    const int pro = a.pro.stats ? (a.pro.silu ? 2 : 1) : 0;
+    const int pro = a.pro.stats ? (a.pro_res ? 3 : a.pro.silu ? 2 : 1) : 0;
+    if (pro == 3) {
+        if (a.kind != DMN_K3X3 || a.w2 || a.C1 || !a.pro_out || !a.pro.silu || a.pro.tbias) {
+            dmn_set_error("conv: the fused block tail needs a plain single-source 3x3 convolution");
+            return DMN_ERR_INVALID;
+        }
+        return dispatch_tile<T, DMN_K3X3, 3>(a, c, lds, s);
+    }
     if (a.w2) {
         if (a.kind != DMN_K3X3 || pro != 0) {
             dmn_set_error("conv: the fused 1x1 shortcut needs a plain 3x3 convolution");
@@ -533,6 +555,7 @@ int set_attr_all() {
     if ((rc = set_attr_kind<T, DMN_K3X3, 0>())) return rc;
     if ((rc = set_attr_kind<T, DMN_K3X3, 1>())) return rc;
     if ((rc = set_attr_kind<T, DMN_K3X3, 2>())) return rc;
+    if ((rc = set_attr_kind<T, DMN_K3X3, 3>())) return rc;
     if ((rc = set_attr_kind<T, DMN_K1X1, 0>())) return rc;
     if ((rc = set_attr_kind<T, DMN_K1X1, 1>())) return rc;
     if ((rc = set_attr_kind<T, DMN_K1X1, 2>())) return rc;

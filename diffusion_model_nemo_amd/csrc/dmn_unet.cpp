@@ -294,17 +294,63 @@ static Act do_conv(Fwd& f, const PackedConv& pc, const Act& in0, const Act* in1,
     return out;
 }
 
+// A ResnetBlock whose closing `SiLU(GroupNorm(h2)) + res` has not been applied yet: the next block's first
+// convolution applies it while staging its input and writes the result to `out` on the way.
+struct LazyTail {
+    bool active = false;
+    Act h2, r, out;           // block2.proj output with statistics; shortcut tensor (when has_r); target of the tail
+    bool has_r = false;
+    const void* res = nullptr;   // residual operand: r.p or the block input
+    const float *g2 = nullptr, *b2 = nullptr;
+};
+
 // ResnetBlock (parts/convnext.py:78-86). statsG > 0: also produce GroupNorm(statsG) statistics of the output.
-static Act resblock(Fwd& f, const ResBlockW& w, Act& x, Act* x2, const float* tb, int tb_stride, int statsG) {
+// `pending`: the producer of x left its tail to this block's first convolution (x.p is allocated, not written).
+// `defer`: leave this block's tail to the consumer (returned Act is allocated, not written; no statistics).
+static Act resblock(Fwd& f, const ResBlockW& w, Act& x, Act* x2, const float* tb, int tb_stride, int statsG,
+                    LazyTail* pending = nullptr, LazyTail* defer = nullptr) {
     const int G = f.u->cfg.groups;
     Act r;
     const Act* resp = &x;
     if (w.has_res) resp = &r;   // res_conv(x) comes out of block1's launch (same input tile)
-    Act h1 = do_conv(f, w.c1, x, x2, nullptr, nullptr, G, w.has_res ? &w.res : nullptr, w.has_res ? &r : nullptr);
+    Act h1;
+    if (pending && pending->active) {
+        // conv1 reads SiLU(GN(h2_prev)) + res_prev and materialises it into x.p
+        ConvArgs a;
+        conv_args_from(w.c1, f.u->cfg.dtype, a, f.B, x.H, x.W);
+        a.in0 = pending->h2.p;
+        a.C0 = x.C;
+        a.pro = norm_in(pending->h2, pending->g2, pending->b2, f.B, 1, nullptr, 0);
+        a.pro_res = pending->res;
+        a.pro_out = x.p;
+        h1 = f.new_act(w.c1.Cout, a.out_H, a.out_W);
+        a.out = h1.p;
+        a.epi.G = G;
+        h1.sG = G;
+        h1.sSlots = conv_epi_slots(a);
+        h1.stats = f.new_stats(G, h1.sSlots);
+        a.epi.stats = h1.stats;
+        if (f.ok() && !f.dry) f.run(launch_conv(a, f.s));
+        f.free_act(pending->h2);
+        if (pending->has_r) f.free_act(pending->r);
+        pending->active = false;
+    } else {
+        h1 = do_conv(f, w.c1, x, x2, nullptr, nullptr, G, w.has_res ? &w.res : nullptr, w.has_res ? &r : nullptr);
+    }
     NormIn n1 = norm_in(h1, w.g1, w.b1, f.B, 1, w.tb_off >= 0 ? tb + w.tb_off : nullptr, tb_stride);
     Act h2 = do_conv(f, w.c2, h1, nullptr, &n1, nullptr, G);
     f.free_act(h1);
     Act out = f.new_act(h2.C, h2.H, h2.W);
+    if (defer) {
+        defer->active = true;
+        defer->h2 = h2;
+        defer->has_r = w.has_res;
+        defer->r = r;
+        defer->res = resp->p;
+        defer->g2 = w.g2;
+        defer->b2 = w.b2;
+        return out;
+    }
     NormApplyArgs na;
     memset(&na, 0, sizeof(na));
     na.dtype = f.u->cfg.dtype;
@@ -483,9 +529,12 @@ int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float,
 
     std::vector<Act> skips;
     for (int i = 0; i < nlev; ++i) {
-        Act a1 = resblock(f, u->downs[i].rb[0], cur, nullptr, tb, tbs, 0);
-        f.free_act(cur);
-        Act a2 = resblock(f, u->downs[i].rb[1], a1, nullptr, tb, tbs, 1);
+        // the first block's tail is applied by the second block's first convolution (which also stores it)
+        LazyTail lt;
+        const bool lazy = u->downs[i].rb[1].c1.kind == DMN_K3X3 && !u->downs[i].rb[1].has_res;
+        Act a1 = resblock(f, u->downs[i].rb[0], cur, nullptr, tb, tbs, 0, nullptr, lazy ? &lt : nullptr);
+        Act a2 = resblock(f, u->downs[i].rb[1], a1, nullptr, tb, tbs, 1, &lt, nullptr);
+        f.free_act(cur);   // the block input stays alive as the deferred tail's residual
         f.free_act(a1);
         Act a3 = lin_attn(f, u->downs[i].attn, a2);
         f.free_act(a2);
@@ -508,10 +557,12 @@ int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float,
     for (int i = 0; i < nlev - 1; ++i) {
         Act sk = skips.back();
         skips.pop_back();
-        Act a1 = resblock(f, u->ups[i].rb[0], cur, &sk, tb, tbs, 0);
+        LazyTail lt;
+        const bool lazy = u->ups[i].rb[1].c1.kind == DMN_K3X3 && !u->ups[i].rb[1].has_res;
+        Act a1 = resblock(f, u->ups[i].rb[0], cur, &sk, tb, tbs, 0, nullptr, lazy ? &lt : nullptr);
         f.free_act(cur);
         f.free_act(sk);
-        Act a2 = resblock(f, u->ups[i].rb[1], a1, nullptr, tb, tbs, 1);
+        Act a2 = resblock(f, u->ups[i].rb[1], a1, nullptr, tb, tbs, 1, &lt, nullptr);
         f.free_act(a1);
         Act a3 = lin_attn(f, u->ups[i].attn, a2);
         f.free_act(a2);
