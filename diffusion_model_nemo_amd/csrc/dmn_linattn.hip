@@ -620,7 +620,11 @@ void linattn_fused_plan(int n, int B, int C, int dtype, int* slice1, int* splits
         *splits = 1;
         s1 = 0;
     }
-    while (s1 > 32 && ((long long)((n + s1 - 1) / s1) * B < 256 || s1 * row > 72 * 1024 || s1 / 2 >= n)) s1 /= 2;
+    // halve the slice for more workgroups, but never beyond 64 splits per image (the merge holds their factors in LDS)
+    while (s1 > 32 && (s1 * row > 72 * 1024 || s1 / 2 >= n ||
+                       ((long long)((n + s1 - 1) / s1) * B < 256 && (n + s1 / 2 - 1) / (s1 / 2) <= 64)))
+        s1 /= 2;
+    while (s1 && (n + s1 - 1) / s1 > 64) s1 *= 2;
     if (s1) {
         *slice1 = s1;
         *splits = (n + s1 - 1) / s1;
