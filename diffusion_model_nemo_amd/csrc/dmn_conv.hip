@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
     constexpr int MT = BM / (16 * WM);
     constexpr int NT = BN / (16 * WN);
     static_assert(MT >= 1 && NT >= 1, "tile too small for the wave grid");
-    constexpr int XB = MT <= 4 ? 2 : 1;             // pixel-fragment buffers (double buffering when cheap)
+    constexpr int XB = 2;                          // pixel-fragment buffers (double buffering when cheap)
     constexpr int KCH = ElemTraits<T>::kChunk;
     constexpr int PER = ElemTraits<T>::kPer16B;
     constexpr int IH = (TH - 1) * S + KT::EXT, IW = (TW - 1) * S + KT::EXT;
