@@ -130,14 +130,14 @@ __global__ void __launch_bounds__(kNormThreads) norm_apply_kernel(const NormAppl
 // The label is either read from `t` (int64 or float32) or from a per-step schedule table indexed by a
 // device-resident step counter (so a captured graph can be replayed for every step).
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) time_mlp_kernel(const TimeArgs a) {
+__device__ __forceinline__ void time_mlp_body(const TimeArgs& a, int bx, int b) {
     // grid (chunks, rows): every workgroup recomputes the two small dense layers (20k MACs) and then produces
     // its slice of the per-block biases. Weights are stored TRANSPOSED ([in][out]) so that thread o reads
     // column o coalesced and all its loads are independent (the kernel is pure latency otherwise).
     __shared__ float sE[64];
     __shared__ float sH[512];
     __shared__ float sT[512];
-    const int b = blockIdx.y, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int dim = a.dim, hid = 4 * a.dim, half = a.dim / 2;
     float label;
     if (a.t) {
@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(256) time_mlp_kernel(const TimeArgs a) {
         sT[o] = silu_precise(acc + a.b2[o]);
     }
     __syncthreads();
-    const int o = blockIdx.x * 256 + tid;
+    const int o = bx * 256 + tid;
     if (o < a.nout) {
         float acc = 0.f;
 #pragma unroll 16
@@ -174,6 +174,8 @@ __global__ void __launch_bounds__(256) time_mlp_kernel(const TimeArgs a) {
         a.out[(size_t)b * a.nout + o] = acc + a.bb[o];
     }
 }
+
+__global__ void __launch_bounds__(256) time_mlp_kernel(const TimeArgs a) { time_mlp_body(a, blockIdx.x, blockIdx.y); }
 
 // ---------------------------------------------------------------------------------------------------
 // Ingest: init_conv 7x7 pad 3 (modules/unet.py:41,132) reading the reference's NCHW fp32 layout and
@@ -222,14 +224,13 @@ __global__ void __launch_bounds__(256) ingest_kernel(const IngestArgs a) {
 // kernel row ky the 8 pixels x 4 channels to the right of an output pixel are 64 contiguous bytes = one k-step
 // (the eighth pixel meets zero weights). 7 k-steps per output tile instead of 147 scalar taps.
 template <int COUT>
-__global__ void __launch_bounds__(256) ingest_mfma_kernel(const IngestArgs a) {
+__device__ __forceinline__ void ingest_mfma_body(const IngestArgs& a, int bx, int b) {
     constexpr int TS = 16, HALO = 3, IH = TS + 2 * HALO, RW = 24, NT = COUT / 16;
     __shared__ __attribute__((aligned(16))) __bf16 sIn[IH * RW * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
     const int tiles_x = (a.W + TS - 1) / TS;
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
-    const int b = blockIdx.y;
+    const int ty = bx / tiles_x, tx = bx % tiles_x;
     const int y0 = ty * TS - HALO, x0 = tx * TS - HALO;
     // weights first: 7 * NT fragments per wave, straight into registers
     bf16x8 wf[NT][7];
@@ -287,6 +288,22 @@ __global__ void __launch_bounds__(256) ingest_mfma_kernel(const IngestArgs a) {
                 *reinterpret_cast<bf16x4*>(dst + nt * 16 + lq * 4) = o;
             }
         }
+    }
+}
+
+template <int COUT>
+__global__ void __launch_bounds__(256) ingest_mfma_kernel(const IngestArgs a) {
+    ingest_mfma_body<COUT>(a, blockIdx.x, blockIdx.y);
+}
+
+// The time path and the ingest convolution are independent and open every network evaluation: one launch runs both
+// (blockIdx.x < ingest_blocks: an ingest tile of image blockIdx.y; beyond: a slice of the time path of row blockIdx.y).
+template <int COUT>
+__global__ void __launch_bounds__(256) ingest_time_kernel(const IngestArgs a, const TimeArgs t, int ingest_blocks) {
+    if ((int)blockIdx.x < ingest_blocks) {
+        ingest_mfma_body<COUT>(a, blockIdx.x, blockIdx.y);
+    } else if ((int)blockIdx.y < t.rows) {
+        time_mlp_body(t, blockIdx.x - ingest_blocks, blockIdx.y);
     }
 }
 
@@ -375,6 +392,20 @@ int launch_norm_apply(NormApplyArgs& a, hipStream_t s) {
 int launch_time_mlp(TimeArgs& a, hipStream_t s) {
     DMN_REQUIRE(a.dim <= 64 && a.dim % 2 == 0 && 4 * a.dim <= 512, DMN_ERR_LIMIT, "time_mlp: dim=%d exceeds 64", a.dim);
     hipLaunchKernelGGL(time_mlp_kernel, dim3((a.nout + 255) / 256, a.rows), dim3(256), 0, s, a);
+    DMN_HIP_CHECK(hipGetLastError());
+    return DMN_OK;
+}
+
+bool ingest_time_fusable(const IngestArgs& a, const TimeArgs& t) {
+    return a.dtype == DMN_BF16 && a.wfrag && (a.Cout == 32 || a.Cout == 64) && t.rows <= a.B && t.dim <= 64;
+}
+
+int launch_ingest_time(IngestArgs& a, TimeArgs& t, hipStream_t s) {
+    DMN_REQUIRE(ingest_time_fusable(a, t), DMN_ERR_INVALID, "ingest + time path: not fusable in this configuration");
+    const int ib = ((a.H + 15) / 16) * ((a.W + 15) / 16);
+    dim3 grid(ib + (t.nout + 255) / 256, a.B);
+    if (a.Cout == 32) hipLaunchKernelGGL(ingest_time_kernel<32>, grid, dim3(256), 0, s, a, t, ib);
+    else hipLaunchKernelGGL(ingest_time_kernel<64>, grid, dim3(256), 0, s, a, t, ib);
     DMN_HIP_CHECK(hipGetLastError());
     return DMN_OK;
 }

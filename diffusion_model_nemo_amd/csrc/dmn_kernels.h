@@ -110,6 +110,8 @@ struct IngestArgs {
     int B, Cin, H, W, Cout;
 };
 int launch_ingest(IngestArgs& a, hipStream_t s);
+bool ingest_time_fusable(const IngestArgs& a, const TimeArgs& t);
+int launch_ingest_time(IngestArgs& a, TimeArgs& t, hipStream_t s);   // both in one launch (bf16 networks)
 
 // tail: [GN + SiLU] -> 1x1 conv -> NCHW fp32
 struct EgressArgs {

@@ -489,12 +489,12 @@ int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float,
 
     float* tb = nullptr;
     int tb_rows = B;
+    TimeArgs ta;
+    memset(&ta, 0, sizeof(ta));
     if (c.with_time_emb) {
         // in the sampling loops every image shares the step's label: one row, broadcast with stride 0
         tb_rows = (t == nullptr && table != nullptr) ? 1 : B;
         tb = (float*)f.alloc((size_t)tb_rows * u->tb_total * 4);
-        TimeArgs ta;
-        memset(&ta, 0, sizeof(ta));
         ta.t = t;
         ta.t_is_float = t_is_float;
         ta.table = table;
@@ -509,7 +509,6 @@ int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float,
         ta.wb = u->twb; ta.bb = u->tbb;
         ta.nout = u->tb_total;
         ta.out = tb;
-        if (f.ok() && !dry) f.run(launch_time_mlp(ta, s));
     }
     const int tbs = tb_rows == 1 ? 0 : u->tb_total;
 
@@ -524,7 +523,14 @@ int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float,
         ia.bias = u->init_b;
         ia.out = cur.p;
         ia.B = B; ia.Cin = c.channels; ia.H = H; ia.W = W; ia.Cout = c.dim;
-        if (f.ok() && !dry) f.run(launch_ingest(ia, s));
+        if (f.ok() && !dry) {
+            if (c.with_time_emb && ingest_time_fusable(ia, ta)) {
+                f.run(launch_ingest_time(ia, ta, s));   // the two independent openers of the network in one launch
+            } else {
+                if (c.with_time_emb) f.run(launch_time_mlp(ta, s));
+                f.run(launch_ingest(ia, s));
+            }
+        }
     }
 
     std::vector<Act> skips;

@@ -8,7 +8,7 @@ for r in rows:
     e = d.setdefault(k, {'name': r['Kernel_Name'], 'grid': r['Grid_Size'], 't0': int(r['Start_Timestamp']), 't1': int(r['End_Timestamp'])})
     e[r['Counter_Name']] = e.get(r['Counter_Name'], 0) + float(r['Counter_Value'])
 ks = sorted(d)
-tm = [k for k in ks if 'time_mlp' in d[k]['name']]
+tm = [k for k in ks if 'time_mlp' in d[k]['name'] or 'ingest_time' in d[k]['name']]
 s, e = tm[1], tm[2]
 cols = sys.argv[2:]
 for k in ks:

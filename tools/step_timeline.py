@@ -3,7 +3,7 @@
 import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'time_mlp' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'time_mlp' in r['Kernel_Name'] or 'ingest_time' in r['Kernel_Name']]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else len(idx) // 2
 s, e = idx[k], idx[k + 1]
 t0 = int(rows[s]['Start_Timestamp'])
