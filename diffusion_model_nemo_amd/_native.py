@@ -19,7 +19,7 @@ F32, BF16 = 0, 1
 class DmnUnetCfg(C.Structure):
     _fields_ = [("dim", C.c_int), ("n_mults", C.c_int), ("dim_mults", C.c_int * DMN_MAX_MULTS), ("channels", C.c_int),
                 ("out_dim", C.c_int), ("groups", C.c_int), ("heads", C.c_int), ("dim_head", C.c_int),
-                ("tail_norm", C.c_int), ("with_time_emb", C.c_int), ("dtype", C.c_int)]
+                ("tail_norm", C.c_int), ("with_time_emb", C.c_int), ("dtype", C.c_int), ("num_classes", C.c_int)]
 
 
 class DmnTensorDesc(C.Structure):
@@ -35,6 +35,7 @@ SIGNATURES = {
     "dmn_unet_create": (_i, [C.POINTER(DmnUnetCfg), C.POINTER(_vp)]),
     "dmn_unet_destroy": (None, [_vp]),
     "dmn_unet_load_weights": (_i, [_vp, C.POINTER(DmnTensorDesc), _i]),
+    "dmn_unet_set_class_labels": (_i, [_vp, _vp]),
     "dmn_unet_workspace_bytes": (_i, [_vp, _i, _i, _i, C.POINTER(_sz)]),
     "dmn_unet_forward": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "dmn_ddpm_step": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _u64, _i64, _vp]),

@@ -192,7 +192,7 @@ extern "C" int dmn_ddpm_sample_loop(DmnUnet* u, const float* table, int nsteps, 
     const int C = u->cfg.channels;
     DMN_HIP_CHECK(hipMemsetAsync(lb.step_idx, 0, 256, s));
     if (draw_prior && (rc = launch_prior(x, B, C * H * W, seed, (unsigned)nsteps, img_offset, 1.0f, s))) return rc;
-    SampleKey key = {x, table, workspace, keep, nullptr, 1, B, H, W, learned_variance | (pred_x0 << 1), nsteps, seed, img_offset, 0.f};
+    SampleKey key = {x, table, workspace, keep, nullptr, 1, B, H, W, learned_variance | (pred_x0 << 1), nsteps, seed, img_offset, 0.f, u->labels};
     auto body = [&]() -> int {
         int r = unet_forward_impl(u, x, nullptr, 1, table, lb.step_idx, lb.net, B, H, W, lb.arena, lb.arena_bytes, s, false, nullptr);
         if (r) return r;
@@ -224,7 +224,7 @@ extern "C" int dmn_pc_sample_loop(DmnUnet* u, const float* table, int nsteps, fl
     DMN_HIP_CHECK(hipMemsetAsync(lb.step_idx, 0, 256, s));
     if (draw_prior && (rc = launch_prior(x, B, C * H * W, seed, (unsigned)nsteps, img_offset, prior_scale, s))) return rc;
     SampleKey key = {x, table, workspace, keep, xmean, 2, B, H, W,
-                     predictor | (corrector << 2) | (n_corrector_steps << 4) | (denoise << 12), nsteps, seed, img_offset, snr};
+                     predictor | (corrector << 2) | (n_corrector_steps << 4) | (denoise << 12), nsteps, seed, img_offset, snr, u->labels};
     auto body = [&]() -> int {
         int r;
         if (corrector) {

@@ -201,8 +201,9 @@ __global__ void __launch_bounds__(256) ingest_kernel(const IngestArgs a) {
     __syncthreads();
     const int py = threadIdx.x / TS, px = threadIdx.x % TS;
     float acc[COUT];
+    const float* emb = a.class_embed ? a.class_embed + (size_t)(a.labels ? a.labels[b] : a.num_classes) * COUT : nullptr;
 #pragma unroll
-    for (int o = 0; o < COUT; ++o) acc[o] = a.bias[o];
+    for (int o = 0; o < COUT; ++o) acc[o] = a.bias[o] + (emb ? emb[o] : 0.f);
     for (int c = 0; c < a.Cin; ++c)
         for (int ky = 0; ky < 7; ++ky)
 #pragma unroll
@@ -242,6 +243,11 @@ __device__ __forceinline__ void ingest_mfma_body(const IngestArgs& a, int bx, in
     f32x4 bias[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) bias[nt] = *reinterpret_cast<const f32x4*>(a.bias + nt * 16 + lq * 4);
+    if (a.class_embed) {   // class embedding row of this image, added like a second bias (unet.py:139-141)
+        const float* emb = a.class_embed + (size_t)(a.labels ? a.labels[b] : a.num_classes) * COUT;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bias[nt] += *reinterpret_cast<const f32x4*>(emb + nt * 16 + lq * 4);
+    }
     for (int i = tid; i < IH * RW; i += 256) {
         const int ly = i / RW, lx = i % RW;
         const int gy = y0 + ly, gx = x0 + lx;

@@ -108,6 +108,9 @@ struct IngestArgs {
     const float* bias;
     void* out;        // [B][H][W][Cout]
     int B, Cin, H, W, Cout;
+    const float* class_embed;   // optional [num_classes + 1][Cout]: row labels[b] is added to every pixel of image b
+    const long long* labels;    // [B] or nullptr (every image takes row num_classes)
+    int num_classes;
 };
 int launch_ingest(IngestArgs& a, hipStream_t s);
 bool ingest_time_fusable(const IngestArgs& a, const TimeArgs& t);

@@ -523,6 +523,11 @@ int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float,
         ia.bias = u->init_b;
         ia.out = cur.p;
         ia.B = B; ia.Cin = c.channels; ia.H = H; ia.W = W; ia.Cout = c.dim;
+        if (c.num_classes > 0) {
+            ia.class_embed = u->class_embed;
+            ia.labels = u->labels;
+            ia.num_classes = c.num_classes;
+        }
         if (f.ok() && !dry) {
             if (c.with_time_emb && ingest_time_fusable(ia, ta)) {
                 f.run(launch_ingest_time(ia, ta, s));   // the two independent openers of the network in one launch
@@ -859,6 +864,8 @@ static void free_weights(DmnUnet* u) {
     }
     if (u->init_wfrag) (void)hipFree(u->init_wfrag);
     u->init_wfrag = nullptr;
+    if (u->class_embed) (void)hipFree(u->class_embed);
+    u->class_embed = nullptr;
     u->loaded = false;
 }
 
@@ -866,6 +873,7 @@ extern "C" int dmn_unet_create(const DmnUnetCfg* cfg, DmnUnet** out) {
     DMN_REQUIRE(cfg && out, DMN_ERR_INVALID, "dmn_unet_create: null argument");
     DMN_REQUIRE(cfg->n_mults >= 1 && cfg->n_mults <= DMN_MAX_MULTS, DMN_ERR_INVALID, "n_mults=%d", cfg->n_mults);
     DMN_REQUIRE(cfg->dtype == DMN_F32 || cfg->dtype == DMN_BF16, DMN_ERR_INVALID, "dtype=%d", cfg->dtype);
+    DMN_REQUIRE(cfg->num_classes >= 0, DMN_ERR_INVALID, "num_classes=%d", cfg->num_classes);
     DMN_REQUIRE(cfg->dim % 32 == 0 && cfg->dim <= 64, DMN_ERR_LIMIT, "dim=%d must be 32 or 64", cfg->dim);
     DMN_REQUIRE(cfg->dim_head == 32 && cfg->heads >= 1, DMN_ERR_INVALID, "dim_head=%d (only 32 supported)", cfg->dim_head);
     DMN_REQUIRE(cfg->channels >= 1 && cfg->channels <= 4 && cfg->out_dim >= 1 && cfg->out_dim <= 8, DMN_ERR_LIMIT,
@@ -881,6 +889,13 @@ extern "C" int dmn_unet_create(const DmnUnetCfg* cfg, DmnUnet** out) {
     u->downs.resize(cfg->n_mults);
     u->ups.resize(cfg->n_mults - 1);
     *out = u;
+    return DMN_OK;
+}
+
+extern "C" int dmn_unet_set_class_labels(DmnUnet* u, const int64_t* labels) {
+    DMN_REQUIRE(u, DMN_ERR_INVALID, "dmn_unet_set_class_labels: null handle");
+    DMN_REQUIRE(u->cfg.num_classes > 0 || labels == nullptr, DMN_ERR_INVALID, "the network has no class embedding");
+    u->labels = reinterpret_cast<const long long*>(labels);
     return DMN_OK;
 }
 
@@ -935,6 +950,10 @@ extern "C" int dmn_unet_load_weights(DmnUnet* u, const DmnTensorDesc* params, in
                         }
             if ((rc = upload(fr.data(), fr.size() * 2, &u->init_wfrag))) return rc;
         }
+    }
+    if (c.num_classes > 0) {
+        GETP(ce, "class_embed.weight", c.num_classes + 1, dim);
+        if ((rc = upload_f32(ce->data, (size_t)(c.num_classes + 1) * dim, &u->class_embed))) return rc;
     }
     if (c.with_time_emb) {
         GETP(w1, "time_mlp.1.weight", td, dim);

@@ -40,8 +40,9 @@ struct SampleKey {           // identifies a captured step graph
     unsigned long long seed;
     long long img_offset;
     float snr;
+    const void* labels;
     bool operator==(const SampleKey& o) const {
-        return x == o.x && table == o.table && ws == o.ws && keep == o.keep && xmean == o.xmean && kind == o.kind &&
+        return labels == o.labels && x == o.x && table == o.table && ws == o.ws && keep == o.keep && xmean == o.xmean && kind == o.kind &&
                B == o.B && H == o.H && W == o.W && flags == o.flags && nsteps == o.nsteps && seed == o.seed &&
                img_offset == o.img_offset && snr == o.snr;
     }
@@ -59,6 +60,8 @@ struct DmnUnet {
     // ingest / egress (fp32)
     float *init_w = nullptr, *init_b = nullptr, *tail_g = nullptr, *tail_b = nullptr, *tail_w = nullptr, *tail_bias = nullptr;
     void* init_wfrag = nullptr;   // bf16 handles: ingest weights as MFMA fragments
+    float* class_embed = nullptr; // [num_classes + 1][dim] fp32 (class-conditional networks)
+    const long long* labels = nullptr;   // borrowed device labels of the coming forwards
     // cached step graph of the sampling loops
     hipGraphExec_t graph_exec = nullptr;
     SampleKey graph_key = {};

@@ -22,6 +22,19 @@ def _fresh_seed() -> int:
     return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
 
 
+def _unwrap_conditional(model):
+    """The reference samples conditionally by handing the sampler `functools.partial(model.forward, classes=label)`
+    (models/conditional_ddpm.py:63). Recognise that shape and return (network, labels) so the device loop can run;
+    anything else comes back unchanged with labels None."""
+    import functools
+    if isinstance(model, functools.partial) and not model.args and set(model.keywords) <= {"classes"}:
+        owner = getattr(model.func, "__self__", None)
+        net = owner if isinstance(owner, Unet) else getattr(owner, "diffusion_model", None)
+        if isinstance(net, Unet) and getattr(model.func, "__name__", "") in ("forward", "__call__"):
+            return net, model.keywords.get("classes")
+    return model, None
+
+
 class GaussianDiffusion(AbstractDiffusionProcess):
     learned_variance = False
     _step_flags = 0   # bits above bit 0 of the library's `pred_x0` argument (bit 1: generalized / DDIM update)
@@ -169,7 +182,9 @@ class GaussianDiffusion(AbstractDiffusionProcess):
         hist = torch.empty((nsteps, B, Cc, H, W), dtype=torch.float32, device=dev) if keep == "all" else None
         lv = 1 if self.learned_variance else 0
         pred_x0 = (0 if self.objective == 'pred_noise' else 1) | self._step_flags
+        model, labels = _unwrap_conditional(model)
         if isinstance(model, Unet):
+            model.set_class_labels(labels, B, dev)
             ws = model.workspace(B, H, W, dev, sampling=True)
             handle = model.native_handle()
             cur = torch.cuda.current_stream(dev)
@@ -211,7 +226,7 @@ class GaussianDiffusion(AbstractDiffusionProcess):
         if keep not in ("all", "last"):
             raise ValueError("keep must be 'all' or 'last'")
         if device is None:
-            device = next(model.parameters()).device
+            device = next(_unwrap_conditional(model)[0].parameters()).device
         device = torch.device(device)
         if device.type != "cuda":
             raise RuntimeError("p_sample_loop runs only on an MI355X device (no CPU implementation)")

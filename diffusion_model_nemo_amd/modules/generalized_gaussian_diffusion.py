@@ -104,7 +104,8 @@ class GeneralizedGaussianDiffusion(GaussianDiffusion):
         if keep not in ("all", "last"):
             raise ValueError("keep must be 'all' or 'last'")
         if device is None:
-            device = next(model.parameters()).device
+            from .gaussian_diffusion import _unwrap_conditional
+            device = next(_unwrap_conditional(model)[0].parameters()).device
         device = torch.device(device)
         if device.type != "cuda":
             raise RuntimeError("p_sample_loop runs only on an MI355X device (no CPU implementation)")

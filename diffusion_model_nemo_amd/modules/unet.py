@@ -95,8 +95,6 @@ class Unet(nn.Module):
         if use_convnext:
             raise NotImplementedError("use_convnext=True is not part of the accelerated path "
                                       "(every shipped config sets use_convnext: False)")
-        if num_classes is not None:
-            raise NotImplementedError("class conditioning is not part of the accelerated path yet")
         if dropout not in (None, 0, 0.0):
             raise NotImplementedError("dropout > 0 is not supported by the HIP forward (sampling path)")
         if resnet_block_order not in ('conv_bn_act', 'bn_act_conv'):
@@ -109,8 +107,9 @@ class Unet(nn.Module):
         self.dim = dim
         self.resnet_block_order = resnet_block_order
         self.resnet_block_groups = resnet_block_groups
-        self.num_classes = None
+        self.num_classes = num_classes
         self.compute_dtype = compute_dtype
+        self._labels = None   # device labels of the current forward / sampling chain (kept alive here)
         self.init_conv = nn.Conv2d(channels, dim, kernel_size=7, padding=3)
 
         dims = [dim, *[dim * m for m in dim_mults]]
@@ -151,6 +150,10 @@ class Unet(nn.Module):
             tail = [nn.Conv2d(dim, self.out_dim, 1)]
         self.final_conv = nn.Sequential(_ResnetBlock(dim, dim, None, g), *tail)
 
+        if self.num_classes is not None:
+            # unet.py:118-120: one extra row (index num_classes) stands for "no class"
+            self.class_embed = nn.Embedding(self.num_classes + 1, embedding_dim=self.dim, padding_idx=self.num_classes)
+
         self._handle = None
         self._weights_version = None
         self._workspace = None
@@ -170,7 +173,25 @@ class Unet(nn.Module):
         c.tail_norm = 1 if self.resnet_block_order == 'bn_act_conv' else 0
         c.with_time_emb = 1
         c.dtype = N.BF16 if self.compute_dtype == "bf16" else N.F32
+        c.num_classes = 0 if self.num_classes is None else int(self.num_classes)
         return c
+
+    def set_class_labels(self, classes: Optional[torch.Tensor], batch: int, device):
+        """Labels used by the following forwards / native sampling loops; None = the 'null' class for every image
+        (unet.py:135-137). Ignored by unconditional networks, like the reference ignores `classes` then."""
+        if self.num_classes is None:
+            return
+        if classes is None:
+            self._labels = None
+        else:
+            classes = classes.to(device=device, dtype=torch.int64).contiguous()
+            if classes.dim() != 1 or classes.numel() != batch:
+                raise ValueError("classes must have shape [B]")
+            if int(classes.min()) < 0 or int(classes.max()) > self.num_classes:
+                raise IndexError("class label out of range")
+            self._labels = classes
+        N.check(N.lib().dmn_unet_set_class_labels(self.native_handle(), None if self._labels is None
+                                                  else self._labels.data_ptr()))
 
     def _version(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
@@ -242,6 +263,7 @@ class Unet(nn.Module):
         else:
             t, is_float = time.to(device=x.device, dtype=torch.int64).contiguous(), 0
         handle = self.native_handle()
+        self.set_class_labels(classes, B, x.device)
         ws = self.workspace(B, H, W, x.device)
         out = torch.empty((B, self.out_dim, H, W), dtype=torch.float32, device=x.device)
         N.check(N.lib().dmn_unet_forward(handle, x.data_ptr(), t.data_ptr(), is_float, out.data_ptr(), B, H, W,

@@ -40,6 +40,7 @@ typedef struct {
     int tail_norm;                 /* 1: resnet_block_order == 'bn_act_conv' => GN+SiLU before the last 1x1 */
     int with_time_emb;
     int dtype;                     /* 0 f32, 1 bf16 */
+    int num_classes;               /* 0: unconditional; > 0: class_embed has num_classes + 1 rows (unet.py:118-120) */
 } DmnUnetCfg;
 
 /* One parameter of the reference state_dict: HOST float32 data, contiguous, PyTorch shape order. */
@@ -59,6 +60,10 @@ void dmn_unet_destroy(DmnUnet* u);
 /* Packs the reference's parameters (names as in Unet.state_dict()) into the device layout. Synchronous. */
 int dmn_unet_load_weights(DmnUnet* u, const DmnTensorDesc* params, int n_params);
 int dmn_unet_workspace_bytes(const DmnUnet* u, int B, int H, int W, size_t* bytes);
+/* Class labels of the next forwards / sampling loops (unet.py:134-141): DEVICE int64 [B], borrowed until replaced;
+ * NULL selects the extra "null" row num_classes for every image, like classes=None in the reference. */
+int dmn_unet_set_class_labels(DmnUnet* u, const int64_t* labels);
+
 /* eps = Unet(x, t).  t: [B] int64 (t_is_float = 0) or float32 (1), device memory. out: [B][out_dim][H][W]. */
 int dmn_unet_forward(DmnUnet* u, const float* x, const void* t, int t_is_float, float* out, int B, int H, int W,
                      void* workspace, size_t workspace_bytes, void* stream);

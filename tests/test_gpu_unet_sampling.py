@@ -105,6 +105,39 @@ def test_unet_forward_dim64_and_three_levels_match_oracle():
         assert float((y - ref).abs().max()) <= 3e-4, (dim, mults)
 
 
+def test_class_conditional_unet_and_sampling():
+    """unet.py:118-141 and models/conditional_ddpm.py:44-88: labelled / null-class forwards against the reference
+    golden; the conditional sampling call shape (a partial of forward) stays on the device loop and equals the
+    step-by-step Python loop bit for bit."""
+    import functools
+    from diffusion_model_nemo_amd.modules import GaussianDiffusion, Unet
+    g = load_golden("unet_cond")
+    sd = make_state_dict(unet_param_shapes(num_classes=10))
+    u = Unet(input_dim=32, dim=32, dim_mults=[1, 2, 4, 8], channels=3, use_convnext=False, dropout=0.0, num_classes=10,
+             compute_dtype="fp32")
+    u.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    u = u.cuda().eval()
+    x, t, labels = T(g["x"]).cuda(), T(g["t"]).cuda(), T(g["labels"]).cuda()
+    assert err(u(x, t, labels), g["y_labels"])[0] <= 2e-4
+    assert err(u(x, t), g["y_default"])[0] <= 2e-4
+    with pytest.raises(IndexError):
+        u(x, t, torch.tensor([0, 11, 2], device="cuda"))
+    gd = GaussianDiffusion(timesteps=12, schedule_name="linear")
+    fn = functools.partial(u.forward, classes=labels)
+    a = gd.p_sample_loop(fn, (3, 3, 32, 32), device="cuda", seed=5, return_device_tensor=True)          # device loop
+    b = gd.p_sample_loop(lambda xx, tt: u(xx, tt, labels), (3, 3, 32, 32), device="cuda", seed=5,
+                         return_device_tensor=True)                                                      # Python loop
+    c = gd.p_sample_loop(u, (3, 3, 32, 32), device="cuda", seed=5, return_device_tensor=True)            # null class
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    # the oracle agrees with the conditional chain
+    p = R.to_torch(sd)
+    consts = R.ddpm_constants(12, "linear")
+    with torch.no_grad():
+        ref = R.ddpm_sample_chain(lambda xx, tt: R.unet_forward(p, xx, tt, classes=labels.cpu()), consts, (3, 3, 32, 32),
+                                  lambda s_: T(philox.normal_like((3, 3, 32, 32), 5, s_, 0 if s_ == 12 else 1)))[0]
+    assert err(a, ref.numpy())[0] <= 1e-4
+
+
 def test_unet_forward_bf16_close_to_reference():
     g = load_golden("unet")
     u = build_unet("bf16")

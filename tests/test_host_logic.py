@@ -169,7 +169,9 @@ def test_unsupported_configurations_fail_loudly():
     with pytest.raises(NotImplementedError):
         Unet(input_dim=32, dim=32, use_convnext=True)
     with pytest.raises(NotImplementedError):
-        Unet(input_dim=32, dim=32, use_convnext=False, num_classes=10)
+        Unet(input_dim=32, dim=32, use_convnext=False, dropout=0.1)
+    uc = Unet(input_dim=32, dim=32, use_convnext=False, num_classes=10)
+    assert tuple(uc.state_dict()["class_embed.weight"].shape) == (11, 32)
     u = Unet(input_dim=32, dim=32, use_convnext=False)
     with pytest.raises(RuntimeError):
         u(torch.zeros(1, 3, 32, 32), torch.zeros(1, dtype=torch.long))   # no CPU path
@@ -186,5 +188,5 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert b"gfx950" in lib.dmn_version()
     # structure sizes agree with the C declarations (int fields only / pointer + int + 4 x int64)
-    assert ctypes.sizeof(_native.DmnUnetCfg) == 4 * (10 + 8)
+    assert ctypes.sizeof(_native.DmnUnetCfg) == 4 * (11 + 8)
     assert ctypes.sizeof(_native.DmnTensorDesc) == 8 + 8 + 8 + 32

@@ -284,3 +284,13 @@ def test_ddim_chains_match_reference(golden):
         assert len(xs) == want.shape[0]
         err = max(float((a - b).abs().max()) for a, b in zip(xs, want))
         assert err <= 2e-5, (tag, err)
+
+
+def test_class_conditional_unet_matches_reference(golden):
+    """unet.py:131-141: the class embedding row is added after init_conv; classes=None means the extra 'null' row."""
+    g = golden("unet_cond")
+    p = R.to_torch(make_state_dict(unet_param_shapes(num_classes=10)))
+    x, t, labels = T(g["x"]), T(g["t"]), T(g["labels"])
+    with torch.no_grad():
+        close(R.unet_forward(p, x, t, classes=labels), g["y_labels"], atol=2e-5)
+        close(R.unet_forward(p, x, t), g["y_default"], atol=2e-5)

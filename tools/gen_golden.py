@@ -399,6 +399,23 @@ def gen_train(M, out):
     npz(out, "train_step", **arrays)
 
 
+def gen_cond(M, out):
+    """Class-conditional Unet (unet.py:118-141): 10 classes; labelled, null-class and default (classes=None) forwards."""
+    from oracle.weights import unet_param_shapes
+    u = M.Unet(input_dim=32, dim=32, dim_mults=[1, 2, 4, 8], channels=3, with_time_emb=True, resnet_block_groups=8,
+               use_convnext=False, dropout=0.0, num_classes=10)
+    load_named(u, "", seed=0)   # the padding row gets ordinary values too: the forward just looks the row up
+    u.eval()
+    ref_shapes = {k: tuple(v.shape) for k, v in u.state_dict().items()}
+    assert ref_shapes == {k: tuple(v) for k, v in unet_param_shapes(num_classes=10).items()}
+    x = x_input((3, 3, 32, 32), seed=23)
+    t = torch.tensor([5, 400, 990], dtype=torch.long)
+    labels = torch.tensor([3, 10, 0], dtype=torch.long)
+    with torch.no_grad():
+        arrays = {"x": x, "t": t, "labels": labels, "y_labels": u(x, t, labels), "y_default": u(x, t)}
+    npz(out, "unet_cond", **arrays)
+
+
 def gen_ddim(M, out, seed=3):
     """GeneralizedGaussianDiffusion (DDIM) chains, B=2 @ 32x32, T=1000 cosine: 20 strided steps with eta=0 and
     eta=0.5, plus a pred_x0-objective chain of 10 steps; every x_t kept (model range)."""
@@ -434,7 +451,7 @@ def main():
     torch.set_num_threads(8)
     os.makedirs(args.out, exist_ok=True)
     jobs = dict(schedules=gen_schedules, blocks=gen_blocks, unet=gen_unet, p_sample=gen_psample,
-                sde=gen_sde, train=gen_train, chain=gen_chain, ddim=gen_ddim)
+                sde=gen_sde, train=gen_train, chain=gen_chain, ddim=gen_ddim, cond=gen_cond)
     for name, fn in jobs.items():
         if args.only and name not in args.only:
             continue
