@@ -45,6 +45,7 @@ SIGNATURES = {
     "dmn_sde_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "dmn_pc_sample_loop": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _f, _u64, _i64, _vp, _vp, _vp,
                                 _sz, _vp, _i]),
+    "dmn_bpd_loop": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _u64, _i64, _vp, _i, _vp, _f, _f, _vp, _sz, _vp, _i]),
     "dmn_sample_workspace_bytes": (_i, [_vp, _i, _i, _i, C.POINTER(_sz)]),
     "dmn_loop_last_ms": (_i, [_vp, C.POINTER(_f)]),
     "dmn_bench_dominant_kernel": (_i, [_vp, _i, _i, _i, _i, _vp, _sz, _vp, C.POINTER(_f), C.POINTER(C.c_double)]),

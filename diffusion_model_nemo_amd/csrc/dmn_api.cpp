@@ -253,6 +253,42 @@ extern "C" int dmn_pc_sample_loop(DmnUnet* u, const float* table, int nsteps, fl
     return run_loop(u, key, nsteps, s, use_graph, body);
 }
 
+extern "C" int dmn_bpd_loop(DmnUnet* u, const float* table, int nsteps, const float* x0, int B, int H, int W,
+                            int learned_variance, uint64_t seed, int64_t img_offset, float* terms, int terms_stride,
+                            float* prior, float prior_sqrt_acp, float prior_log_1m_acp, void* workspace,
+                            size_t workspace_bytes, void* stream, int use_graph) {
+    DMN_REQUIRE(u && table && x0 && terms && prior && workspace && nsteps > 0 && terms_stride >= nsteps, DMN_ERR_INVALID,
+                "dmn_bpd_loop: bad argument");
+    DMN_REQUIRE(u->cfg.out_dim == u->cfg.channels * (learned_variance ? 2 : 1), DMN_ERR_INVALID,
+                "network emits %d channels, evaluation expects %d", u->cfg.out_dim, u->cfg.channels * (learned_variance ? 2 : 1));
+    hipStream_t s = (hipStream_t)stream;
+    LoopBufs lb;
+    int rc = carve(u, B, H, W, workspace, workspace_bytes, lb, nullptr);
+    if (rc) return rc;
+    const int C = u->cfg.channels;
+    DMN_REQUIRE((size_t)B * bpd_slots(C * H * W) * 4 <= dmn_sde_scratch_bytes(B, C, H, W), DMN_ERR_WORKSPACE,
+                "dmn_bpd_loop: scratch too small");
+    DMN_HIP_CHECK(hipMemsetAsync(lb.step_idx, 0, 256, s));
+    if ((rc = launch_bpd_prior(x0, prior, B, C * H * W, prior_sqrt_acp, prior_log_1m_acp, s))) return rc;
+    SampleKey key = {x0, table, workspace, terms, prior, 3, B, H, W, learned_variance, nsteps, seed, img_offset,
+                     (float)terms_stride, u->labels};
+    auto body = [&]() -> int {
+        BpdArgs a;
+        memset(&a, 0, sizeof(a));
+        a.c = step_common(table, lb.step_idx, 0, x0, lb.net, nullptr, lb.xmean, B, C, H * W, seed, img_offset, nullptr);
+        a.partials = lb.partials;
+        a.terms = terms;
+        a.terms_stride = terms_stride;
+        a.learned_variance = learned_variance;
+        int r;
+        if ((r = launch_bpd_qsample(a, s))) return r;
+        if ((r = unet_forward_impl(u, lb.xmean, nullptr, 1, table, lb.step_idx, lb.net, B, H, W, lb.arena, lb.arena_bytes, s, false, nullptr))) return r;
+        if ((r = launch_bpd_term(a, s))) return r;
+        return launch_advance(lb.step_idx, s);
+    };
+    return run_loop(u, key, nsteps, s, use_graph, body);
+}
+
 extern "C" int dmn_loop_last_ms(DmnUnet* u, float* ms) {
     DMN_REQUIRE(u && ms, DMN_ERR_INVALID, "dmn_loop_last_ms: null argument");
     DMN_REQUIRE(u->ev_valid, DMN_ERR_INVALID, "dmn_loop_last_ms: no sampling loop has run on this handle");

@@ -9,6 +9,8 @@
 //   DDIM rows:  1 sqrt(1 - a_t)  2 sqrt(a_t)  3 sqrt(a_next)  4 c1 (noise)  5 c2 (direction)
 //   SDE rows:   1 a  2 b  3 c  (x_mean = a x + b net, x = x_mean + c z)
 //               4 score scale (score = scale * net)  5 alpha (Langevin)  6 fixed corrector step (ALD)
+//   BPD rows:   1 sqrt(a_t)  2 sqrt(1 - a_t)  3 sqrt(1/a_t)  4 sqrt(1/a_t - 1)  5 posterior_mean_coef1
+//               6 posterior_mean_coef2  7 posterior_log_variance_clipped  9 log(beta)  10 [t == 0]
 //   col 8  step id used to key the noise generator
 #define DMN_TABLE_COLS 12
 
@@ -52,3 +54,17 @@ int langevin_slots(int per);
 int launch_prior(float* x, int B, int per, unsigned long long seed, unsigned pstep, long long img_offset, float scale,
                  hipStream_t s);
 int launch_advance(int* step_idx, hipStream_t s);
+
+// Bits-per-dimension evaluation (models/abstract_diffusion_model.py:137-197), one timestep per table row.
+struct BpdArgs {
+    StepCommon c;          // x = x_start, x_out = x_t buffer, net = network output at (x_t, t); noise stream 3
+    float* partials;       // [B][slots]
+    float* terms;          // [B][terms_stride], column = the row's timestep (table col 0)
+    int terms_stride;
+    int slots;
+    int learned_variance;
+};
+int bpd_slots(int per);
+int launch_bpd_qsample(const BpdArgs& a, hipStream_t s);   // x_t = sqrt(a_t) x_0 + sqrt(1 - a_t) z
+int launch_bpd_term(BpdArgs& a, hipStream_t s);            // per-sample KL / decoder NLL in bits -> terms
+int launch_bpd_prior(const float* x0, float* prior, int B, int per, float sqrt_acp_T, float log_1m_acp_T, hipStream_t s);

@@ -197,6 +197,97 @@ __global__ void __launch_bounds__(256) prior_kernel(float* x, int B, int per, un
 
 __global__ void advance_kernel(int* step_idx) { *step_idx += 1; }
 
+// ---- bits per dimension ---------------------------------------------------------------------------------------
+// q_sample (gaussian_diffusion.py:104-116) with the generator's stream 3. grid (ceil(per/4/256), B)
+__global__ void __launch_bounds__(256) bpd_qsample_kernel(const BpdArgs a) {
+    const StepCommon& c = a.c;
+    const int b = blockIdx.y, per = c.C * c.HW;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (4 * q >= per) return;
+    const float* tr = c.table + (size_t)(c.step_idx ? *c.step_idx : c.step) * DMN_TABLE_COLS;
+    float z[4];
+    load_noise(c, (unsigned)tr[8], 3u, b, q, per, z);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int e = 4 * q + r;
+        if (e < per) c.x_out[(size_t)b * per + e] = tr[1] * c.x[(size_t)b * per + e] + tr[2] * z[r];
+    }
+}
+
+__device__ __forceinline__ float approx_normal_cdf(float v) {   // utils.py:37-38
+    return 0.5f * (1.0f + tanhf(0.7978845608028654f * (v + 0.044715f * (v * v * v))));
+}
+
+// Per-element variational-bound term (variational_bound_loss.py:31-52, utils.py:28-56) summed per workgroup.
+// grid (slots, B); partials [B][slots]
+__global__ void __launch_bounds__(256) bpd_term_kernel(const BpdArgs a) {
+    __shared__ float sred[4];
+    const StepCommon& c = a.c;
+    const int b = blockIdx.y, per = c.C * c.HW;
+    const float* tr = c.table + (size_t)(c.step_idx ? *c.step_idx : c.step) * DMN_TABLE_COLS;
+    const float sra = tr[3], srm1 = tr[4], c1 = tr[5], c2 = tr[6], plv = tr[7], logb = tr[9];
+    const bool t0 = tr[10] != 0.f;
+    const int mo_c = a.learned_variance ? 2 * c.C : c.C;
+    float sum = 0.f;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < per; e += gridDim.x * 256) {
+        const float x0 = c.x[(size_t)b * per + e];
+        const float xt = c.x_out[(size_t)b * per + e];
+        const float eps = c.net[(size_t)b * mo_c * c.HW + e];
+        float mlv = plv;
+        if (a.learned_variance) {
+            const float frac = (c.net[(size_t)b * mo_c * c.HW + (size_t)c.C * c.HW + e] + 1.0f) * 0.5f;
+            mlv = frac * logb + (1.0f - frac) * plv;
+        }
+        const float true_mean = c1 * x0 + c2 * xt;
+        const float px0 = fminf(fmaxf(sra * xt - srm1 * eps, -1.0f), 1.0f);
+        const float model_mean = c1 * px0 + c2 * xt;
+        float term;
+        if (!t0) {
+            const float d = true_mean - model_mean;
+            term = 0.5f * (-1.0f + mlv - plv + expf(plv - mlv) + d * d * expf(-mlv));
+        } else {
+            const float cen = x0 - model_mean;
+            const float inv = expf(-0.5f * mlv);
+            const float cp = approx_normal_cdf(inv * (cen + 1.0f / 255.0f));
+            const float cm = approx_normal_cdf(inv * (cen - 1.0f / 255.0f));
+            const float lp = x0 < -0.999f ? logf(fmaxf(cp, 1e-12f))
+                             : x0 > 0.999f ? logf(fmaxf(1.0f - cm, 1e-12f)) : logf(fmaxf(cp - cm, 1e-12f));
+            term = -lp;
+        }
+        sum += term;
+    }
+    sum = wave_sum(sum);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) a.partials[(size_t)b * a.slots + blockIdx.x] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+}
+
+// terms[b][t] = sum of the slots / (elements * ln 2). grid (ceil(B/256))
+__global__ void __launch_bounds__(256) bpd_reduce_kernel(const BpdArgs a) {
+    const StepCommon& c = a.c;
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= c.B) return;
+    const float* tr = c.table + (size_t)(c.step_idx ? *c.step_idx : c.step) * DMN_TABLE_COLS;
+    float s = 0.f;
+    for (int i = 0; i < a.slots; ++i) s += a.partials[(size_t)b * a.slots + i];
+    a.terms[(size_t)b * a.terms_stride + (int)tr[0]] = s / (float)(c.C * c.HW) * 1.4426950408889634f;
+}
+
+// prior_bpd[b] = mean_e KL(N(sqrt(a_T) x0, 1 - a_T) || N(0, 1)) / ln 2 (abstract_diffusion_model.py:181-184). grid (B)
+__global__ void __launch_bounds__(256) bpd_prior_kernel(const float* x0, float* prior, int per, float m, float lv) {
+    __shared__ float sred[4];
+    const int b = blockIdx.x;
+    float sum = 0.f;
+    for (int e = threadIdx.x; e < per; e += 256) {
+        const float mu = m * x0[(size_t)b * per + e];
+        sum += 0.5f * (-1.0f + 0.0f - lv + expf(lv - 0.0f) + mu * mu * expf(-0.0f));
+    }
+    sum = wave_sum(sum);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) prior[b] = ((sred[0] + sred[1]) + (sred[2] + sred[3])) / (float)per * 1.4426950408889634f;
+}
+
 }  // namespace
 
 static dim3 step_grid(const StepCommon& c) { return dim3(((c.C * c.HW + 3) / 4 + 255) / 256, c.B); }
@@ -230,6 +321,28 @@ int launch_prior(float* x, int B, int per, unsigned long long seed, unsigned pst
                  hipStream_t s) {
     hipLaunchKernelGGL(prior_kernel, dim3(((per + 3) / 4 + 255) / 256, B), dim3(256), 0, s, x, B, per, seed, pstep,
                        img_offset, scale);
+    DMN_HIP_CHECK(hipGetLastError());
+    return DMN_OK;
+}
+int bpd_slots(int per) {
+    int s = (per + 1023) / 1024;
+    return s > 16 ? 16 : s;
+}
+int launch_bpd_qsample(const BpdArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(bpd_qsample_kernel, step_grid(a.c), dim3(256), 0, s, a);
+    DMN_HIP_CHECK(hipGetLastError());
+    return DMN_OK;
+}
+int launch_bpd_term(BpdArgs& a, hipStream_t s) {
+    a.slots = bpd_slots(a.c.C * a.c.HW);
+    hipLaunchKernelGGL(bpd_term_kernel, dim3(a.slots, a.c.B), dim3(256), 0, s, a);
+    DMN_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(bpd_reduce_kernel, dim3((a.c.B + 255) / 256), dim3(256), 0, s, a);
+    DMN_HIP_CHECK(hipGetLastError());
+    return DMN_OK;
+}
+int launch_bpd_prior(const float* x0, float* prior, int B, int per, float sqrt_acp_T, float log_1m_acp_T, hipStream_t s) {
+    hipLaunchKernelGGL(bpd_prior_kernel, dim3(B), dim3(256), 0, s, x0, prior, per, sqrt_acp_T, log_1m_acp_T);
     DMN_HIP_CHECK(hipGetLastError());
     return DMN_OK;
 }

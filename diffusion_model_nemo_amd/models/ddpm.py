@@ -44,6 +44,41 @@ class AbstractDiffusionModel(nn.Module):
         self.diffusion_model.set_compute_dtype(compute_dtype)
         return self
 
+    def calculate_bits_per_dimension(self, x_start: torch.Tensor, diffusion_model_fn=None, max_batch_size: int = 32,
+                                     seed: Optional[int] = None):
+        """abstract_diffusion_model.py:137-197: the variational bound in bits per dimension, one network evaluation
+        per timestep, all T steps replayed on the device. Returns {'total_bpd' [B], 'terms_bpd' [B, T],
+        'prior_bpd' [B]}. `diffusion_model_fn` is what `get_diffusion_model(batch)` returns (default: the network)."""
+        import ctypes as C
+        from .. import _native as N
+        from ..modules.gaussian_diffusion import _unwrap_conditional
+        from ..modules.unet import Unet
+        sampler = self.sampler
+        if getattr(sampler, "objective", "pred_noise") != "pred_noise":
+            raise NotImplementedError("bits per dimension is built for the 'pred_noise' objective")
+        net, labels = _unwrap_conditional(self.diffusion_model if diffusion_model_fn is None else diffusion_model_fn)
+        if not isinstance(net, Unet):
+            raise NotImplementedError("bits per dimension needs the accelerated network (no Python-callable path)")
+        if not x_start.is_cuda:
+            raise RuntimeError("calculate_bits_per_dimension runs only on MI355X device tensors")
+        B = x_start.size(0) if max_batch_size <= 0 else min(max_batch_size, x_start.size(0))
+        x0 = x_start[:B].contiguous().float()
+        _, Cc, H, W = x0.shape
+        T = sampler.timesteps
+        dev = x0.device
+        table = sampler.bpd_table(dev)
+        terms = torch.zeros(B, T, dtype=torch.float32, device=dev)
+        prior = torch.zeros(B, dtype=torch.float32, device=dev)
+        net.set_class_labels(labels, B, dev)
+        ws = net.workspace(B, H, W, dev, sampling=True)
+        seed = sampler._resolve_seed(seed)
+        N.check(N.lib().dmn_bpd_loop(
+            net.native_handle(), table.data_ptr(), T, x0.data_ptr(), B, H, W, 1 if sampler.learned_variance else 0, seed, 0,
+            terms.data_ptr(), T, prior.data_ptr(), float(sampler.sqrt_alphas_cumprod[T - 1]),
+            float(sampler.log_one_minus_alphas_cumprod[T - 1]), ws.data_ptr(), ws.numel(),
+            N.current_stream_handle(dev), 1))
+        return {'total_bpd': terms.sum(dim=1) + prior, 'terms_bpd': terms, 'prior_bpd': prior}
+
 
 class DDPM(AbstractDiffusionModel):
     def __init__(self, cfg, trainer=None):

@@ -32,12 +32,37 @@ def _unwrap_conditional(model):
         net = owner if isinstance(owner, Unet) else getattr(owner, "diffusion_model", None)
         if isinstance(net, Unet) and getattr(model.func, "__name__", "") in ("forward", "__call__"):
             return net, model.keywords.get("classes")
+    # `model.forward` of a network or of a DDPM-style wrapper (what get_diffusion_model() returns unconditionally)
+    owner = getattr(model, "__self__", None)
+    if owner is not None and getattr(model, "__name__", "") == "forward":
+        net = owner if isinstance(owner, Unet) else getattr(owner, "diffusion_model", None)
+        if isinstance(net, Unet) and not getattr(getattr(owner, "sampler", None), "use_class_conditioning", False):
+            return net, None
     return model, None
 
 
 class GaussianDiffusion(AbstractDiffusionProcess):
     learned_variance = False
     _step_flags = 0   # bits above bit 0 of the library's `pred_x0` argument (bit 1: generalized / DDIM update)
+
+    def bpd_table(self, device) -> torch.Tensor:
+        """[T][12] float32 device table for the bits-per-dimension evaluation, row s <-> timestep T-1-s; BPD row
+        layout of csrc/dmn_sampler.h."""
+        T = self.timesteps
+        order = torch.arange(T - 1, -1, -1)
+        tab = torch.zeros(T, N.TABLE_COLS, dtype=torch.float32)
+        tab[:, 0] = order.float()
+        tab[:, 1] = self.sqrt_alphas_cumprod[order]
+        tab[:, 2] = self.sqrt_one_minus_alphas_cumprod[order]
+        tab[:, 3] = self.sqrt_recip_alphas_cumprod[order]
+        tab[:, 4] = self.sqrt_recipm1_alphas_cumprod[order]
+        tab[:, 5] = self.posterior_mean_coef1[order]
+        tab[:, 6] = self.posterior_mean_coef2[order]
+        tab[:, 7] = self.posterior_log_variance_clipped[order]
+        tab[:, 8] = order.float()
+        tab[:, 9] = torch.log(self.betas)[order]
+        tab[:, 10] = (order == 0).float()
+        return tab.to(device)
 
     def step_labels(self):
         """Timestep handed to the network in each row of the step table."""

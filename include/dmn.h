@@ -111,6 +111,15 @@ int dmn_pc_sample_loop(DmnUnet* u, const float* table, int nsteps, float* x, int
                        int corrector, int n_corrector_steps, float snr, int denoise, int draw_prior, float prior_scale,
                        uint64_t seed, int64_t img_offset, float* keep, float* x_mean_out, void* workspace,
                        size_t workspace_bytes, void* stream, int use_graph);
+/* AbstractDiffusionModel.calculate_bits_per_dimension (models/abstract_diffusion_model.py:137-197) for the
+ * 'pred_noise' objective: for every row of `table` (BPD row layout, csrc/dmn_sampler.h; normally t = T-1 .. 0)
+ * x_t = q_sample(x0, t) with generator stream 3, network evaluation, then the per-sample variational-bound term in
+ * bits (VariationalBoundLoss.compute_variation_loss_terms, loss/variational_bound_loss.py:31-52) into
+ * terms[b * terms_stride + t]. prior[b] receives the prior term computed from sqrt(a_{T-1}) and log(1 - a_{T-1}).
+ * x0, terms, prior: device float32. workspace: >= dmn_sample_workspace_bytes. */
+int dmn_bpd_loop(DmnUnet* u, const float* table, int nsteps, const float* x0, int B, int H, int W, int learned_variance,
+                 uint64_t seed, int64_t img_offset, float* terms, int terms_stride, float* prior, float prior_sqrt_acp,
+                 float prior_log_1m_acp, void* workspace, size_t workspace_bytes, void* stream, int use_graph);
 int dmn_sample_workspace_bytes(const DmnUnet* u, int B, int H, int W, size_t* bytes);
 /* Device time (HIP events on the loop's stream) of the last dmn_*_sample_loop call on this handle; waits for it.
  * No counterpart in the reference: measurement hook used by bench.py. */

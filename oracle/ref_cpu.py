@@ -262,6 +262,73 @@ def ddpm_sample_chain(model_fn: Callable[[Tensor, Tensor], Tensor], c, shape, no
     return out
 
 
+# ----------------------------------------------------------------------------------------------
+# Variational bound / bits per dimension (diffusion_model_nemo/utils.py:24-56,
+# loss/variational_bound_loss.py:31-52, models/abstract_diffusion_model.py:137-197)
+# ----------------------------------------------------------------------------------------------
+def normal_kl(mean1, logvar1, mean2, logvar2):
+    """utils.py:28-34."""
+    return 0.5 * (-1.0 + logvar2 - logvar1 + torch.exp(logvar1 - logvar2) + ((mean1 - mean2) ** 2) * torch.exp(-logvar2))
+
+
+def discretized_gaussian_log_likelihood(x, means, log_scales, thres=0.999):
+    """utils.py:37-56 (tanh approximation of the normal CDF, bins of width 2/255)."""
+    def cdf(v):
+        return 0.5 * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (v + 0.044715 * (v ** 3))))
+
+    def log(v):
+        return torch.log(v.clamp(min=1e-12))
+
+    centered = x - means
+    inv_stdv = torch.exp(-log_scales)
+    cdf_plus = cdf(inv_stdv * (centered + 1.0 / 255.0))
+    cdf_min = cdf(inv_stdv * (centered - 1.0 / 255.0))
+    return torch.where(x < -thres, log(cdf_plus), torch.where(x > thres, log(1.0 - cdf_min), log(cdf_plus - cdf_min)))
+
+
+def vlb_terms(samples, model_mean, model_log_variance, true_mean, true_log_variance_clipped, t):
+    """VariationalBoundLoss.compute_variation_loss_terms (variational_bound_loss.py:31-52): per-sample KL in bits,
+    replaced by the discretised decoder NLL at t == 0."""
+    def mean_flat(v):
+        return v.mean(dim=tuple(range(1, v.ndim)))
+
+    kl = mean_flat(normal_kl(true_mean, true_log_variance_clipped, model_mean, model_log_variance)) * (1.0 / math.log(2.0))
+    nll = -discretized_gaussian_log_likelihood(samples, model_mean, 0.5 * model_log_variance)
+    nll = mean_flat(nll) * (1.0 / math.log(2.0))
+    return torch.where(t == 0, nll, kl)
+
+
+def bits_per_dimension(model_fn, c, x_start: Tensor, noise_fn, learned_variance: bool = False):
+    """AbstractDiffusionModel.calculate_bits_per_dimension (abstract_diffusion_model.py:137-197) for the
+    'pred_noise' objective. ``noise_fn(t)`` is the q_sample draw of timestep t. Returns total_bpd [B],
+    terms_bpd [B, T], prior_bpd [B]."""
+    T = int(c["betas"].shape[0])
+    B, nd = x_start.shape[0], x_start.ndim
+    terms = torch.zeros(B, T)
+    for ti in range(T - 1, -1, -1):
+        t = torch.full((B,), ti, dtype=torch.long)
+        x_t = q_sample(c, x_start, t, noise_fn(ti))
+        true_mean = _ex(c["posterior_mean_coef1"], t, nd) * x_start + _ex(c["posterior_mean_coef2"], t, nd) * x_t
+        true_lv = _ex(c["posterior_log_variance_clipped"], t, nd)
+        out = model_fn(x_t, t)
+        if learned_variance:
+            eps, v = out.chunk(2, dim=1)
+            frac = (v + 1) * 0.5
+            model_lv = frac * _ex(torch.log(c["betas"]), t, nd) + (1 - frac) * true_lv
+        else:
+            eps, model_lv = out, true_lv.expand(-1, *x_start.shape[1:])
+        x0 = (_ex(c["sqrt_recip_alphas_cumprod"], t, nd) * x_t - _ex(c["sqrt_recipm1_alphas_cumprod"], t, nd) * eps).clamp(-1.0, 1.0)
+        model_mean = _ex(c["posterior_mean_coef1"], t, nd) * x0 + _ex(c["posterior_mean_coef2"], t, nd) * x_t
+        terms[:, ti] = vlb_terms(x_start, model_mean, model_lv, true_mean, true_lv, t)
+    tp = torch.full((B,), T - 1, dtype=torch.long)
+    qt_mean = _ex(c["sqrt_alphas_cumprod"], tp, nd) * x_start
+    qt_lv = _ex(c["log_one_minus_alphas_cumprod"], tp, nd)
+    zero = torch.tensor(0.0)
+    kl_prior = normal_kl(qt_mean, qt_lv, zero, zero)
+    prior = kl_prior.mean(dim=tuple(range(1, nd))) / math.log(2.0)
+    return {"total_bpd": terms.sum(dim=1) + prior, "terms_bpd": terms, "prior_bpd": prior}
+
+
 def ddim_sequence(timesteps: int, ddim_timesteps: int):
     """(t, t_next) pairs in execution order (generalized_gaussian_diffusion.py:111-113,121-123)."""
     n = ddim_timesteps if ddim_timesteps > 0 else timesteps

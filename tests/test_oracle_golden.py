@@ -294,3 +294,21 @@ def test_class_conditional_unet_matches_reference(golden):
     with torch.no_grad():
         close(R.unet_forward(p, x, t, classes=labels), g["y_labels"], atol=2e-5)
         close(R.unet_forward(p, x, t), g["y_default"], atol=2e-5)
+
+
+def test_bits_per_dimension_matches_reference(golden):
+    """abstract_diffusion_model.py:137-197 driven over the reference's samplers and VariationalBoundLoss."""
+    g = golden("bpd_T20_B2_32")
+    x0 = T(g["x0"])
+    c = R.ddpm_constants(20, "cosine")
+
+    def noise_fn(t):
+        return torch.from_numpy(philox.normal_like(tuple(x0.shape), 4, t, 3))
+
+    for tag, lv in (("fixed", False), ("learned", True)):
+        p = R.to_torch(make_state_dict(unet_param_shapes(learned_variance=lv)))
+        with torch.no_grad():
+            r = R.bits_per_dimension(lambda x, t: R.unet_forward(p, x, t), c, x0, noise_fn, learned_variance=lv)
+        close(r["terms_bpd"], g[f"{tag}_terms"], atol=2e-5, rtol=2e-5)
+        close(r["prior_bpd"], g[f"{tag}_prior"], atol=1e-6, rtol=1e-6)
+        close(r["total_bpd"], g[f"{tag}_total"], atol=1e-4, rtol=2e-5)

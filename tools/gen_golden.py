@@ -416,6 +416,46 @@ def gen_cond(M, out):
     npz(out, "unet_cond", **arrays)
 
 
+def gen_bpd(M, out, seed=4):
+    """Bits per dimension (models/abstract_diffusion_model.py:137-197). `models/` cannot be imported without NeMo /
+    Lightning, so the 30-line loop is re-driven here over the reference's own pieces: the samplers' q_sample /
+    q_posterior / p_mean_variance / q_mean_variance, VariationalBoundLoss.compute_variation_loss_terms and
+    utils.normal_kl / mean_flattened. T=20, B=2 @ 32x32, fixed and learned variance."""
+    import math
+    from diffusion_model_nemo import utils
+    from diffusion_model_nemo.loss.variational_bound_loss import VariationalBoundLoss
+    B, T = 2, 20
+    shape = (B, 3, 32, 32)
+    x0 = (x_input(shape, seed=41) * 0.5).clamp(-1, 1)
+    x0[0, :, :4] = 1.0    # exercise both saturated branches of the discretised likelihood
+    x0[1, :, :4] = -1.0
+    arrays = {"x0": x0}
+    for tag, lv in (("fixed", False), ("learned", True)):
+        u = build_unet(M, learned_variance=lv)
+        sampler = (M.LearnedGaussianDiffusion if lv else M.GaussianDiffusion)(timesteps=T, schedule_name="cosine")
+        terms = torch.zeros(B, T)
+        plan = [(t, 3) for t in range(T - 1, -1, -1)]
+        with NoiseInjector(plan, seed=seed), torch.no_grad():
+            for t in range(T - 1, -1, -1):
+                t_b = torch.full([B], t, dtype=torch.long)
+                x_t = sampler.q_sample(x_start=x0, t=t_b)
+                true_mean, true_lv = sampler.q_posterior(x_start=x0, x=x_t, t=t_b)
+                model_mean, _, model_lv, _ = sampler.p_mean_variance(u, x=x_t, t=t_b, return_pred_x_start=True)
+                if model_lv.shape != model_mean.shape:
+                    model_lv = model_lv.expand(-1, *model_mean.size()[1:])
+                terms[:, t] = VariationalBoundLoss.compute_variation_loss_terms(
+                    samples=x0, model_mean=model_mean, model_log_variance=model_lv, true_mean=true_mean,
+                    true_log_variance_clipped=true_lv, t=t_b)
+            t_prior = torch.full([B], T - 1, dtype=torch.long)
+            qt_mean, _, qt_lv = sampler.q_mean_variance(x_start=x0, t=t_prior)
+            zero = torch.tensor(0.0)
+            prior = utils.mean_flattened(utils.normal_kl(mean1=qt_mean, logvar1=qt_lv, mean2=zero, logvar2=zero)) / math.log(2.0)
+        arrays[f"{tag}_terms"] = terms
+        arrays[f"{tag}_prior"] = prior
+        arrays[f"{tag}_total"] = terms.sum(dim=1) + prior
+    npz(out, "bpd_T20_B2_32", **arrays)
+
+
 def gen_ddim(M, out, seed=3):
     """GeneralizedGaussianDiffusion (DDIM) chains, B=2 @ 32x32, T=1000 cosine: 20 strided steps with eta=0 and
     eta=0.5, plus a pred_x0-objective chain of 10 steps; every x_t kept (model range)."""
@@ -451,7 +491,7 @@ def main():
     torch.set_num_threads(8)
     os.makedirs(args.out, exist_ok=True)
     jobs = dict(schedules=gen_schedules, blocks=gen_blocks, unet=gen_unet, p_sample=gen_psample,
-                sde=gen_sde, train=gen_train, chain=gen_chain, ddim=gen_ddim, cond=gen_cond)
+                sde=gen_sde, train=gen_train, chain=gen_chain, ddim=gen_ddim, cond=gen_cond, bpd=gen_bpd)
     for name, fn in jobs.items():
         if args.only and name not in args.only:
             continue
