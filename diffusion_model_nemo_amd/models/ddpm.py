@@ -35,6 +35,59 @@ class AbstractDiffusionModel(nn.Module):
     def get_diffusion_model(self, batch: Dict):
         return self.forward
 
+    # ---- `.nemo` archives (what ModelPT.save_to / restore_from exchange: a tar with model_config.yaml and
+    # model_weights.ckpt; used by examples/ddpm/eval_ddpm.py:70 and the other example scripts) --------------------
+    CONFIG_MEMBER = "model_config.yaml"
+    WEIGHTS_MEMBER = "model_weights.ckpt"
+
+    def save_to(self, save_path: str):
+        """Writes the model section of the config and the state_dict in the `.nemo` layout (uncompressed tar)."""
+        import io
+        import tarfile
+
+        import yaml
+
+        def plain(o):   # Config -> builtin containers (raw access: no attribute wrapping on the way)
+            if isinstance(o, dict):
+                return {k: plain(v) for k, v in dict.items(o)}
+            if isinstance(o, (list, tuple)):
+                return [plain(v) for v in o]
+            return o
+
+        blobs = {self.CONFIG_MEMBER: yaml.safe_dump(plain(self.cfg), sort_keys=False).encode()}
+        buf = io.BytesIO()
+        torch.save({k: v.detach().cpu() for k, v in self.state_dict().items()}, buf)
+        blobs[self.WEIGHTS_MEMBER] = buf.getvalue()
+        with tarfile.open(save_path, "w:") as tar:
+            for name, data in blobs.items():
+                info = tarfile.TarInfo("./" + name)
+                info.size = len(data)
+                tar.addfile(info, io.BytesIO(data))
+
+    @classmethod
+    def restore_from(cls, restore_path: str, trainer=None, map_location=None, strict: bool = True, overrides=None):
+        """Builds the model from a `.nemo` archive (plain or gzip-compressed tar). The weights are read with
+        `torch.load(..., weights_only=True)`: nothing stored in the file is executed."""
+        import io
+        import tarfile
+
+        import yaml
+        with tarfile.open(restore_path, "r:*") as tar:
+            members = {m.name.lstrip("./"): m for m in tar.getmembers() if m.isfile()}
+            for need in (cls.CONFIG_MEMBER, cls.WEIGHTS_MEMBER):
+                if need not in members:
+                    raise FileNotFoundError(f"{restore_path} holds no {need}")
+            cfg = yaml.load(tar.extractfile(members[cls.CONFIG_MEMBER]).read().decode(), Loader=yaml.SafeLoader)
+            blob = tar.extractfile(members[cls.WEIGHTS_MEMBER]).read()
+        if isinstance(cfg, dict) and "model" in cfg and "diffusion_model" not in cfg:
+            cfg = cfg["model"]            # a full experiment config rather than its model section
+        model = cls(to_config(cfg, overrides), trainer=trainer)
+        state = torch.load(io.BytesIO(blob), map_location=map_location or "cpu", weights_only=True)
+        if isinstance(state, dict) and "state_dict" in state and not any(k.startswith("diffusion_model.") for k in state):
+            state = state["state_dict"]
+        model.load_state_dict(state, strict=strict)
+        return model
+
     def change_sampler(self, sampler_cfg):
         """abstract_diffusion_model.py:130-135."""
         self.sampler = instantiate(sampler_cfg)

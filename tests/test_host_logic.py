@@ -190,3 +190,38 @@ def test_library_loads_and_exports_every_declared_symbol():
     # structure sizes agree with the C declarations (int fields only / pointer + int + 4 x int64)
     assert ctypes.sizeof(_native.DmnUnetCfg) == 4 * (11 + 8)
     assert ctypes.sizeof(_native.DmnTensorDesc) == 8 + 8 + 8 + 32
+
+
+def test_nemo_archive_round_trip(tmp_path):
+    """`.nemo` layout (tar: model_config.yaml + model_weights.ckpt) written and read back: same config, same weights,
+    and the reader also accepts the gzip-compressed form without the './' member prefix."""
+    import tarfile
+    from diffusion_model_nemo_amd.config import load_config
+    from diffusion_model_nemo_amd.models import DDPM
+    p = tmp_path / "cfg.yaml"
+    p.write_text(REFERENCE_STYLE_CFG)
+    m = DDPM(load_config(str(p), ["model.image_size=32", "model.timesteps=50"]).model)
+    with torch.no_grad():
+        for i, prm in enumerate(m.parameters()):
+            prm.add_(0.001 * (i % 7))
+    path = str(tmp_path / "DDPM.nemo")
+    m.save_to(path)
+    with tarfile.open(path) as tar:
+        assert sorted(n.lstrip("./") for n in tar.getnames()) == ["model_config.yaml", "model_weights.ckpt"]
+    r = DDPM.restore_from(path)
+    assert r.timesteps == 50 and r.image_size == 32 and r.sampler.timesteps == 50
+    a, b = m.state_dict(), r.state_dict()
+    assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
+    gz = str(tmp_path / "DDPM_gz.nemo")
+    with tarfile.open(path) as src, tarfile.open(gz, "w:gz") as dst:
+        for mem in src.getmembers():
+            data = src.extractfile(mem).read()
+            mem.name = mem.name.lstrip("./")
+            import io
+            dst.addfile(mem, io.BytesIO(data))
+    r2 = DDPM.restore_from(gz)
+    assert all(torch.equal(a[k], r2.state_dict()[k]) for k in a)
+    with pytest.raises(FileNotFoundError):
+        with tarfile.open(str(tmp_path / "bad.nemo"), "w:") as t:
+            pass
+        DDPM.restore_from(str(tmp_path / "bad.nemo"))
