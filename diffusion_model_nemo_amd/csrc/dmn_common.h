@@ -30,6 +30,12 @@ template <> __device__ __forceinline__ float from_f32<float>(float v) { return v
 template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return (__bf16)v; }
 
 __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+// bf16 path: y = x*a + b as one fused multiply-add whatever the translation unit's contraction setting
+// (the fp32 parity path keeps the separate multiply and add of the reference's kernels).
+__device__ __forceinline__ float silu_affine_fast(float x, float a, float b, float c) {
+    const float y = __builtin_fmaf(x, a, b);
+    return __builtin_fmaf(y, __builtin_amdgcn_rcpf(1.0f + __expf(-y)), c);
+}
 // The fp32 parity path uses the full-precision exponential so SiLU agrees with the reference's
 // ATen kernel to rounding; the bf16 path may use the fast one.
 __device__ __forceinline__ float silu_precise(float v) { return v / (1.0f + expf(-v)); }

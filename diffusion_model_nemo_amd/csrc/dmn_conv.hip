@@ -207,13 +207,16 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
                     for (int e = 0; e < PER; ++e) {
                         float y = v.get(e);
-                        if (PRO) {
+                        if constexpr (PRO >= 2 && sizeof(T) == 2) {
+                            y = silu_affine_fast(y, ca[e], cb[e], PRO == 2 ? ct[e] : r2.get(e));
+                        } else if (PRO) {
                             y = y * ca[e] + cb[e];
-                            if (PRO == 2) y = ((sizeof(T) == 4) ? silu_precise(y) : silu_f(y)) + ct[e];
-                            if constexpr (PRO == 3) y = ((sizeof(T) == 4) ? silu_precise(y) : silu_f(y)) + r2.get(e);
+                            if (PRO == 2) y = silu_precise(y) + ct[e];
+                            if constexpr (PRO == 3) y = silu_precise(y) + r2.get(e);
                         }
-                        v.set(e, in ? y : 0.f);
+                        v.set(e, y);
                     }
+                    if (!in) v.v = V{};                  // padding is zero AFTER the prologue
                     if (pix < NPIX) *reinterpret_cast<V*>(sX + pix * rowB + part * 16) = v.v;
                     if constexpr (PRO == 3) {
                         // the tile's own pixels (not the halo) of the first channel slice materialise the block output

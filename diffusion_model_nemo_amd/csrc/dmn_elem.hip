@@ -77,9 +77,18 @@ __global__ void __launch_bounds__(kNormThreads) norm_apply_kernel(const NormAppl
             if (res) r.v = vres[j];
 #pragma unroll
             for (int e = 0; e < PER; ++e) {
-                float y = v.get(e) * ca[e] + cbeta[e];
-                if (a.norm.silu) y = (sizeof(T) == 4) ? silu_precise(y) : silu_f(y);
-                y += ct[e];
+                float y;
+                if constexpr (sizeof(T) == 2) {
+                    if (a.norm.silu) {
+                        y = silu_affine_fast(v.get(e), ca[e], cbeta[e], ct[e]);
+                    } else {
+                        y = __builtin_fmaf(v.get(e), ca[e], cbeta[e]) + ct[e];
+                    }
+                } else {
+                    y = v.get(e) * ca[e] + cbeta[e];
+                    if (a.norm.silu) y = silu_precise(y);
+                    y += ct[e];
+                }
                 if (res) y += r.get(e);
                 v.set(e, y);
                 const float yr = v.get(e);  // statistics of the value the consumer will read
@@ -317,41 +326,82 @@ __global__ void __launch_bounds__(256) ingest_time_kernel(const IngestArgs a, co
 // Egress: final_conv tail (modules/unet.py:112-116): [GroupNorm(groups) -> SiLU ->] 1x1 conv to 3 or 6
 // channels, written in the reference's NCHW fp32 layout. One pixel per thread.
 // ---------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int CO>   // CO > 0: compile-time output channels; CO == 0: a.Cout <= 8 at run time
 __global__ void __launch_bounds__(256) egress_kernel(const EgressArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sCoef = reinterpret_cast<float*>(smem);   // 3*C
     float* sW = sCoef + 3 * a.C;                     // Cout*C + Cout, then 2*G scratch
     const int b = blockIdx.y, C = a.C;
-    const bool norm = a.norm.stats != nullptr;
-    if (norm) norm_coefs_to_lds(a.norm, b, C, sCoef, sW);
-    for (int i = threadIdx.x; i < a.Cout * C; i += 256) sW[i] = a.w[i];
-    for (int i = threadIdx.x; i < a.Cout; i += 256) sW[a.Cout * C + i] = a.bias[i];
-    __syncthreads();
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= a.HW) return;
+    const int Cout = CO ? CO : a.Cout;
+    constexpr int NO = CO ? CO : 8;
     constexpr int PER = ElemTraits<T>::kPer16B;
+    constexpr int NVMAX = 8;                         // vectors of one pixel kept in registers (C <= 64 bf16 / 32 f32)
     using V = decltype(Vec16<T>::v);
-    float acc[8];
+    const bool norm = a.norm.stats != nullptr;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const bool live = p < a.HW;
+    const int nv = C / PER;
+    const T* in = static_cast<const T*>(a.in) + ((size_t)b * a.HW + (live ? p : 0)) * C;
+    // the pixel's channels are requested before the statistics round trip
+    V vin[NVMAX];
 #pragma unroll
-    for (int o = 0; o < 8; ++o) acc[o] = o < a.Cout ? sW[a.Cout * C + o] : 0.f;
-    const T* in = static_cast<const T*>(a.in) + ((size_t)b * a.HW + p) * C;
-    for (int cb = 0; cb < C; cb += PER) {
+    for (int j = 0; j < NVMAX; ++j)
+        if (j < nv) vin[j] = *reinterpret_cast<const V*>(in + j * PER);
+    if (norm) norm_coefs_to_lds(a.norm, b, C, sCoef, sW);
+    for (int i = threadIdx.x; i < Cout * C; i += 256) sW[i] = a.w[i];
+    for (int i = threadIdx.x; i < Cout; i += 256) sW[Cout * C + i] = a.bias[i];
+    __syncthreads();
+    if (!live) return;
+    float acc[NO];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) acc[o] = o < Cout ? sW[Cout * C + o] : 0.f;
+    auto consume = [&](const V& raw, int cb) {
         Vec16<T> v;
-        v.v = *reinterpret_cast<const V*>(in + cb);
+        v.v = raw;
+        float y[PER];
 #pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            float y = v.get(j);
+        for (int q = 0; q < PER; q += 4) {
+            f32x4 ca{1.f, 1.f, 1.f, 1.f}, cbeta{0.f, 0.f, 0.f, 0.f};
             if (norm) {
-                y = y * sCoef[cb + j] + sCoef[C + cb + j];
-                if (a.norm.silu) y = (sizeof(T) == 4) ? silu_precise(y) : silu_f(y);
+                ca = *reinterpret_cast<const f32x4*>(sCoef + cb + q);
+                cbeta = *reinterpret_cast<const f32x4*>(sCoef + C + cb + q);
             }
 #pragma unroll
-            for (int o = 0; o < 8; ++o)
-                if (o < a.Cout) acc[o] = fmaf(y, sW[o * C + cb + j], acc[o]);
+            for (int j = 0; j < 4; ++j) {
+                float x = v.get(q + j);
+                if (norm) {
+                    if constexpr (sizeof(T) == 2) {
+                        x = __builtin_fmaf(x, ca[j], cbeta[j]);
+                        if (a.norm.silu) x = silu_f(x);
+                    } else {
+                        x = x * ca[j] + cbeta[j];
+                        if (a.norm.silu) x = silu_precise(x);
+                    }
+                }
+                y[q + j] = x;
+            }
         }
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            if (CO == 0 && o >= Cout) break;
+#pragma unroll
+            for (int q = 0; q < PER; q += 4) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(sW + o * C + cb + q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[o] = fmaf(y[q + j], w[j], acc[o]);
+            }
+        }
+    };
+    if (nv <= NVMAX) {
+#pragma unroll
+        for (int j = 0; j < NVMAX; ++j)
+            if (j < nv) consume(vin[j], j * PER);
+    } else {
+        for (int cb = 0; cb < C; cb += PER) consume(*reinterpret_cast<const V*>(in + cb), cb);
     }
-    for (int o = 0; o < a.Cout; ++o) a.out[((size_t)b * a.Cout + o) * a.HW + p] = acc[o];
+#pragma unroll
+    for (int o = 0; o < NO; ++o)
+        if (o < Cout) a.out[((size_t)b * Cout + o) * a.HW + p] = acc[o];
 }
 
 }  // namespace
@@ -440,10 +490,23 @@ int launch_egress(EgressArgs& a, hipStream_t s) {
     DMN_REQUIRE(a.Cout >= 1 && a.Cout <= 8, DMN_ERR_LIMIT, "egress: Cout=%d (max 8)", a.Cout);
     const size_t lds = (3 * (size_t)a.C + (size_t)a.Cout * a.C + a.Cout + 2 * (size_t)(a.norm.stats ? a.norm.G : 0) + 16) * 4;
     dim3 grid((a.HW + 255) / 256, a.B);
-    if (a.dtype == DMN_F32)
-        hipLaunchKernelGGL(egress_kernel<float>, grid, dim3(256), lds, s, a);
-    else
-        hipLaunchKernelGGL(egress_kernel<__bf16>, grid, dim3(256), lds, s, a);
+    DMN_REQUIRE(a.C % 8 == 0, DMN_ERR_INVALID, "egress: C=%d must be a multiple of 8", a.C);
+#define DMN_EGRESS(T, CO) hipLaunchKernelGGL((egress_kernel<T, CO>), grid, dim3(256), lds, s, a)
+#define DMN_EGRESS_T(T)                                   \
+    switch (a.Cout) {                                     \
+        case 1: DMN_EGRESS(T, 1); break;                  \
+        case 2: DMN_EGRESS(T, 2); break;                  \
+        case 3: DMN_EGRESS(T, 3); break;                  \
+        case 6: DMN_EGRESS(T, 6); break;                  \
+        default: DMN_EGRESS(T, 0); break;                 \
+    }
+    if (a.dtype == DMN_F32) {
+        DMN_EGRESS_T(float)
+    } else {
+        DMN_EGRESS_T(__bf16)
+    }
+#undef DMN_EGRESS_T
+#undef DMN_EGRESS
     DMN_HIP_CHECK(hipGetLastError());
     return DMN_OK;
 }
