@@ -70,14 +70,36 @@ __device__ __forceinline__ void mma_step(const Vec16<float>& a, const Vec16<floa
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[3], b.v[3], acc, 0, 0, 0);
 }
 
+// Cross-lane moves inside an aligned row of 16 lanes as DPP modifiers (a few cycles) instead of LDS-routed
+// permutes (~100 cycles each). Every lane of the wave must be active.
+template <int CTRL> __device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+// Sum / max over each aligned row of 16 lanes; every lane of the row receives the same, order-fixed result.
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_move<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);   // row_half_mirror
+    v += dpp_move<0x140>(v);   // row_mirror
+    return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_move<0xB1>(v));
+    v = fmaxf(v, dpp_move<0x4E>(v));
+    v = fmaxf(v, dpp_move<0x141>(v));
+    v = fmaxf(v, dpp_move<0x140>(v));
+    return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v = row16_sum(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    v = row16_max(v);
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
     return v;
 }
 

@@ -149,23 +149,30 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
     V sr[SB];
     V sr2[PRO == 3 ? SB : 1];                       // residual operand of the fused block tail
     unsigned smask = 0;                             // bit j: unit j of the batch lies inside the image
+    // Branch-free on purpose: with short-circuit tests the compiler wraps every load in nested exec-mask regions
+    // that re-fetch kernel arguments, several hundred cycles of set-up per workgroup.
+    const int inH = a.H, inW = a.W, inC0 = a.C0, inC1 = a.C1;
+    const T* const in0p = static_cast<const T*>(a.in0);
+    const T* const in1p = static_cast<const T*>(a.in1);
+    const T* const resp3 = static_cast<const T*>(a.pro_res);
     auto stage_issue = [&](int cg0, int j0) {
         const int c = cg0 + part * PER;
-        const bool first = c < a.C0;
-        const T* src = static_cast<const T*>(first ? a.in0 : a.in1);
-        const int cs = first ? c : c - a.C0, Csrc = first ? a.C0 : a.C1;
+        const bool first = c < inC0;
+        const T* src = first ? in0p : in1p;
+        const unsigned cs = first ? c : c - inC0, Csrc = first ? inC0 : inC1;
         smask = 0;
 #pragma unroll
         for (int j = 0; j < SB; ++j) {
             const int pix = (tid + 256 * (j0 + j)) >> lgu;
             const int ly = pix / IW, lx = pix - ly * IW;
             const int gy = iy0 + ly, gx = ix0 + lx;
-            const bool in = pix < NPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            smask |= in ? 1u << j : 0u;
-            // slots outside the image read pixel 0 (always mapped) and are zeroed when written: no branch here
-            const unsigned off = in ? (unsigned)((b * a.H + gy) * a.W + gx) * (unsigned)Csrc + (unsigned)cs : (unsigned)cs;
+            const bool in = (pix < NPIX) & ((unsigned)gy < (unsigned)inH) & ((unsigned)gx < (unsigned)inW);
+            smask |= (unsigned)in << j;
+            // slots outside the image read pixel 0 (always mapped) and are zeroed when written
+            const unsigned poff = (unsigned)((b * inH + gy) * inW + gx) * Csrc + cs;
+            const unsigned off = in ? poff : cs;
             sr[j] = *reinterpret_cast<const V*>(src + off);
-            if constexpr (PRO == 3) sr2[j] = *reinterpret_cast<const V*>(static_cast<const T*>(a.pro_res) + off);
+            if constexpr (PRO == 3) sr2[j] = *reinterpret_cast<const V*>(resp3 + off);
         }
     };
     stage_issue(0, 0);
@@ -368,11 +375,8 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
             // reduce over the 16 pixel lanes; lane (lane&15)==0 of each quarter holds the sums of a 4-channel quad
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) {
-                    ssum[nt] += __shfl_xor(ssum[nt], o, 64);
-                    ssq[nt] += __shfl_xor(ssq[nt], o, 64);
-                }
+                ssum[nt] = row16_sum(ssum[nt]);
+                ssq[nt] = row16_sum(ssq[nt]);
                 if (l15 == 0) {
                     const int quad = (wn * NT + nt) * 4 + lq;  // local quad index in [0, BN/4)
                     sRed[(wm * (BN / 4) + quad) * 2] = ssum[nt];

@@ -23,7 +23,7 @@ __device__ __forceinline__ void norm_coefs_to_lds(const NormIn& n, int b, int C,
     }
     // Statistics: a wave reduces 64 / seg groups at once, seg lanes per group (seg = 16, 32 or 64 >= slots when
     // possible), so the slot loads of all its groups are in flight together. Lanes stride over the slots, then a
-    // fixed-order butterfly inside the segment: deterministic.
+    // fixed-order butterfly inside the segment (DPP inside rows of 16 lanes): deterministic.
     const int wave = tid >> 6, lane = tid & 63, nwaves = nthr >> 6;
     const int seg = n.slots <= 16 ? 16 : n.slots <= 32 ? 32 : 64;
     const int gpw = 64 / seg;
@@ -39,9 +39,15 @@ __device__ __forceinline__ void norm_coefs_to_lds(const NormIn& n, int b, int C,
                 ss += v.y;
             }
         }
-        for (int o = seg >> 1; o > 0; o >>= 1) {
-            s += __shfl_xor(s, o, 64);
-            ss += __shfl_xor(ss, o, 64);
+        s = row16_sum(s);
+        ss = row16_sum(ss);
+        if (seg >= 32) {
+            s += __shfl_xor(s, 16, 64);
+            ss += __shfl_xor(ss, 16, 64);
+        }
+        if (seg == 64) {
+            s += __shfl_xor(s, 32, 64);
+            ss += __shfl_xor(ss, 32, 64);
         }
         if (sl == 0 && g < n.G) {
             const float mean = s * n.inv_count;

@@ -57,7 +57,13 @@ def run(name, B, H, W, cin, cout, k, stride, pad, transposed, pro, epi_G, dtype=
     life = (d[:, 5] - d[:, 0]) / 100.0
     cyc_per_us = np.median((d[:, 4] - d[:, 7]) / np.maximum(life, 0.01))
     med = np.median(ph, 0)
-    starts = np.sort((d[:, 0] - d[:, 0].min()) / 100.0)
+    st0 = (d[:, 0] - d[:, 0].min()) / 100.0
+    starts = np.sort(st0)
+    if starts[-1] > 3.0:   # more than one residency round: medians of the first and of the later workgroups
+        for nm, sel in (("first round", st0 < 1.5), ("later rounds", st0 >= 1.5)):
+            m = np.median(ph[sel], 0)
+            print(f"    {nm:13s} wgs={int(sel.sum()):5d} coef={m[0]:6.0f} stage={m[1]:6.0f} mfma={m[2]:6.0f} epi={m[3]:6.0f} "
+                  f"total={m[4]:6.0f}  life={np.median(life[sel]):5.1f}us")
     print(f"{name:34s} wgs={nwg:5d} span={wall:6.1f}us  wg life med={np.median(life):5.1f}us  cycles: coef={med[0]:6.0f} "
           f"stage={med[1]:6.0f} mfma={med[2]:6.0f} epi={med[3]:6.0f} total={med[4]:6.0f}  (~{cyc_per_us:.0f} cyc/us) "
           f"last start={starts[-1]:.1f}us")
