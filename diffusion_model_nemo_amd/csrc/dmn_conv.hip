@@ -112,13 +112,16 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
     }
     V w[RS][NT];
     const int nflat = KS * NTAPS;                   // fragments per output-channel tile
+    // Unconditional on purpose (past the end the last fragment is fetched again and never used): with a branch
+    // around the load the compiler can no longer count the loads in flight and waits for ALL of them
+    // (vmcnt(0)) before every use, which serialises the ring on the L2 latency.
     auto ring_fill = [&](int slot, int flat) {
+        const int f = flat < nflat ? flat : nflat - 1;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) w[slot][nt] = *reinterpret_cast<const V*>(wfrag[nt] + (size_t)flat * 64 * PER);
+        for (int nt = 0; nt < NT; ++nt) w[slot][nt] = *reinterpret_cast<const V*>(wfrag[nt] + (size_t)f * 64 * PER);
     };
 #pragma unroll
-    for (int e = 0; e < RS; ++e)
-        if (e < nflat) ring_fill(e, e);
+    for (int e = 0; e < RS; ++e) ring_fill(e, e);
 
     f32x4 bias[NT];
 #pragma unroll
@@ -284,13 +287,13 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
                                 w2.v = w2v[nt];
 #pragma unroll
                                 for (int mt = 0; mt < MT; ++mt) mma_step(w2, xf[XB == 2 ? (e & 1) : 0][mt], acc2[mt][nt]);
-                                if (ksbase + ksl + 1 < KS)
-                                    w2v[nt] = *reinterpret_cast<const V*>(w2frag[nt] + (size_t)(ksbase + ksl + 1) * 64 * PER);
+                                const int ksn = ksbase + ksl + 1 < KS ? ksbase + ksl + 1 : KS - 1;   // unconditional, as the ring
+                                w2v[nt] = *reinterpret_cast<const V*>(w2frag[nt] + (size_t)ksn * 64 * PER);
                             }
                         }
                     }
                 }
-                if (flat0 + e + RS < nflat) ring_fill(e % RS, flat0 + e + RS);   // the slot just consumed
+                ring_fill(e % RS, flat0 + e + RS);   // the slot just consumed
                 __builtin_amdgcn_sched_barrier(0);   // keep later taps' LDS reads from piling up in registers
             }
         }
