@@ -37,7 +37,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIB_DIR, exist_ok=True)
     hdr_time = _newest_header()
     flags = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
-             "-ffp-contract=off"]
+             "-ffp-contract=off", "-fno-honor-nans"]
     jobs = []
     objs = []
     for src in SOURCES:

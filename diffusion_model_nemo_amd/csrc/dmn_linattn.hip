@@ -18,6 +18,8 @@
 #include "dmn_kernels.h"
 #include "dmn_norm.h"
 
+#include <type_traits>
+
 namespace {
 
 // optional phase timestamps (tuning aid): slot 0 wall clock at start, 7 cycle counter at start, 1..4 cycle counter at
@@ -176,35 +178,42 @@ __global__ void __launch_bounds__(256) la_fused_ctx_kernel(const LinAttnFusedArg
     };
 
     // ---- sweep 1: per-channel maximum of k over the slice ------------------------------------------------
+    // A slice that lies wholly inside the image (every size the network produces) takes the unmasked bodies.
+    const bool full = p0 + slice <= a.n;
     float mx[2] = {-INFINITY, -INFINITY};
+    auto sweep1 = [&](auto masked_t) {
+        constexpr bool MASKED = decltype(masked_t)::value;
 #pragma unroll 2
-    for (int pp = 0; pp < npt; pp += 2) {
-        f32x4 kacc[2][2];
+        for (int pp = 0; pp < npt; pp += 2) {
+            f32x4 kacc[2][2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) kacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < 2; ++j) kacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const Vec16<T> k0 = kfrag(0, ks), k1 = kfrag(1, ks);
+            for (int ks = 0; ks < KS; ++ks) {
+                const Vec16<T> k0 = kfrag(0, ks), k1 = kfrag(1, ks);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                Vec16<T> xf;
-                xf.v = *reinterpret_cast<const V*>(sX + (size_t)((pp + i) * 16 + l15) * row_bytes + lq * 16 + ks * 64);
-                mma_step(xf, k0, kacc[i][0]);     // D[px][cout]
-                mma_step(xf, k1, kacc[i][1]);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool valid = p0 + (pp + i) * 16 + lq * 4 + r < a.n;
-                    mx[ct] = valid ? fmaxf(mx[ct], kacc[i][ct][r]) : mx[ct];
+                for (int i = 0; i < 2; ++i) {
+                    Vec16<T> xf;
+                    xf.v = *reinterpret_cast<const V*>(sX + (size_t)((pp + i) * 16 + l15) * row_bytes + lq * 16 + ks * 64);
+                    mma_step(xf, k0, kacc[i][0]);     // D[px][cout]
+                    mma_step(xf, k1, kacc[i][1]);
                 }
-    }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool valid = !MASKED || p0 + (pp + i) * 16 + lq * 4 + r < a.n;
+                        mx[ct] = valid ? fmaxf(mx[ct], kacc[i][ct][r]) : mx[ct];
+                    }
+        }
+    };
+    if (full) sweep1(std::false_type{});
+    else sweep1(std::true_type{});
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
         mx[ct] = fmaxf(mx[ct], __shfl_xor(mx[ct], 16, 64));
@@ -218,65 +227,74 @@ __global__ void __launch_bounds__(256) la_fused_ctx_kernel(const LinAttnFusedArg
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) ctx[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float zs[2] = {0.f, 0.f};
+    // The softmax denominators come from the matrix pipe too (P against a matrix of ones): row d of zacc holds Z[d]
+    // in the same lanes and registers as row d of the ctx tiles.
+    f32x4 zacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    Vec16<T> ones;
+#pragma unroll
+    for (int e = 0; e < ElemTraits<T>::kPer16B; ++e) ones.set(e, 1.0f);
+    // exp(k - max) as exp2(k * log2(e) - max * log2(e)): one fused multiply-add ahead of the transcendental
+    constexpr float kLog2e = 1.4426950408889634f;
+    const float mxl[2] = {mx[0] * kLog2e, mx[1] * kLog2e};
+    auto sweep2 = [&](auto masked_t) {
+        constexpr bool MASKED = decltype(masked_t)::value;
 #pragma unroll 2
-    for (int pp = 0; pp < npt; pp += 2) {        // 32 pixels = one bf16 k-step (two f32 k-steps)
-        f32x4 kacc[2][2], vacc[2][2];             // [pixel tile of the pair][channel tile]
+        for (int pp = 0; pp < npt; pp += 2) {        // 32 pixels = one bf16 k-step (two f32 k-steps)
+            f32x4 kacc[2][2], vacc[2][2];             // [pixel tile of the pair][channel tile]
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) kacc[i][j] = vacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < 2; ++j) kacc[i][j] = vacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const Vec16<T> k0 = kfrag(0, ks), k1 = kfrag(1, ks), v0 = vfrag(0, ks), v1 = vfrag(1, ks);
+            for (int ks = 0; ks < KS; ++ks) {
+                const Vec16<T> k0 = kfrag(0, ks), k1 = kfrag(1, ks), v0 = vfrag(0, ks), v1 = vfrag(1, ks);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                Vec16<T> xf;
-                xf.v = *reinterpret_cast<const V*>(sX + (size_t)((pp + i) * 16 + l15) * row_bytes + lq * 16 + ks * 64);
-                mma_step(xf, k0, kacc[i][0]);
-                mma_step(xf, k1, kacc[i][1]);
-                mma_step(xf, v0, vacc[i][0]);
-                mma_step(xf, v1, vacc[i][1]);
+                for (int i = 0; i < 2; ++i) {
+                    Vec16<T> xf;
+                    xf.v = *reinterpret_cast<const V*>(sX + (size_t)((pp + i) * 16 + l15) * row_bytes + lq * 16 + ks * 64);
+                    mma_step(xf, k0, kacc[i][0]);
+                    mma_step(xf, k1, kacc[i][1]);
+                    mma_step(xf, v0, vacc[i][0]);
+                    mma_step(xf, v1, vacc[i][1]);
+                }
             }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool valid = !MASKED || p0 + (pp + i) * 16 + lq * 4 + r < a.n;
+                        float e;
+                        if constexpr (sizeof(T) == 4) e = expf(kacc[i][ct][r] - mx[ct]);
+                        else e = __builtin_amdgcn_exp2f(__builtin_fmaf(kacc[i][ct][r], kLog2e, -mxl[ct]));
+                        kacc[i][ct][r] = valid ? e : 0.f;
+                    }
+#pragma unroll
+            for (int sub = 0; sub < SUB; ++sub)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const Vec16<T> pa = acc_operand(kacc[0][dt], kacc[1][dt], sub, (T*)nullptr);   // A[d][k = px]
+                    mma_step(pa, ones, zacc[dt]);     // Z[d] = sum_px P[px][d], in every column of row d
+#pragma unroll
+                    for (int et = 0; et < 2; ++et) {
+                        const Vec16<T> vb = acc_operand(vacc[0][et], vacc[1][et], sub, (T*)nullptr);   // B[k = px][e]
+                        mma_step(pa, vb, ctx[dt][et]);
+                    }
+                }
         }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool valid = p0 + (pp + i) * 16 + lq * 4 + r < a.n;
-                    const float e = valid ? ((sizeof(T) == 4) ? expf(kacc[i][ct][r] - mx[ct]) : __expf(kacc[i][ct][r] - mx[ct])) : 0.f;
-                    kacc[i][ct][r] = e;
-                    zs[ct] += e;
-                }
-#pragma unroll
-        for (int sub = 0; sub < SUB; ++sub)
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                const Vec16<T> pa = acc_operand(kacc[0][dt], kacc[1][dt], sub, (T*)nullptr);   // A[d][k = px]
-#pragma unroll
-                for (int et = 0; et < 2; ++et) {
-                    const Vec16<T> vb = acc_operand(vacc[0][et], vacc[1][et], sub, (T*)nullptr);   // B[k = px][e]
-                    mma_step(pa, vb, ctx[dt][et]);
-                }
-            }
-    }
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-        zs[ct] += __shfl_xor(zs[ct], 16, 64);
-        zs[ct] += __shfl_xor(zs[ct], 32, 64);
-    }
+    };
+    if (full) sweep2(std::false_type{});
+    else sweep2(std::true_type{});
     if (a.splits == 1) {
-        // the slice is the whole image: normalise, scale and transpose here. Row d of an accumulator tile needs
-        // 1 / Z[d], which lives in the lanes whose column index is d.
+        // the slice is the whole image: normalise, scale and transpose here
         T* out = static_cast<T*>(a.ctxT) + ((size_t)b * kHeads + h) * kD * kD;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int d = dt * 16 + lq * 4 + r;
-                const float inv = 0.17677669529663687f / __shfl(zs[dt], lq * 4 + r, 64);
+                const float inv = 0.17677669529663687f / zacc[dt][r];
                 const int pos = sizeof(T) == 4 ? d : ((d & 15) >> 2) * 8 + (d >> 4) * 4 + (d & 3);   // inverse of perm32
 #pragma unroll
                 for (int et = 0; et < 2; ++et) out[(et * 16 + l15) * kD + pos] = from_f32<T>(ctx[dt][et][r] * inv);
@@ -291,10 +309,13 @@ __global__ void __launch_bounds__(256) la_fused_ctx_kernel(const LinAttnFusedArg
                 for (int r = 0; r < 4; ++r) dst[(dt * 16 + lq * 4 + r) * kD + et * 16 + l15] = ctx[dt][et][r];
         if (lq == 0) {
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-                dst[kD * kD + ct * 16 + l15] = mx[ct];
-                dst[kD * kD + kD + ct * 16 + l15] = zs[ct];
-            }
+            for (int ct = 0; ct < 2; ++ct) dst[kD * kD + ct * 16 + l15] = mx[ct];
+        }
+        if (l15 == 0) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[kD * kD + kD + dt * 16 + lq * 4 + r] = zacc[dt][r];
         }
     }
     LA_STAMP(a.dbg, 4)
@@ -425,6 +446,9 @@ __global__ void __launch_bounds__(256) la_fused_out_kernel(const LinAttnFusedArg
         for (int sub = 0; sub < SUB; ++sub)
             cf[et][sub].v = *reinterpret_cast<const V*>(sCtx + (size_t)(wave * kD + et * 16 + l15) * CTX_ROW + sub * 64 + lq * 16);
 
+    Vec16<T> ones;
+#pragma unroll
+    for (int e = 0; e < ElemTraits<T>::kPer16B; ++e) ones.set(e, 1.0f);
     float ssum = 0.f, ssq = 0.f;
     T* yout = static_cast<T*>(a.y) + (size_t)b * a.n * C;
     for (int g = 0; g < a.tpw; ++g) {
@@ -458,28 +482,52 @@ __global__ void __launch_bounds__(256) la_fused_out_kernel(const LinAttnFusedArg
             for (int r = 0; r < 4; ++r) m = fmaxf(m, fmaxf(q[pt][0][r], q[pt][1][r]));
             m = fmaxf(m, __shfl_xor(m, 16, 64));
             m = fmaxf(m, __shfl_xor(m, 32, 64));
-            float s = 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                q[pt][0][r] = (sizeof(T) == 4) ? expf(q[pt][0][r] - m) : __expf(q[pt][0][r] - m);
-                q[pt][1][r] = (sizeof(T) == 4) ? expf(q[pt][1][r] - m) : __expf(q[pt][1][r] - m);
-                s += q[pt][0][r] + q[pt][1][r];
-            }
-            s += __shfl_xor(s, 16, 64);
-            s += __shfl_xor(s, 32, 64);
-            const float inv = 1.0f / s;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                q[pt][0][r] *= inv;
-                q[pt][1][r] *= inv;
-            }
-            // out[e][px] = sum_d ctx[d][e] q[d][px]
             f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            if constexpr (sizeof(T) == 4) {
+                float s = 0.f;
 #pragma unroll
-            for (int sub = 0; sub < SUB; ++sub) {
-                const Vec16<T> qb = acc_operand(q[pt][0], q[pt][1], sub, (T*)nullptr);
-                mma_step(cf[0][sub], qb, o[0]);
-                mma_step(cf[1][sub], qb, o[1]);
+                for (int r = 0; r < 4; ++r) {
+                    q[pt][0][r] = expf(q[pt][0][r] - m);
+                    q[pt][1][r] = expf(q[pt][1][r] - m);
+                    s += q[pt][0][r] + q[pt][1][r];
+                }
+                s += __shfl_xor(s, 16, 64);
+                s += __shfl_xor(s, 32, 64);
+                const float inv = 1.0f / s;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    q[pt][0][r] *= inv;
+                    q[pt][1][r] *= inv;
+                }
+                // out[e][px] = sum_d ctx[d][e] q[d][px]
+#pragma unroll
+                for (int sub = 0; sub < SUB; ++sub) {
+                    const Vec16<T> qb = acc_operand(q[pt][0], q[pt][1], sub, (T*)nullptr);
+                    mma_step(cf[0][sub], qb, o[0]);
+                    mma_step(cf[1][sub], qb, o[1]);
+                }
+            } else {
+                // bf16: exp2 with the log2(e) factor folded into one fma; the softmax denominator is a third MFMA of
+                // the same operand against a matrix of ones (the sum over d of exactly the bf16 values the
+                // numerator uses, delivered to every lane of the pixel: no cross-lane traffic), applied after.
+                constexpr float kLog2e = 1.4426950408889634f;
+                const float ml = m * kLog2e;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    q[pt][0][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(q[pt][0][r], kLog2e, -ml));
+                    q[pt][1][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(q[pt][1][r], kLog2e, -ml));
+                }
+                const Vec16<T> qb = acc_operand(q[pt][0], q[pt][1], 0, (T*)nullptr);
+                f32x4 den = f32x4{0.f, 0.f, 0.f, 0.f};
+                mma_step(cf[0][0], qb, o[0]);
+                mma_step(cf[1][0], qb, o[1]);
+                mma_step(ones, qb, den);
+                const float inv = __builtin_amdgcn_rcpf(den[0]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    o[0][r] *= inv;
+                    o[1][r] *= inv;
+                }
             }
             // lane: pixel l15, channels e = et*16 + 4*lq .. +3 -> k-major row of the pixel
 #pragma unroll
