@@ -38,6 +38,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hdr_time = _newest_header()
     flags = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
              "-ffp-contract=off", "-fno-honor-nans"]
+    # Kernels whose MFMA accumulators feed VALU code inside the loop (softmax, operand re-packing): MFMA results in
+    # plain VGPRs, or the compiler shuttles them through the accumulator file and back on every iteration.
+    extra = {"dmn_linattn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "dmn_attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
     jobs = []
     objs = []
     for src in SOURCES:
@@ -45,7 +48,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         op = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
         objs.append(op)
         if force or not os.path.exists(op) or os.path.getmtime(op) < max(os.path.getmtime(sp), hdr_time):
-            cmd = [hipcc, *flags, "-x", "hip", "-c", sp, "-o", op]
+            cmd = [hipcc, *flags, *extra.get(src, []), "-x", "hip", "-c", sp, "-o", op]
             jobs.append(cmd)
 
     def run(cmd):
