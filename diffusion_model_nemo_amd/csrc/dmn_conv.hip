@@ -67,7 +67,8 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
     constexpr int PER = ElemTraits<T>::kPer16B;
     constexpr int IH = (TH - 1) * S + KT::EXT, IW = (TW - 1) * S + KT::EXT;
     constexpr int NPIX = IH * IW;
-    constexpr int SB = 6;                           // staging loads in flight per thread
+    constexpr int SB = TH == 8 ? 8 : 6;             // staging loads in flight per thread (8x8 tiles: 100 halo pixels of
+                                                    // 128 / 256 channels are 7 / 13 units per thread: one / two batches)
     using V = decltype(Vec16<T>::v);
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
