@@ -308,13 +308,19 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
         for (int nt = 0; nt < NT; ++nt) ssum[nt] = ssq[nt] = 0.f;
         T* outp = static_cast<T*>(a.out);
         const T* resp = static_cast<const T*>(a.res);
+        // Output offsets in 32 bits (the launcher bounds the tensor), linear in mt: pixel tile mt of the wave lies
+        // ROWS rows below tile 0 at the same column, so one scalar stride replaces the per-tile multiplications.
+        constexpr int ROWS = 16 / TW;
+        const int prow = (wm * MT * 16 + l15) / TW, pcol = (wm * MT * 16 + l15) % TW;
+        const int oyt0 = tile_y * TH + prow, oxt = tile_x * TW + pcol;
+        const unsigned obase0 = (unsigned)((b * a.out_H + oyt0 * a.out_sy + P.out_oy) * a.out_W + oxt * a.out_sx + P.out_ox) *
+                                (unsigned)a.Cout;
+        const unsigned ostep = (unsigned)(ROWS * a.out_sy * a.out_W) * (unsigned)a.Cout;
+        const bool col_ok = oxt < a.Wo;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int p = (wm * MT + mt) * 16 + l15;
-            const int oyt = tile_y * TH + p / TW, oxt = tile_x * TW + p % TW;
-            const bool valid = oyt < a.Ho && oxt < a.Wo;
-            const int oy = oyt * a.out_sy + P.out_oy, ox = oxt * a.out_sx + P.out_ox;
-            const size_t obase = ((size_t)(b * a.out_H + oy) * a.out_W + ox) * a.Cout;
+            const bool valid = col_ok && oyt0 + mt * ROWS < a.Ho;
+            const unsigned obase = obase0 + (unsigned)mt * ostep;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int n = n0 + (wn * NT + nt) * 16 + lq * 4;
@@ -359,10 +365,9 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
                 const f32x4 b2 = *reinterpret_cast<const f32x4*>(a.bias2 + n);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    const int p = (wm * MT + mt) * 16 + l15;
-                    const int oyt = tile_y * TH + p / TW, oxt = tile_x * TW + p % TW;
-                    if (oyt < a.Ho && oxt < a.Wo) {
-                        const size_t o = ((size_t)(b * a.out_H + oyt) * a.out_W + oxt) * a.Cout + n;
+                    if (col_ok && oyt0 + mt * ROWS < a.Ho) {
+                        // the shortcut is a stride-1 convolution: its output grid is the input grid
+                        const unsigned o = (unsigned)((b * a.out_H + oyt0 + mt * ROWS) * a.out_W + oxt) * (unsigned)a.Cout + n;
                         if constexpr (sizeof(T) == 4) {
                             *reinterpret_cast<f32x4*>(out2 + o) = acc2[mt][nt] + b2;
                         } else {
@@ -628,6 +633,7 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
     while ((1 << a.lg_upp) < upp) ++a.lg_upp;
     DMN_REQUIRE((long long)a.B * a.H * a.W * (a.C0 > a.C1 ? a.C0 : a.C1) < (1ll << 31), DMN_ERR_LIMIT,
                 "conv: input tensor beyond 2^31 elements");
+    DMN_REQUIRE((long long)a.B * a.out_H * a.out_W * a.Cout < (1ll << 31), DMN_ERR_LIMIT, "conv: output tensor beyond 2^31 elements");
     if (a.pro.stats) DMN_REQUIRE(Cin <= 1024, DMN_ERR_LIMIT, "conv: input normalisation limited to 1024 channels");
     const size_t lds = lds_bytes(a, c, a.cg);
     DMN_REQUIRE(lds <= 160 * 1024, DMN_ERR_INVALID, "conv: LDS request %zu too large", lds);
