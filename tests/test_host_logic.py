@@ -225,3 +225,40 @@ def test_nemo_archive_round_trip(tmp_path):
         with tarfile.open(str(tmp_path / "bad.nemo"), "w:") as t:
             pass
         DDPM.restore_from(str(tmp_path / "bad.nemo"))
+
+
+def test_pixel_values_adapter_round_trip():
+    """Image column -> `pixel_values` in [-1, 1] (CHW float32), image column dropped; flip only in train mode; reverse
+    transform gives the uint8 HWC image back (data/hf_vision_data.py:14-54,77-97)."""
+    from diffusion_model_nemo_amd import data as D
+    rng = np.random.default_rng(0)
+    imgs = [rng.integers(0, 256, size=(12, 10, 3), dtype=np.uint8) for _ in range(4)]
+    ex = D.test_transforms({"img": list(imgs), "label": [1, 2, 3, 4]})
+    assert "img" not in ex and len(ex["pixel_values"]) == 4
+    pv = ex["pixel_values"][0]
+    assert pv.dtype == torch.float32 and tuple(pv.shape) == (3, 12, 10)
+    np.testing.assert_allclose(pv.numpy(), imgs[0].transpose(2, 0, 1) / 255.0 * 2 - 1, atol=1e-6)
+    back = D.get_reverse_transform(uint=True, as_pil=False)(pv)
+    assert back.dtype == np.uint8 and np.abs(back.astype(int) - imgs[0].astype(int)).max() <= 1
+    # grey-scale (HW) images get a channel axis; train mode flips some images left-right and nothing else
+    g = torch.Generator().manual_seed(3)
+    grey = [rng.integers(0, 256, size=(8, 8), dtype=np.uint8) for _ in range(16)]
+    tr = D.train_transforms({"image": list(grey)}, generator=g)["pixel_values"]
+    flipped = 0
+    for t, src in zip(tr, grey):
+        ref = torch.from_numpy(src).float()[None] / 255.0 * 2 - 1
+        assert tuple(t.shape) == (1, 8, 8)
+        if torch.equal(t, ref):
+            continue
+        assert torch.equal(t, ref.flip(-1))
+        flipped += 1
+    assert 0 < flipped < 16
+    with pytest.raises(ValueError):
+        D.test_transforms({"picture": []})
+    ds = D.PixelValuesDataset({"img": imgs, "label": [0, 1, 2, 3]}, mode="test")
+    batch = D.collate_pixel_values([ds[i] for i in range(len(ds))])
+    assert tuple(batch["pixel_values"].shape) == (4, 3, 12, 10) and batch["label"].tolist() == [0, 1, 2, 3]
+    assert float(batch["pixel_values"].min()) >= -1.0 and float(batch["pixel_values"].max()) <= 1.0
+    # resize (shorter side) + centre crop to a square network input
+    t = D.get_transform(8, center_crop=True)(imgs[0])
+    assert tuple(t.shape) == (3, 8, 8)
