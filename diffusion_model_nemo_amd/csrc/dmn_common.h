@@ -55,6 +55,18 @@ template <> struct Vec16<__bf16> {
     __device__ __forceinline__ void set(int i, float x) { v[i] = (__bf16)x; }
 };
 
+// Streaming store of a 16-byte (or 8-byte) vector: written through the L2 instead of left dirty in it. Every kernel
+// here produces a tensor that the NEXT launch reads, possibly from another XCD, so the data has to reach memory
+// before the kernel can retire; written through, that drain overlaps the kernel instead of extending its end.
+template <typename V> __device__ __forceinline__ void store_stream(V* dst, const V& v) {
+    if constexpr (sizeof(V) == 16) {
+        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(dst));
+    } else {
+        static_assert(sizeof(V) == 8, "8- or 16-byte vectors");
+        __builtin_nontemporal_store(__builtin_bit_cast(u32x2, v), reinterpret_cast<u32x2*>(dst));
+    }
+}
+
 // One k-step of the 16x16 MFMA on two 16-byte fragments: D += A(16 x k) * B(k x 16).
 // bf16: a single v_mfma_f32_16x16x32_bf16 (lane holds k = 8*(lane>>4) .. +7).
 // f32 : four v_mfma_f32_16x16x4_f32; lane group g = lane>>4 holds channels 4g..4g+3 of a 16-channel

@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
                         const int ly = pix / IW, lx = pix - ly * IW;
                         if (in && blockIdx.y == 0 && ly >= P.pad_y && ly < P.pad_y + TH && lx >= P.pad_x && lx < P.pad_x + TW) {
                             const unsigned off = (unsigned)((b * a.H + iy0 + ly) * a.W + ix0 + lx) * (unsigned)a.C0 + (unsigned)c;
-                            *reinterpret_cast<V*>(static_cast<T*>(a.pro_out) + off) = v.v;
+                            store_stream(reinterpret_cast<V*>(static_cast<T*>(a.pro_out) + off), v.v);
                         }
                     }
                 }
@@ -346,13 +346,19 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
                             for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
                         }
                     }
+                    // the sub-pixel phases of the transposed convolution interleave their pixels: those partial
+                    // lines are left to merge in the L2, everything else streams out
+                    constexpr bool STREAM = KIND != DMN_KT2X2;
                     if constexpr (sizeof(T) == 4) {
-                        *reinterpret_cast<f32x4*>(outp + obase + n) = f32x4{v[0], v[1], v[2], v[3]};
+                        const f32x4 o = f32x4{v[0], v[1], v[2], v[3]};
+                        if constexpr (STREAM) store_stream(reinterpret_cast<f32x4*>(outp + obase + n), o);
+                        else *reinterpret_cast<f32x4*>(outp + obase + n) = o;
                     } else {
                         bf16x4 o;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) o[r] = (__bf16)v[r];
-                        *reinterpret_cast<bf16x4*>(outp + obase + n) = o;
+                        if constexpr (STREAM) store_stream(reinterpret_cast<bf16x4*>(outp + obase + n), o);
+                        else *reinterpret_cast<bf16x4*>(outp + obase + n) = o;
                     }
                 }
             }
@@ -369,12 +375,12 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
                         // the shortcut is a stride-1 convolution: its output grid is the input grid
                         const unsigned o = (unsigned)((b * a.out_H + oyt0 + mt * ROWS) * a.out_W + oxt) * (unsigned)a.Cout + n;
                         if constexpr (sizeof(T) == 4) {
-                            *reinterpret_cast<f32x4*>(out2 + o) = acc2[mt][nt] + b2;
+                            store_stream(reinterpret_cast<f32x4*>(out2 + o), acc2[mt][nt] + b2);
                         } else {
                             bf16x4 ov;
 #pragma unroll
                             for (int r = 0; r < 4; ++r) ov[r] = (__bf16)(acc2[mt][nt][r] + b2[r]);
-                            *reinterpret_cast<bf16x4*>(out2 + o) = ov;
+                            store_stream(reinterpret_cast<bf16x4*>(out2 + o), ov);
                         }
                     }
                 }

@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(kNormThreads) norm_apply_kernel(const NormAppl
                 s[e / 4] += yr;
                 ss[e / 4] += yr * yr;
             }
-            *reinterpret_cast<V*>(out + (size_t)i * PER) = v.v;
+            store_stream(reinterpret_cast<V*>(out + (size_t)i * PER), v.v);
         }
     }
     if (want) {
@@ -300,7 +300,7 @@ __device__ __forceinline__ void ingest_mfma_body(const IngestArgs& a, int bx, in
                 bf16x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = (__bf16)acc[r][nt][j];
-                *reinterpret_cast<bf16x4*>(dst + nt * 16 + lq * 4) = o;
+                store_stream(reinterpret_cast<bf16x4*>(dst + nt * 16 + lq * 4), o);
             }
         }
     }

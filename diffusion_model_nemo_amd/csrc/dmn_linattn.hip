@@ -575,12 +575,12 @@ __global__ void __launch_bounds__(256) la_fused_out_kernel(const LinAttnFusedArg
                         ssq += v[r] * v[r];
                     }
                     if constexpr (sizeof(T) == 4) {
-                        *reinterpret_cast<f32x4*>(yout + (size_t)px * C + c) = f32x4{v[0], v[1], v[2], v[3]};
+                        store_stream(reinterpret_cast<f32x4*>(yout + (size_t)px * C + c), f32x4{v[0], v[1], v[2], v[3]});
                     } else {
                         bf16x4 ov;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) ov[r] = (__bf16)v[r];
-                        *reinterpret_cast<bf16x4*>(yout + (size_t)px * C + c) = ov;
+                        store_stream(reinterpret_cast<bf16x4*>(yout + (size_t)px * C + c), ov);
                     }
                 }
             }
