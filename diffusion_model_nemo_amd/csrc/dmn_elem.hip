@@ -401,7 +401,7 @@ __global__ void __launch_bounds__(256) egress_kernel(const EgressArgs a) {
     }
 #pragma unroll
     for (int o = 0; o < NO; ++o)
-        if (o < Cout) a.out[((size_t)b * Cout + o) * a.HW + p] = acc[o];
+        if (o < Cout) __builtin_nontemporal_store(acc[o], &a.out[((size_t)b * Cout + o) * a.HW + p]);
 }
 
 }  // namespace
