@@ -36,6 +36,7 @@ extern "C" int dmn_ddpm_step(const float* table, int row, const float* x, const 
                              int64_t img_offset, void* stream) {
     DMN_REQUIRE(table && x && model_out && x_out && row >= 0, DMN_ERR_INVALID, "dmn_ddpm_step: null argument");
     DdpmStepArgs a;
+    a.step_next = nullptr;
     a.c = step_common(table, nullptr, row, x, model_out, noise, x_out, B, C, H * W, seed, img_offset, nullptr);
     a.learned_variance = learned_variance;
     a.pred_x0 = pred_x0 & 1;
@@ -196,13 +197,19 @@ extern "C" int dmn_ddpm_sample_loop(DmnUnet* u, const float* table, int nsteps, 
     auto body = [&]() -> int {
         int r = unet_forward_impl(u, x, nullptr, 1, table, lb.step_idx, lb.net, B, H, W, lb.arena, lb.arena_bytes, s, false, nullptr);
         if (r) return r;
+        // The update reads the copy of the counter that the network's first kernel made and writes the next value
+        // to the counter itself: no launch of its own for the increment.
+        // (A network without time embedding has no kernel that makes the copy: separate increment then.)
+        const bool handoff = u->cfg.with_time_emb != 0;
         DdpmStepArgs a;
-        a.c = step_common(table, lb.step_idx, 0, x, lb.net, nullptr, x, B, C, H * W, seed, img_offset, keep);
+        a.c = step_common(table, handoff ? lb.step_idx + kStepCopyOffset : lb.step_idx, 0, x, lb.net, nullptr, x, B, C, H * W, seed,
+                          img_offset, keep);
+        a.step_next = handoff ? lb.step_idx : nullptr;
         a.learned_variance = learned_variance;
         a.pred_x0 = pred_x0 & 1;
         a.ddim = (pred_x0 >> 1) & 1;
         if ((r = launch_ddpm_step(a, s))) return r;
-        return launch_advance(lb.step_idx, s);
+        return handoff ? DMN_OK : launch_advance(lb.step_idx, s);
     };
     return run_loop(u, key, nsteps, s, use_graph, body);
 }

@@ -152,7 +152,9 @@ __device__ __forceinline__ void time_mlp_body(const TimeArgs& a, int bx, int b) 
     if (a.t) {
         label = a.t_is_float ? static_cast<const float*>(a.t)[b] : (float)static_cast<const long long*>(a.t)[b];
     } else {
-        label = a.table[(size_t)(*a.step_idx) * a.table_cols + a.label_col];
+        const int row = *a.step_idx;
+        label = a.table[(size_t)row * a.table_cols + a.label_col];
+        if (a.step_copy && bx == 0 && b == 0 && tid == 0) *a.step_copy = row;
     }
     if (tid < half) {
         const float e = label * a.freqs[tid];

@@ -88,6 +88,7 @@ struct TimeArgs {
     int t_is_float;
     const float* table;     // optional [nsteps][table_cols]; label = table[*step_idx][label_col]
     const int* step_idx;
+    int* step_copy;         // optional: receives *step_idx (one thread), for the kernels that run after the network
     int table_cols, label_col;
     int rows, dim;          // rows = B, or 1 when every sample shares the table label; hidden = 4*dim
     const float* freqs;     // [dim/2]

@@ -30,6 +30,8 @@ struct StepCommon {
 };
 struct DdpmStepArgs {
     StepCommon c;
+    int* step_next;       // optional: receives (row + 1), the counter the NEXT network evaluation reads. Must not be
+                          // the location c.step_idx points to (other workgroups of this launch still read that).
     int learned_variance; // net has 2C channels: eps | v
     int pred_x0;          // objective == 'pred_x0'
     int ddim;             // generalized (DDIM) update with the DDIM row layout

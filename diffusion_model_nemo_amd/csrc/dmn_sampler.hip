@@ -33,6 +33,7 @@ __global__ void __launch_bounds__(256) ddpm_step_kernel(const DdpmStepArgs a) {
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (4 * q >= per) return;
     const int row = c.step_idx ? *c.step_idx : c.step;
+    if (a.step_next && q == 0 && b == 0) *a.step_next = row + 1;
     const float* tr = c.table + (size_t)row * DMN_TABLE_COLS;
     const float sra = tr[1], srm1 = tr[2], c1 = tr[3], c2 = tr[4], plv = tr[5], logb = tr[6], mask = tr[7];
     float z[4];

@@ -472,7 +472,7 @@ static Act full_attn(Fwd& f, const AttnW& w, Act& x) {
 }
 
 // The whole forward. `t`/`t_is_float` or (`table`, `step_idx`) provide the time label.
-int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float, const float* table, const int* step_idx,
+int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float, const float* table, int* step_idx,
                       float* out, int B, int H, int W, void* ws, size_t ws_bytes, hipStream_t s, bool dry, size_t* high) {
     const DmnUnetCfg& c = u->cfg;
     DMN_REQUIRE(u->loaded || dry, DMN_ERR_WEIGHTS, "dmn_unet_forward: weights not loaded");
@@ -499,6 +499,9 @@ int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float,
         ta.t_is_float = t_is_float;
         ta.table = table;
         ta.step_idx = step_idx;
+        // the counter is copied 16 ints further on: kernels behind the network may read the copy while the last of
+        // them already writes the next value to the original
+        ta.step_copy = step_idx ? step_idx + kStepCopyOffset : nullptr;
         ta.table_cols = DMN_TABLE_COLS;
         ta.label_col = 0;
         ta.rows = tb_rows;

@@ -74,5 +74,8 @@ int pack_conv(PackedConv& pc, int dtype, const float* w, const float* bias, int 
               int pad, bool transposed);
 void free_conv(PackedConv& pc);
 void conv_args_from(const PackedConv& pc, int dtype, ConvArgs& a, int B, int H, int W);
-int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float, const float* table, const int* step_idx,
+// With a device step counter (`table` + `step_idx`), the evaluation also copies the counter to
+// step_idx[kStepCopyOffset]; step_idx must then address at least kStepCopyOffset + 1 ints.
+constexpr int kStepCopyOffset = 16;
+int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float, const float* table, int* step_idx,
                       float* out, int B, int H, int W, void* ws, size_t ws_bytes, hipStream_t s, bool dry, size_t* high);
