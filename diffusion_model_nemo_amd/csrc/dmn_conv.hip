@@ -34,6 +34,14 @@ namespace {
 constexpr int kRowPad = 32;    // bytes added to every LDS pixel row
 constexpr int kLdsSlack = 512; // fragment reads of skipped k-steps may run past the last row
 
+// 3x3 tap (dy * 3 + dx) of ring entry e = dx * 3 + i: dx outer; inside a column the 8-wide tiles take dy = 0, 2, 1
+// (both even rows pairs first), the 16-wide tiles dy = 0, 1, 2.
+template <int TH> __host__ __device__ constexpr int k3_tap(int e) {
+    const int dx = e / 3, i = e % 3;
+    const int dy = TH == 16 ? i : (i == 0 ? 0 : i == 1 ? 2 : 1);
+    return dy * 3 + dx;
+}
+
 template <int KIND> struct KindTraits;
 template <> struct KindTraits<DMN_K3X3> { static constexpr int NTAPS = 9, EXT = 3, S = 1, KW = 3, GK = 1; };
 template <> struct KindTraits<DMN_K1X1> { static constexpr int NTAPS = 1, EXT = 1, S = 1, KW = 1, GK = 4; };
@@ -121,8 +129,16 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) w[slot][nt] = *reinterpret_cast<const V*>(wfrag[nt] + (size_t)f * 64 * PER);
     };
+    // 3x3: the taps of a k-step are visited column by column (dx outer) so that the pixel fragments read from LDS for
+    // one dx serve all three dy (see the MFMA loop); ring entry e of a k-step is tap k3_tap(e).
+    auto ring_fill3 = [&](int slot, int ks, int e) {   // e may run past 8 into the following k-steps
+        ring_fill(slot, (ks + e / 9) * 9 + k3_tap<TH>(e % 9));
+    };
 #pragma unroll
-    for (int e = 0; e < RS; ++e) ring_fill(e, e);
+    for (int e = 0; e < RS; ++e) {
+        if constexpr (KIND == DMN_K3X3) ring_fill3(e, 0, e);
+        else ring_fill(e, e);
+    }
 
     f32x4 bias[NT];
 #pragma unroll
@@ -253,6 +269,61 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
             xoff[mt] = (((p / TW) * S) * IW + (p % TW) * S) * rowB + lq * 16;
         }
         const int ksbase = cg0 / KCH;
+        if constexpr (KIND == DMN_K3X3) {
+            // A 16-pixel fragment is one row of a 16-wide tile or two rows of an 8-wide tile. For a fixed dx the three
+            // dy of a pixel tile are fragments of the SAME column window shifted by whole rows, so the wave reads each
+            // distinct fragment once per (k-step, dx) and feeds it to every (pixel tile, dy) that needs it:
+            //   16 wide: rows r0 .. r0+MT+1                      -> MT + 2 reads for 3 * MT MFMA operands
+            //    8 wide: row pairs (2j, 2j+1), j = 0..MT, for dy = 0 / 2 and (2j+1, 2j+2), j < MT, for dy = 1
+            //                                                   -> 2 * MT + 1 reads
+            // (the loop is bound by LDS reads otherwise: 1 KB per MFMA and wave).
+            constexpr int NR = TW == 16 ? MT + 2 : 2 * MT + 1;
+            const int rstride = IW * rowB;
+            const int rb0 = TW == 16 ? ((wm * MT) * IW + l15) * rowB + lq * 16
+                                     : ((2 * wm * MT + (l15 >> 3)) * IW + (l15 & 7)) * rowB + lq * 16;
+            for (int ksl = 0; ksl < KSG; ++ksl) {
+                const int ks = ksbase + ksl;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    Vec16<T> R[NR];
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) {
+                        const int rows = TW == 16 ? j : (j <= MT ? 2 * j : 2 * (j - MT - 1) + 1);
+                        R[j].v = *reinterpret_cast<const V*>(sX + rb0 + rows * rstride + dx * rowB + ksl * 64);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const int e = dx * 3 + i;
+                        const int dy = k3_tap<TH>(e) / 3;
+                        Vec16<T> wv[NT];
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) wv[nt].v = w[e % RS][nt];
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            const int fj = TW == 16 ? mt + dy : (dy == 1 ? MT + 1 + mt : mt + dy / 2);
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) mma_step(wv[nt], R[fj], acc[mt][nt]);
+                        }
+                        if constexpr (RES) {
+                            if (dy == 1 && dx == 1) {   // centre tap: the pixel itself
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt) {
+                                    Vec16<T> w2;
+                                    w2.v = w2v[nt];
+#pragma unroll
+                                    for (int mt = 0; mt < MT; ++mt)
+                                        mma_step(w2, R[TW == 16 ? mt + 1 : MT + 1 + mt], acc2[mt][nt]);
+                                    const int ksn = ks + 1 < KS ? ks + 1 : KS - 1;   // unconditional, as the ring
+                                    w2v[nt] = *reinterpret_cast<const V*>(w2frag[nt] + (size_t)ksn * 64 * PER);
+                                }
+                            }
+                        }
+                        ring_fill3(e % RS, ks, e + RS);   // the slot just consumed
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        } else
         for (int ksl = 0; ksl < KSG; ksl += GK) {
             const int flat0 = (ksbase + ksl) * NTAPS; // fragment index of entry 0 of this iteration
             Vec16<T> xf[XB][MT];
