@@ -13,7 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libdmn_hip.so")
-SOURCES = ["dmn_conv.hip", "dmn_elem.hip", "dmn_attn.hip", "dmn_linattn.hip", "dmn_sampler.hip", "dmn_unet.cpp", "dmn_api.cpp"]
+SOURCES = ["dmn_conv.hip", "dmn_elem.hip", "dmn_attn.hip", "dmn_linattn.hip", "dmn_sampler.hip", "dmn_unet.cpp", "dmn_api.cpp",
+           "dmn_train_gemm.hip", "dmn_train_ops.hip", "dmn_train.cpp"]
 ARCH = "gfx950"
 
 
@@ -40,7 +41,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
              "-ffp-contract=off", "-fno-honor-nans"]
     # Kernels whose MFMA accumulators feed VALU code inside the loop (softmax, operand re-packing): MFMA results in
     # plain VGPRs, or the compiler shuttles them through the accumulator file and back on every iteration.
-    extra = {"dmn_linattn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "dmn_attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+    extra = {"dmn_linattn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "dmn_attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+             # hardware float atomics for the split reductions of the training kernels
+             "dmn_train_gemm.hip": ["-munsafe-fp-atomics"], "dmn_train_ops.hip": ["-munsafe-fp-atomics"]}
     jobs = []
     objs = []
     for src in SOURCES:

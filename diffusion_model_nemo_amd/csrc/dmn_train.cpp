@@ -1,0 +1,788 @@
+// Training step of the DDPM U-Net behind the C-ABI (include/dmn.h, dmn_train_*): forward with saved activations,
+// L_simple, backward through every layer, and the fused clip + AdamW update. Follows DDPM.training_step
+// (diffusion_model_nemo/models/ddpm.py:43-57), Unet.forward (modules/unet.py:131-168, use_convnext=False),
+// ResnetBlock / Block (parts/convnext.py:8-45,63-86), LinearAttention / Attention (parts/mha.py:7-59) and
+// DiffusionLoss (loss/simple_loss.py:37-45); what autograd derives in the reference is written out here as a tape of
+// backward closures over the kernels of dmn_train.h. Parameters and gradients live in ONE flat float32 buffer each, in
+// the reference's per-tensor layouts (so state_dicts interchange and one RCCL all-reduce covers all gradients); the
+// GEMM-ordered copies the kernels consume are rebuilt from it at the start of every step.
+#include <string.h>
+
+#include <cmath>
+
+#include <deque>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../../include/dmn.h"
+#include "dmn_common.h"
+#include "dmn_train.h"
+
+namespace {
+
+struct PInfo {
+    std::string name;
+    int ndim = 0;
+    int64_t shape[4] = {0, 0, 0, 0};
+    long long off = 0, numel = 0;
+};
+
+struct ConvP {
+    int w = -1, b = -1;            // parameter indices (bias optional)
+    long long f_off = 0, b_off = 0;
+    int f_ld = 0, b_ld = 0;
+    int Cin = 0, Cout = 0, k = 1, stride = 1, pad = 0;
+    bool transposed = false;
+};
+struct NormP {
+    int g = -1, b = -1;
+};
+struct ResP {
+    ConvP c1, c2, res;
+    NormP n1, n2;
+    bool has_res = false;
+    int tb_off = -1;
+};
+struct AttnP {
+    NormP pre, post;
+    ConvP qkv, out;
+    bool linear = true;
+};
+struct LevelP {
+    ResP rb[2];
+    AttnP attn;
+    ConvP resample;
+    bool has_resample = false;
+};
+
+}   // namespace
+
+struct DmnTrainer {
+    DmnUnetCfg cfg;
+    int loss_kind = 1;
+    std::vector<PInfo> params;
+    long long n_flat = 0;
+    std::vector<RepackDesc> descs;
+    RepackDesc* descs_dev = nullptr;
+    long long gemm_numel = 0, max_numel = 0;
+    // structure
+    ConvP init, t1, t2, tball, tail;
+    NormP tail_norm;
+    std::vector<LevelP> downs, ups;
+    ResP mid1, mid2, final_rb;
+    AttnP mid_attn;
+    int tb_total = 0;
+    long long tb_bias_off = 0;   // the per-block time-linear biases are consecutive in the flat buffer
+    // workspace region sizes of the last shape
+    int sz_B = 0, sz_H = 0, sz_W = 0;
+    size_t sz_zero = 0, sz_arena = 0, sz_total = 0;
+};
+
+namespace {
+
+struct Builder {
+    DmnTrainer* tr;
+    long long flat = 0, gemm = 0;
+    int add_param(const std::string& name, std::initializer_list<int64_t> shape) {
+        PInfo p;
+        p.name = name;
+        p.ndim = (int)shape.size();
+        p.numel = 1;
+        int i = 0;
+        for (int64_t s : shape) {
+            p.shape[i++] = s;
+            p.numel *= s;
+        }
+        p.off = flat;
+        flat += (p.numel + 3) & ~3ll;
+        tr->params.push_back(p);
+        return (int)tr->params.size() - 1;
+    }
+    void add_desc(ConvP& c, int taps) {
+        RepackDesc d;
+        memset(&d, 0, sizeof(d));
+        d.src_off = tr->params[c.w].off;
+        d.n_out = c.Cout;
+        d.n_in = c.Cin;
+        d.taps = taps;
+        d.transposed = c.transposed ? 1 : 0;
+        d.f_off = c.f_off;
+        d.f_ld = c.f_ld;
+        d.b_off = c.b_off;
+        d.b_ld = c.b_ld;
+        tr->descs.push_back(d);
+        const long long n = (long long)c.Cout * c.Cin * taps;
+        if (n > tr->max_numel) tr->max_numel = n;
+    }
+    ConvP conv(const std::string& name, int cout, int cin, int k, int stride, int pad, bool bias, bool transposed = false) {
+        ConvP c;
+        c.Cin = cin;
+        c.Cout = cout;
+        c.k = k;
+        c.stride = stride;
+        c.pad = pad;
+        c.transposed = transposed;
+        if (transposed) c.w = add_param(name + ".weight", {cin, cout, k, k});
+        else c.w = add_param(name + ".weight", {cout, cin, k, k});
+        if (bias) c.b = add_param(name + ".bias", {cout});
+        const long long n = (long long)cout * cin * k * k;
+        c.f_off = c.b_off = gemm;
+        c.f_ld = cout;
+        c.b_ld = cin;
+        gemm += (n + 3) & ~3ll;
+        add_desc(c, k * k);
+        return c;
+    }
+    ConvP linear(const std::string& name, int cout, int cin) {
+        ConvP c;
+        c.Cin = cin;
+        c.Cout = cout;
+        c.w = add_param(name + ".weight", {cout, cin});
+        c.b = add_param(name + ".bias", {cout});
+        c.f_off = c.b_off = gemm;
+        c.f_ld = cout;
+        c.b_ld = cin;
+        gemm += ((long long)cout * cin + 3) & ~3ll;
+        add_desc(c, 1);
+        return c;
+    }
+    NormP norm(const std::string& name, int c) {
+        NormP n;
+        n.g = add_param(name + ".weight", {c});
+        n.b = add_param(name + ".bias", {c});
+        return n;
+    }
+    ResP resblock(const std::string& pre, int cin, int cout) {
+        ResP r;
+        r.c1 = conv(pre + ".block1.proj", cout, cin, 3, 1, 1, true);
+        r.n1 = norm(pre + ".block1.norm", cout);
+        r.c2 = conv(pre + ".block2.proj", cout, cout, 3, 1, 1, true);
+        r.n2 = norm(pre + ".block2.norm", cout);
+        r.has_res = cin != cout;
+        if (r.has_res) r.res = conv(pre + ".res_conv", cout, cin, 1, 1, 0, true);
+        return r;
+    }
+    AttnP attn(const std::string& pre, int c, bool linear_attn) {
+        const int hidden = tr->cfg.heads * tr->cfg.dim_head;
+        AttnP a;
+        a.linear = linear_attn;
+        a.pre = norm(pre + ".fn.norm", c);
+        a.qkv = conv(pre + ".fn.fn.to_qkv", 3 * hidden, c, 1, 1, 0, false);
+        if (linear_attn) {
+            a.out = conv(pre + ".fn.fn.to_out.0", c, hidden, 1, 1, 0, true);
+            a.post = norm(pre + ".fn.fn.to_out.1", c);
+        } else {
+            a.out = conv(pre + ".fn.fn.to_out", c, hidden, 1, 1, 0, true);
+        }
+        return a;
+    }
+};
+
+struct TimeLin {   // one ResnetBlock's `mlp.1` inside the concatenated [time_dim][tb_total] matrix
+    std::string pre;
+    int cout;
+    ResP* rb;
+};
+
+int build_structure(DmnTrainer* tr) {
+    const DmnUnetCfg& c = tr->cfg;
+    Builder b{tr};
+    const int dim = c.dim, td = 4 * dim, nlev = c.n_mults;
+    std::vector<int> dims(1, dim);
+    for (int i = 0; i < nlev; ++i) dims.push_back(dim * c.dim_mults[i]);
+    tr->downs.resize(nlev);
+    tr->ups.resize(nlev - 1);
+    std::vector<TimeLin> tl;
+    tr->init = b.conv("init_conv", dim, c.channels, 7, 1, 3, true);
+    tr->t1 = b.linear("time_mlp.1", td, dim);
+    tr->t2 = b.linear("time_mlp.3", td, td);
+    for (int i = 0; i < nlev; ++i) {
+        const int ci = dims[i], co = dims[i + 1];
+        const std::string p = "downs." + std::to_string(i);
+        tr->downs[i].rb[0] = b.resblock(p + ".0", ci, co);
+        tl.push_back({p + ".0", co, &tr->downs[i].rb[0]});
+        tr->downs[i].rb[1] = b.resblock(p + ".1", co, co);
+        tl.push_back({p + ".1", co, &tr->downs[i].rb[1]});
+        tr->downs[i].attn = b.attn(p + ".2", co, true);
+        tr->downs[i].has_resample = i < nlev - 1;
+        if (i < nlev - 1) tr->downs[i].resample = b.conv(p + ".3", co, co, 4, 2, 1, true);
+    }
+    const int mid = dims[nlev];
+    tr->mid1 = b.resblock("mid_block1", mid, mid);
+    tl.push_back({"mid_block1", mid, &tr->mid1});
+    tr->mid_attn = b.attn("mid_attn", mid, false);
+    tr->mid2 = b.resblock("mid_block2", mid, mid);
+    tl.push_back({"mid_block2", mid, &tr->mid2});
+    for (int i = 0; i < nlev - 1; ++i) {
+        const int j = nlev - 1 - i;
+        const int ci = dims[j], co = dims[j + 1];
+        const std::string p = "ups." + std::to_string(i);
+        tr->ups[i].rb[0] = b.resblock(p + ".0", co * 2, ci);
+        tl.push_back({p + ".0", ci, &tr->ups[i].rb[0]});
+        tr->ups[i].rb[1] = b.resblock(p + ".1", ci, ci);
+        tl.push_back({p + ".1", ci, &tr->ups[i].rb[1]});
+        tr->ups[i].attn = b.attn(p + ".2", ci, true);
+        tr->ups[i].has_resample = true;
+        tr->ups[i].resample = b.conv(p + ".3", ci, ci, 4, 2, 1, true, true);
+    }
+    tr->final_rb = b.resblock("final_conv.0", dim, dim);
+    if (c.tail_norm) {
+        tr->tail_norm = b.norm("final_conv.1", dim);
+        tr->tail = b.conv("final_conv.3", c.out_dim, dim, 1, 1, 0, true);
+    } else {
+        tr->tail = b.conv("final_conv.1", c.out_dim, dim, 1, 1, 0, true);
+    }
+    // per-block time linears: weights as column blocks of one [td][tb_total] matrix, biases consecutive
+    int total = 0;
+    for (auto& t : tl) total += t.cout;
+    tr->tb_total = total;
+    tr->tball.Cin = td;
+    tr->tball.Cout = total;
+    tr->tball.f_off = b.gemm;
+    tr->tball.f_ld = total;
+    b.gemm += (long long)td * total;
+    tr->tball.b_off = b.gemm;
+    tr->tball.b_ld = td;
+    b.gemm += (long long)td * total;
+    int col = 0;
+    for (auto& t : tl) {
+        ConvP cp;
+        cp.Cin = td;
+        cp.Cout = t.cout;
+        cp.w = b.add_param(t.pre + ".mlp.1.weight", {t.cout, td});
+        cp.f_off = tr->tball.f_off + col;
+        cp.f_ld = total;
+        cp.b_off = tr->tball.b_off + (long long)col * td;
+        cp.b_ld = td;
+        b.add_desc(cp, 1);
+        t.rb->tb_off = col;
+        col += t.cout;
+    }
+    tr->tb_bias_off = b.flat;
+    for (auto& t : tl) {
+        const long long before = b.flat;
+        b.add_param(t.pre + ".mlp.1.bias", {t.cout});
+        if (b.flat - before != t.cout) return DMN_ERR_INVALID;   // widths are multiples of 4: no padding between them
+    }
+    tr->n_flat = b.flat;
+    tr->gemm_numel = b.gemm;
+    return DMN_OK;
+}
+
+// ---- one step ---------------------------------------------------------------------------------------------------
+struct Bump {
+    char* base = nullptr;
+    size_t cap = 0, used = 0;
+    bool dry = false;
+    void* alloc(size_t n) {
+        n = (n + 255) & ~(size_t)255;
+        void* p = dry ? reinterpret_cast<void*>(4096 + used) : (void*)(base + used);
+        used += n;
+        if (!dry && used > cap) return nullptr;
+        return p;
+    }
+};
+
+struct Ten {
+    float* p = nullptr;
+    float* g = nullptr;
+    int C = 0, H = 0, W = 0;
+    bool gset = false;
+};
+
+struct Run {
+    DmnTrainer* tr;
+    hipStream_t s;
+    bool dry;
+    int B;
+    int rc = DMN_OK;
+    Bump a, z;
+    const float* params;
+    float* grads;
+    float *wf, *wb, *dwf;
+    std::vector<std::function<void()>> tape;
+    std::deque<Ten> tens;
+
+    void fail_ws() {
+        if (rc == DMN_OK) {
+            dmn_set_error("training workspace too small");
+            rc = DMN_ERR_WORKSPACE;
+        }
+    }
+    float* alloc(size_t floats) {
+        float* p = (float*)a.alloc(floats * 4);
+        if (!p) fail_ws();
+        return p;
+    }
+    float* zalloc(size_t floats) {
+        float* p = (float*)z.alloc(floats * 4);
+        if (!p) fail_ws();
+        return p;
+    }
+    size_t numel(const Ten* t) const { return (size_t)B * t->H * t->W * t->C; }
+    Ten* nt(int C, int H, int W) {
+        tens.emplace_back();
+        Ten* t = &tens.back();
+        t->C = C;
+        t->H = H;
+        t->W = W;
+        t->p = alloc(numel(t));
+        return t;
+    }
+    // gradient buffer of t and whether the coming write must accumulate
+    float* G(Ten* t, int* acc) {
+        if (!t->g) t->g = alloc(numel(t));
+        *acc = t->gset ? 1 : 0;
+        t->gset = true;
+        return t->g;
+    }
+    bool live() const { return !dry && rc == DMN_OK; }
+    void L(int r) {
+        if (rc == DMN_OK && r != DMN_OK) rc = r;
+    }
+    const float* P(int idx) const { return idx < 0 ? nullptr : params + tr->params[idx].off; }
+    float* GP(int idx) const { return idx < 0 ? nullptr : grads + tr->params[idx].off; }
+};
+
+#define RUN(r, expr)                 \
+    do {                             \
+        if ((r).live()) (r).L(expr); \
+    } while (0)
+
+Ten* conv(Run& r, Ten* x, const ConvP& w, bool need_dx = true, const float* bias_override = nullptr, float* dbias_override = nullptr) {
+    const int Ho = w.transposed ? (x->H - 1) * w.stride - 2 * w.pad + w.k : (x->H + 2 * w.pad - w.k) / w.stride + 1;
+    const int Wo = w.transposed ? (x->W - 1) * w.stride - 2 * w.pad + w.k : (x->W + 2 * w.pad - w.k) / w.stride + 1;
+    Ten* y = r.nt(w.Cout, Ho, Wo);
+    const float* bias = bias_override ? bias_override : r.P(w.b);
+    float* dbias = dbias_override ? dbias_override : r.GP(w.b);
+    PGemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = x->p;
+    a.ldin = x->C;
+    a.Cin = w.Cin;
+    a.B = r.B;
+    a.Hi = x->H;
+    a.Wi = x->W;
+    a.Ho = Ho;
+    a.Wo = Wo;
+    a.kh = a.kw = w.k;
+    a.stride = w.stride;
+    a.pad = w.pad;
+    a.tmode = w.transposed ? 1 : 0;
+    a.w = r.wf + w.f_off;
+    a.ldw = w.f_ld;
+    a.bias = bias;
+    a.out = y->p;
+    a.ldout = w.Cout;
+    a.N = w.Cout;
+    RUN(r, launch_pgemm(a, r.s));
+    Run* rp = &r;
+    const ConvP* wp = &w;
+    r.tape.push_back([rp, x, y, wp, need_dx, dbias, Ho, Wo]() {
+        Run& r = *rp;
+        const ConvP& w = *wp;
+        WGemmArgs g;
+        memset(&g, 0, sizeof(g));
+        g.x = x->p;
+        g.ldx = x->C;
+        g.Cin = w.Cin;
+        g.B = r.B;
+        g.Hi = x->H;
+        g.Wi = x->W;
+        g.Ho = Ho;
+        g.Wo = Wo;
+        g.kh = g.kw = w.k;
+        g.stride = w.stride;
+        g.pad = w.pad;
+        g.tmode = w.transposed ? 1 : 0;
+        g.dy = y->g;
+        g.lddy = w.Cout;
+        g.N = w.Cout;
+        g.dw = r.dwf + w.f_off;
+        g.lddw = w.f_ld;
+        RUN(r, launch_wgemm(g, r.s));
+        if (dbias) RUN(r, launch_colsum(y->g, w.Cout, (long long)r.B * Ho * Wo, w.Cout, dbias, r.s));
+        if (need_dx) {
+            PGemmArgs d;
+            memset(&d, 0, sizeof(d));
+            d.in = y->g;
+            d.ldin = w.Cout;
+            d.Cin = w.Cout;
+            d.B = r.B;
+            d.Hi = Ho;
+            d.Wi = Wo;
+            d.Ho = x->H;
+            d.Wo = x->W;
+            d.kh = d.kw = w.k;
+            d.stride = w.stride;
+            d.pad = w.pad;
+            d.tmode = w.transposed ? 0 : 1;
+            d.w = r.wb + w.b_off;
+            d.ldw = w.b_ld;
+            d.out = r.G(x, &d.accumulate);
+            d.ldout = x->C;
+            d.N = w.Cin;
+            RUN(r, launch_pgemm(d, r.s));
+        }
+    });
+    return y;
+}
+
+// y = act(GroupNorm(x)) + tb
+Ten* gnorm(Run& r, Ten* x, const NormP& n, int G, int act, const float* tb, float* dtb, int tb_ld) {
+    Ten* y = r.nt(x->C, x->H, x->W);
+    float* stats = r.zalloc((size_t)r.B * G * 2);
+    GnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x->p;
+    a.stats = stats;
+    a.gamma = r.P(n.g);
+    a.beta = r.P(n.b);
+    a.tb = tb;
+    a.tb_ld = tb_ld;
+    a.y = y->p;
+    a.B = r.B;
+    a.HW = x->H * x->W;
+    a.C = x->C;
+    a.G = G;
+    a.act = act;
+    RUN(r, launch_gn_stats(x->p, r.B, a.HW, a.C, G, stats, r.s));
+    RUN(r, launch_gn_apply(a, r.s));
+    Run* rp = &r;
+    float* dgamma = r.GP(n.g);
+    float* dbeta = r.GP(n.b);
+    r.tape.push_back([rp, x, y, a, dgamma, dbeta, dtb]() mutable {
+        Run& r = *rp;
+        a.dy = y->g;
+        a.sums = r.zalloc((size_t)r.B * a.C * 3);
+        a.dgamma = dgamma;
+        a.dbeta = dbeta;
+        a.dtb = dtb;
+        a.dx = r.G(x, &a.accumulate);
+        RUN(r, launch_gn_bwd(a, r.s));
+    });
+    return y;
+}
+
+Ten* add(Run& r, Ten* a, Ten* b) {
+    Ten* y = r.nt(a->C, a->H, a->W);
+    RUN(r, launch_add(y->p, a->p, b->p, (long long)r.numel(y), r.s));
+    Run* rp = &r;
+    r.tape.push_back([rp, a, b, y]() {
+        Run& r = *rp;
+        int acc;
+        float* ga = r.G(a, &acc);
+        RUN(r, launch_axpby(ga, y->g, (long long)r.numel(y), acc, r.s));
+        float* gb = r.G(b, &acc);
+        RUN(r, launch_axpby(gb, y->g, (long long)r.numel(y), acc, r.s));
+    });
+    return y;
+}
+
+Ten* cat(Run& r, Ten* a, Ten* b) {
+    Ten* y = r.nt(a->C + b->C, a->H, a->W);
+    const long long rows = (long long)r.B * a->H * a->W;
+    RUN(r, launch_copy_slice(y->p, y->C, 0, a->p, a->C, 0, a->C, rows, 0, r.s));
+    RUN(r, launch_copy_slice(y->p, y->C, a->C, b->p, b->C, 0, b->C, rows, 0, r.s));
+    Run* rp = &r;
+    r.tape.push_back([rp, a, b, y, rows]() {
+        Run& r = *rp;
+        int acc;
+        float* ga = r.G(a, &acc);
+        RUN(r, launch_copy_slice(ga, a->C, 0, y->g, y->C, 0, a->C, rows, acc, r.s));
+        float* gb = r.G(b, &acc);
+        RUN(r, launch_copy_slice(gb, b->C, 0, y->g, y->C, a->C, b->C, rows, acc, r.s));
+    });
+    return y;
+}
+
+Ten* activation(Run& r, Ten* x, int act) {
+    Ten* y = r.nt(x->C, x->H, x->W);
+    RUN(r, launch_act_fwd(x->p, y->p, (long long)r.numel(x), act, r.s));
+    Run* rp = &r;
+    r.tape.push_back([rp, x, y, act]() {
+        Run& r = *rp;
+        int acc;
+        float* gx = r.G(x, &acc);
+        RUN(r, launch_act_bwd(x->p, y->g, gx, (long long)r.numel(x), act, acc, r.s));
+    });
+    return y;
+}
+
+Ten* attn_core(Run& r, Ten* qkv, bool linear) {
+    const int heads = r.tr->cfg.heads, hidden = heads * 32, n = qkv->H * qkv->W;
+    Ten* y = r.nt(hidden, qkv->H, qkv->W);
+    float* ctx = linear ? r.alloc((size_t)r.B * heads * 1024) : nullptr;
+    float* st = linear ? r.alloc((size_t)r.B * heads * 64) : r.alloc((size_t)r.B * heads * n * 2);
+    if (linear) RUN(r, launch_linattn_train_fwd(qkv->p, y->p, ctx, st, r.B, n, heads, r.s));
+    else RUN(r, launch_attn_train_fwd(qkv->p, y->p, st, r.B, n, heads, r.s));
+    Run* rp = &r;
+    r.tape.push_back([rp, qkv, y, ctx, st, linear, n, heads]() {
+        Run& r = *rp;
+        int acc;
+        float* g = r.G(qkv, &acc);   // qkv has this single consumer: the kernels overwrite
+        if (acc && r.rc == DMN_OK) {
+            dmn_set_error("internal: attention input gradient already set");
+            r.rc = DMN_ERR_INVALID;
+        }
+        if (linear) RUN(r, launch_linattn_train_bwd(qkv->p, y->g, ctx, st, g, r.B, n, heads, r.s));
+        else RUN(r, launch_attn_train_bwd(qkv->p, y->p, y->g, st, g, r.B, n, heads, r.s));
+    });
+    return y;
+}
+
+Ten* resblock(Run& r, Ten* x, const ResP& w, Ten* tb) {
+    const int G = r.tr->cfg.groups;
+    Ten* h = conv(r, x, w.c1);
+    const bool time = tb && w.tb_off >= 0;
+    h = gnorm(r, h, w.n1, G, 1, time ? tb->p + w.tb_off : nullptr, time ? tb->g + w.tb_off : nullptr, r.tr->tb_total);
+    h = conv(r, h, w.c2);
+    h = gnorm(r, h, w.n2, G, 1, nullptr, nullptr, 0);
+    Ten* res = w.has_res ? conv(r, x, w.res) : x;
+    return add(r, h, res);
+}
+
+Ten* attention(Run& r, Ten* x, const AttnP& w) {
+    Ten* xn = gnorm(r, x, w.pre, 1, 0, nullptr, nullptr, 0);
+    Ten* qkv = conv(r, xn, w.qkv);
+    Ten* o = attn_core(r, qkv, w.linear);
+    Ten* y = conv(r, o, w.out);
+    if (w.linear) y = gnorm(r, y, w.post, 1, 0, nullptr, nullptr, 0);
+    return add(r, y, x);
+}
+
+struct StepIO {
+    const float *x0, *noise;
+    const long long* t;
+    const float *sa, *sb;
+    float* loss;
+    float* model_out;
+};
+
+struct Sizes {
+    size_t zero = 0, arena = 0, total = 0;
+};
+
+int run_step(DmnTrainer* tr, const float* params, float* grads, const StepIO& io, int B, int H, int W, void* ws, size_t ws_bytes,
+             hipStream_t s, bool dry, Sizes* sz) {
+    const DmnUnetCfg& c = tr->cfg;
+    const int nlev = c.n_mults, div = 1 << (nlev - 1);
+    DMN_REQUIRE(B >= 1 && H % div == 0 && W % div == 0 && H >= div && W >= div, DMN_ERR_INVALID,
+                "training: image %dx%d must be a multiple of %d", H, W, div);
+    Run r;
+    r.tr = tr;
+    r.s = s;
+    r.dry = dry;
+    r.B = B;
+    r.params = params;
+    r.grads = grads;
+    // workspace: [wf | wb | zero region: dwf + zero arena | arena]
+    const size_t gemm_bytes = ((size_t)tr->gemm_numel * 4 + 255) & ~(size_t)255;
+    if (!dry) {
+        // region sizes come from a dry pass of the same code, cached per shape
+        if (tr->sz_B != B || tr->sz_H != H || tr->sz_W != W) {
+            Sizes q;
+            int rc = run_step(tr, params, grads, io, B, H, W, nullptr, 0, s, true, &q);
+            if (rc) return rc;
+            tr->sz_B = B;
+            tr->sz_H = H;
+            tr->sz_W = W;
+            tr->sz_zero = q.zero;
+            tr->sz_arena = q.arena;
+            tr->sz_total = q.total;
+        }
+        DMN_REQUIRE(ws_bytes >= tr->sz_total, DMN_ERR_WORKSPACE, "training workspace: %zu bytes given, %zu needed", ws_bytes,
+                    tr->sz_total);
+        DMN_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, DMN_ERR_INVALID, "training workspace must be 256-byte aligned");
+        if (!tr->descs_dev) {   // first step on the device: upload the layout table (creation itself needs no GPU)
+            DMN_HIP_CHECK(hipMalloc((void**)&tr->descs_dev, tr->descs.size() * sizeof(RepackDesc)));
+            DMN_HIP_CHECK(hipMemcpy(tr->descs_dev, tr->descs.data(), tr->descs.size() * sizeof(RepackDesc), hipMemcpyHostToDevice));
+        }
+    }
+    char* base = (char*)ws;
+    r.wf = (float*)base;
+    r.wb = (float*)(base + gemm_bytes);
+    r.dwf = (float*)(base + 2 * gemm_bytes);
+    if (dry) {
+        r.z.dry = r.a.dry = true;
+    } else {
+        r.z.base = base + 3 * gemm_bytes;
+        r.z.cap = tr->sz_zero;
+        r.a.base = base + 3 * gemm_bytes + tr->sz_zero;
+        r.a.cap = tr->sz_arena;
+        DMN_HIP_CHECK(hipMemsetAsync(r.dwf, 0, gemm_bytes + tr->sz_zero, s));
+        DMN_HIP_CHECK(hipMemsetAsync(grads, 0, (size_t)tr->n_flat * 4, s));
+        RUN(r, launch_repack(tr->descs_dev, (int)tr->descs.size(), tr->max_numel, params, r.wf, r.wb, s));
+    }
+
+    const int td = 4 * c.dim;
+    // inputs
+    Ten* xt = r.nt(c.channels, H, W);
+    Ten* tgt = r.nt(c.channels, H, W);
+    RUN(r, launch_train_ingest(io.x0, io.noise, io.t, io.sa, io.sb, xt->p, tgt->p, B, c.channels, H, W, s));
+    // time path (modules/unet.py:61-66, parts/convnext.py:68-72,81-83)
+    Ten* emb = r.nt(c.dim, 1, 1);
+    RUN(r, launch_sinus(io.t, 0, B, c.dim, emb->p, s));
+    Ten* h1 = conv(r, emb, tr->t1, false);
+    Ten* h2 = activation(r, h1, 1);
+    Ten* temb = conv(r, h2, tr->t2);
+    Ten* st = activation(r, temb, 0);
+    Ten* tb = conv(r, st, tr->tball, true, params + tr->tb_bias_off, grads + tr->tb_bias_off);
+    tb->g = r.zalloc((size_t)B * tr->tb_total);   // every block adds its share
+    tb->gset = true;
+    (void)td;
+
+    Ten* cur = conv(r, xt, tr->init, false);
+    std::vector<Ten*> skips;
+    for (int i = 0; i < nlev; ++i) {
+        cur = resblock(r, cur, tr->downs[i].rb[0], tb);
+        cur = resblock(r, cur, tr->downs[i].rb[1], tb);
+        cur = attention(r, cur, tr->downs[i].attn);
+        if (i > 0) skips.push_back(cur);   // the top-level skip is never consumed (unet.py:95)
+        if (tr->downs[i].has_resample) cur = conv(r, cur, tr->downs[i].resample);
+    }
+    cur = resblock(r, cur, tr->mid1, tb);
+    cur = attention(r, cur, tr->mid_attn);
+    cur = resblock(r, cur, tr->mid2, tb);
+    for (int i = 0; i < nlev - 1; ++i) {
+        Ten* sk = skips.back();
+        skips.pop_back();
+        cur = cat(r, cur, sk);
+        cur = resblock(r, cur, tr->ups[i].rb[0], tb);
+        cur = resblock(r, cur, tr->ups[i].rb[1], tb);
+        cur = attention(r, cur, tr->ups[i].attn);
+        cur = conv(r, cur, tr->ups[i].resample);
+    }
+    cur = resblock(r, cur, tr->final_rb, nullptr);
+    if (c.tail_norm) cur = gnorm(r, cur, tr->tail_norm, c.groups, 1, nullptr, nullptr, 0);
+    Ten* out = conv(r, cur, tr->tail);
+    DMN_REQUIRE(out->H == H && out->W == W, DMN_ERR_INVALID, "internal: output %dx%d", out->H, out->W);
+
+    // loss and its gradient
+    float* loss_dev = dry ? nullptr : io.loss;
+    int acc;
+    float* dout = r.G(out, &acc);
+    if (!dry) DMN_HIP_CHECK(hipMemsetAsync(loss_dev, 0, 4, s));
+    RUN(r, launch_loss(out->p, tgt->p, (long long)r.numel(out), tr->loss_kind, loss_dev, dout, s));
+    if (io.model_out) RUN(r, launch_nhwc_to_nchw(out->p, io.model_out, B, c.out_dim, H * W, s));
+
+    for (size_t i = r.tape.size(); i-- > 0;) r.tape[i]();
+    RUN(r, launch_unpack_grads(tr->descs_dev, (int)tr->descs.size(), tr->max_numel, r.dwf, grads, s));
+
+    if (dry && sz) {
+        sz->zero = (r.z.used + 255) & ~(size_t)255;
+        sz->arena = (r.a.used + 255) & ~(size_t)255;
+        sz->total = 3 * gemm_bytes + sz->zero + sz->arena;
+    }
+    return r.rc;
+}
+
+}   // namespace
+
+extern "C" int dmn_train_create(const DmnUnetCfg* cfg, int loss_kind, DmnTrainer** out) {
+    DMN_REQUIRE(cfg && out, DMN_ERR_INVALID, "dmn_train_create: null argument");
+    DMN_REQUIRE(cfg->n_mults >= 1 && cfg->n_mults <= DMN_MAX_MULTS, DMN_ERR_INVALID, "n_mults=%d", cfg->n_mults);
+    DMN_REQUIRE(cfg->dim % 32 == 0 && cfg->dim >= 32, DMN_ERR_LIMIT, "dim=%d must be a multiple of 32", cfg->dim);
+    DMN_REQUIRE(cfg->dim_head == 32 && cfg->heads >= 1, DMN_ERR_INVALID, "dim_head=%d (only 32 supported)", cfg->dim_head);
+    DMN_REQUIRE(cfg->with_time_emb == 1, DMN_ERR_INVALID, "training needs the time embedding");
+    DMN_REQUIRE(cfg->num_classes == 0, DMN_ERR_INVALID, "class-conditional training is not built");
+    DMN_REQUIRE(cfg->out_dim == cfg->channels, DMN_ERR_INVALID, "L_simple needs out_dim == channels (got %d, %d)", cfg->out_dim, cfg->channels);
+    DMN_REQUIRE(cfg->groups >= 1 && cfg->groups <= 64 && cfg->dim % cfg->groups == 0 && (cfg->dim / cfg->groups) % 4 == 0,
+                DMN_ERR_INVALID, "groups=%d", cfg->groups);
+    DMN_REQUIRE(loss_kind >= 0 && loss_kind <= 2, DMN_ERR_INVALID, "loss_kind=%d", loss_kind);
+    int maxc = cfg->dim;
+    for (int i = 0; i < cfg->n_mults; ++i) {
+        DMN_REQUIRE(cfg->dim_mults[i] >= 1, DMN_ERR_INVALID, "dim_mults[%d]", i);
+        if (cfg->dim * cfg->dim_mults[i] > maxc) maxc = cfg->dim * cfg->dim_mults[i];
+    }
+    DMN_REQUIRE(maxc <= 1024 && 256 % (maxc / 4) == 0, DMN_ERR_LIMIT, "widest level %d channels: must divide 1024", maxc);
+    DmnTrainer* tr = new DmnTrainer();
+    tr->cfg = *cfg;
+    tr->loss_kind = loss_kind;
+    int rc = build_structure(tr);
+    if (rc) {
+        delete tr;
+        dmn_set_error("dmn_train_create: unsupported widths");
+        return rc;
+    }
+    *out = tr;
+    return DMN_OK;
+}
+
+extern "C" void dmn_train_destroy(DmnTrainer* tr) {
+    if (!tr) return;
+    if (tr->descs_dev) (void)hipFree(tr->descs_dev);
+    delete tr;
+}
+
+extern "C" int dmn_train_num_tensors(const DmnTrainer* tr) { return tr ? (int)tr->params.size() : 0; }
+extern "C" int64_t dmn_train_flat_size(const DmnTrainer* tr) { return tr ? (int64_t)tr->n_flat : 0; }
+
+extern "C" int dmn_train_tensor_info(const DmnTrainer* tr, int idx, const char** name, int64_t* offset, int* ndim, int64_t* shape4) {
+    DMN_REQUIRE(tr && idx >= 0 && idx < (int)tr->params.size(), DMN_ERR_INVALID, "dmn_train_tensor_info: index %d", idx);
+    const PInfo& p = tr->params[idx];
+    if (name) *name = p.name.c_str();
+    if (offset) *offset = p.off;
+    if (ndim) *ndim = p.ndim;
+    if (shape4)
+        for (int i = 0; i < 4; ++i) shape4[i] = p.shape[i];
+    return DMN_OK;
+}
+
+extern "C" int dmn_train_workspace_bytes(DmnTrainer* tr, int B, int H, int W, size_t* bytes) {
+    DMN_REQUIRE(tr && bytes, DMN_ERR_INVALID, "dmn_train_workspace_bytes: null argument");
+    StepIO io;
+    memset(&io, 0, sizeof(io));
+    Sizes q;
+    int rc = run_step(tr, nullptr, nullptr, io, B, H, W, nullptr, 0, nullptr, true, &q);
+    if (rc) return rc;
+    *bytes = q.total;
+    return DMN_OK;
+}
+
+extern "C" int dmn_train_loss_and_grads(DmnTrainer* tr, const float* params, float* grads, const float* x0, const float* noise,
+                                        const int64_t* t, const float* sqrt_acp, const float* sqrt_1m_acp, int B, int H, int W,
+                                        float* loss, float* model_out, void* workspace, size_t workspace_bytes, void* stream) {
+    DMN_REQUIRE(tr && params && grads && x0 && noise && t && loss && workspace, DMN_ERR_INVALID,
+                "dmn_train_loss_and_grads: null argument");
+    DMN_REQUIRE((sqrt_acp == nullptr) == (sqrt_1m_acp == nullptr), DMN_ERR_INVALID, "schedule tables: both or neither");
+    StepIO io;
+    io.x0 = x0;
+    io.noise = noise;
+    io.t = reinterpret_cast<const long long*>(t);
+    io.sa = sqrt_acp;
+    io.sb = sqrt_1m_acp;
+    io.loss = loss;
+    io.model_out = model_out;
+    return run_step(tr, params, grads, io, B, H, W, workspace, workspace_bytes, (hipStream_t)stream, false, nullptr);
+}
+
+extern "C" int dmn_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, int step, float max_norm, float grad_scale,
+                              float* scratch, void* stream) {
+    DMN_REQUIRE(params && grads && exp_avg && exp_avg_sq && scratch && n > 0 && step >= 1, DMN_ERR_INVALID, "dmn_adamw_step: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    AdamWArgs a;
+    a.p = params;
+    a.g = grads;
+    a.m = exp_avg;
+    a.v = exp_avg_sq;
+    a.n = n;
+    a.lr = lr;
+    a.beta1 = beta1;
+    a.beta2 = beta2;
+    a.eps = eps;
+    a.weight_decay = weight_decay;
+    a.bias1 = (float)(1.0 - pow((double)beta1, (double)step));
+    a.bias2 = (float)(1.0 - pow((double)beta2, (double)step));
+    a.max_norm = max_norm;
+    a.sq_norm = scratch;
+    a.grad_scale = grad_scale;
+    if (max_norm > 0.f) {
+        DMN_HIP_CHECK(hipMemsetAsync(scratch, 0, 4, s));
+        int rc = launch_sqnorm(grads, n, scratch, s);
+        if (rc) return rc;
+    }
+    return launch_adamw(a, s);
+}

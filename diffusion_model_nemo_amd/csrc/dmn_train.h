@@ -1,0 +1,126 @@
+// Kernels of the training step (forward with saved activations, backward, optimiser) of the DDPM U-Net:
+// DDPM.training_step of the reference (diffusion_model_nemo/models/ddpm.py:43-57) followed by what its
+// Lightning trainer does with the loss (backward, gradient clipping, AdamW). Activations are NHWC float32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// Implicit GEMM over output pixels: out[m][n] (+)= sum_{tap, c} gather(in, m, tap)[c] * w[(tap*Cin + c)][n] + bias[n].
+// tmode 0 gathers like a convolution (iy = oy*stride - pad + ky), tmode 1 like a transposed convolution
+// (iy = (oy + pad - ky) / stride where divisible). The first serves Conv2d forward and ConvTranspose2d input
+// gradients, the second ConvTranspose2d forward and Conv2d input gradients; linear layers are 1x1 on 1x1 images.
+struct PGemmArgs {
+    const float* in;
+    int ldin, Cin;          // floats per input pixel row; channels consumed (from the row's start)
+    int B, Hi, Wi, Ho, Wo;
+    int kh, kw, stride, pad, tmode;
+    const float* w;         // [kh*kw*Cin][ldw]
+    int ldw;
+    const float* bias;      // [N] or null
+    float* out;
+    int ldout, N;
+    int accumulate;
+    int bf16;               // 1: operands rounded to bf16 for the matrix cores (fp32 accumulate)
+};
+int launch_pgemm(const PGemmArgs& a, hipStream_t s);
+
+// Weight gradient: dw[(tap*Cin + c)][n] += sum_m gather(x, m, tap)[c] * dy[m][n]   (atomic over pixel splits)
+struct WGemmArgs {
+    const float* x;
+    int ldx, Cin;
+    int B, Hi, Wi, Ho, Wo;
+    int kh, kw, stride, pad, tmode;
+    const float* dy;
+    int lddy, N;
+    float* dw;
+    int lddw;
+    int bf16;
+};
+int launch_wgemm(const WGemmArgs& a, hipStream_t s);
+
+// out[c] += sum over rows of in[row][c]   (atomic)
+int launch_colsum(const float* in, int ld, long long rows, int C, float* out, hipStream_t s);
+
+// GroupNorm over NHWC: stats[b][g] = {sum, sum of squares} (atomic into zeroed memory)
+int launch_gn_stats(const float* x, int B, int HW, int C, int G, float* stats, hipStream_t s);
+// y = act(gn(x) * gamma + beta) + tb[b][c]   (act: 0 none, 1 SiLU; tb optional with row stride tb_ld)
+struct GnArgs {
+    const float* x;
+    const float* stats;
+    const float *gamma, *beta;
+    const float* tb;
+    int tb_ld;
+    float* y;
+    int B, HW, C, G, act;
+    // backward
+    const float* dy;
+    float* dx;
+    int accumulate;
+    float* sums;            // [B][C][3] zeroed: sum dz*xhat, sum dz, sum dy
+    float *dgamma, *dbeta;  // [C] accumulated atomically
+    float* dtb;             // [B][tb_ld] slice, accumulated
+};
+int launch_gn_apply(const GnArgs& a, hipStream_t s);
+int launch_gn_bwd(const GnArgs& a, hipStream_t s);
+
+// elementwise helpers
+int launch_axpby(float* dst, const float* src, long long n, int accumulate, hipStream_t s);      // dst (+)= src
+int launch_add(float* out, const float* a, const float* b, long long n, hipStream_t s);         // out = a + b
+// dst[row][doff + c] (+)= src[row][soff + c], c < C
+int launch_copy_slice(float* dst, int ldd, int doff, const float* src, int lds, int soff, int C, long long rows,
+                      int accumulate, hipStream_t s);
+// act: 0 SiLU, 1 exact GELU. Forward y = act(x); backward dx (+)= dy * act'(x).
+int launch_act_fwd(const float* x, float* y, long long n, int act, hipStream_t s);
+int launch_act_bwd(const float* x, const float* dy, float* dx, long long n, int act, int accumulate, hipStream_t s);
+// Sinusoidal embedding of integer or float labels: out[b][dim]
+int launch_sinus(const void* t, int t_is_float, int B, int dim, float* out, hipStream_t s);
+
+// x_t = a[t_b] x0 + b[t_b] eps (a, b null: x_t = x0) from NCHW to NHWC, and eps to NHWC as the target.
+int launch_train_ingest(const float* x0, const float* eps, const long long* t, const float* sa, const float* sb, float* xt,
+                        float* tgt, int B, int C, int H, int W, hipStream_t s);
+// loss (+= into a zeroed scalar) of DiffusionLoss with reduction 'mean' (loss/simple_loss.py:37-45): kind 0 l1,
+// 1 l2, 2 huber (smooth_l1, beta 1); dout = d loss / d out. out, tgt, dout: [n] in the same (NHWC) order.
+int launch_loss(const float* out, const float* tgt, long long n, int kind, float* loss, float* dout, hipStream_t s);
+// NHWC [B][HW][C] -> NCHW [B][C][HW]
+int launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, hipStream_t s);
+
+// LinearAttention core on qkv [B][n][3*heads*32] (parts/mha.py:48-56): out [B][n][heads*32].
+// saved: ctx [B][heads][32][32], kstat [B][heads][2][32] (max, sum of exp) for the backward.
+int launch_linattn_train_fwd(const float* qkv, float* out, float* ctx, float* kstat, int B, int n, int heads, hipStream_t s);
+int launch_linattn_train_bwd(const float* qkv, const float* dout, const float* ctx, const float* kstat, float* dqkv, int B,
+                             int n, int heads, hipStream_t s);
+// Attention core (parts/mha.py:20-29): out [B][n][heads*32]; lse [B][heads][n] saved for the backward.
+int launch_attn_train_fwd(const float* qkv, float* out, float* lse, int B, int n, int heads, hipStream_t s);
+int launch_attn_train_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int B, int n,
+                          int heads, hipStream_t s);
+
+// Layout changes between the reference's parameter layout and the GEMM layout, for all tensors in one launch.
+struct RepackDesc {
+    long long src_off;      // offset in the flat reference-layout buffer
+    int n_out, n_in, taps;  // Cout, Cin, kh*kw
+    int transposed;         // 1: ConvTranspose2d weight [Cin][Cout][kh][kw]
+    long long f_off;        // forward GEMM layout [(tap*Cin + ci)][f_ld] at column 0 of this offset
+    int f_ld;
+    long long b_off;        // backward GEMM layout [(tap*Cout + co)][b_ld]
+    int b_ld;
+};
+int launch_repack(const RepackDesc* descs_dev, int n_desc, long long max_numel, const float* params, float* wf, float* wb,
+                  hipStream_t s);
+// grads_ref[src_off + idx] = dwf[...] for every described tensor
+int launch_unpack_grads(const RepackDesc* descs_dev, int n_desc, long long max_numel, const float* dwf, float* grads,
+                        hipStream_t s);
+
+// Global gradient norm and AdamW (torch.nn.utils.clip_grad_norm_, torch.optim.AdamW semantics).
+int launch_sqnorm(const float* g, long long n, float* out_sq, hipStream_t s);   // out_sq += sum g^2 (zeroed by the caller)
+struct AdamWArgs {
+    float* p;
+    const float* g;
+    float *m, *v;
+    long long n;
+    float lr, beta1, beta2, eps, weight_decay;
+    float bias1, bias2;     // 1 - beta^step
+    float max_norm;         // <= 0: no clipping
+    const float* sq_norm;   // device scalar: sum g^2 over ALL parameters
+    float grad_scale;       // multiplies g before everything else (1/world_size after a summing all-reduce)
+};
+int launch_adamw(const AdamWArgs& a, hipStream_t s);

@@ -1,0 +1,360 @@
+// Matrix-core kernels of the training step: the implicit GEMM over pixels that serves every convolution /
+// linear layer forward and its input gradient, and the pixel-reduction GEMM of the weight gradients
+// (what torch.nn.functional.conv2d / conv_transpose2d / linear and their autograd do in the reference:
+// diffusion_model_nemo/parts/convnext.py:11-13, utils.py:77-82, parts/mha.py:13-14,40-42, modules/unet.py:41,61-66).
+// gfx950, 256-thread workgroups = 4 wave64, v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate).
+#include "dmn_common.h"
+#include "dmn_train.h"
+
+namespace {
+
+__device__ __forceinline__ void decode_m(int m, int Ho, int Wo, int pm, int& b, int& oy, int& ox) {
+    const int hw = Ho * Wo;
+    b = m / hw;
+    const int rem = m - b * hw;
+    if (pm) {   // parity-major order inside an image: all pixels of one (oy & 1, ox & 1) class are consecutive
+        const int qn = hw >> 2, w2 = Wo >> 1;
+        const int ph = rem / qn, idx = rem - ph * qn;
+        const int yy = idx / w2, xx = idx - yy * w2;
+        oy = 2 * yy + (ph >> 1);
+        ox = 2 * xx + (ph & 1);
+    } else {
+        oy = rem / Wo;
+        ox = rem - oy * Wo;
+    }
+}
+
+// source coordinate of output coordinate o under kernel offset k; false when the tap falls outside / between pixels
+__device__ __forceinline__ bool src_coord(int o, int k, int stride, int pad, int tmode, int lim, int& i) {
+    if (tmode == 0) {
+        i = o * stride - pad + k;
+        return i >= 0 && i < lim;
+    }
+    const int t = o + pad - k;
+    if (t < 0) return false;
+    if (stride == 2) {
+        if (t & 1) return false;
+        i = t >> 1;
+    } else {
+        if (t % stride) return false;
+        i = t / stride;
+    }
+    return i < lim;
+}
+
+// BN: output channels per workgroup. 64 output pixels per workgroup, 16 per wave. The A operand (pixels x channels)
+// goes from global memory straight into the lanes that feed it to the matrix core: lane (r = lane & 15, q = lane >> 4)
+// loads channels 4q..4q+3 of a 16-channel step of pixel r, and instruction s of the step consumes element s, i.e.
+// the MFMA's k index q stands for channel 4q + s. The B operand (weights) is staged through LDS for the four waves,
+// read with the same channel permutation. One stage = 32 channels of one tap; the next stage's loads are in flight
+// while the current one is multiplied.
+// SLOW: Cin is not a multiple of 32 (the 7x7 ingest on 3 channels): k runs over the flattened (tap, channel) index
+// and every element is gathered by itself.
+template <int BN, bool SLOW>
+__global__ __launch_bounds__(256) void pgemm_kernel(const PGemmArgs a, const int M, const int pm) {
+    constexpr int LDB = BN + 4, NJ = BN / 16, TPR = BN / 4, RPP = 256 / TPR, NB = 32 / RPP;
+    __shared__ float Bs[32 * LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * BN;
+    const int mA = m0 + 16 * wave + r;
+    const bool mvalid = mA < M;
+    int pb = 0, poy = 0, pox = 0;
+    if (mvalid) decode_m(mA, a.Ho, a.Wo, pm, pb, poy, pox);
+    const int K = a.kh * a.kw * a.Cin;
+    int ky0 = 0, kx0 = 0, kst = 1;
+    if (pm) {   // the whole tile shares one parity class: only every second kernel row / column can contribute
+        const int hw = a.Ho * a.Wo;
+        const int ph = (m0 % hw) / (hw >> 2);
+        ky0 = ((ph >> 1) + a.pad) & 1;
+        kx0 = ((ph & 1) + a.pad) & 1;
+        kst = 2;
+    }
+    const int nky = (a.kh - ky0 + kst - 1) / kst, nkx = (a.kw - kx0 + kst - 1) / kst, nch = a.Cin >> 5;
+    const int nstage = SLOW ? (K + 31) / 32 : nky * nkx * nch;
+    const bool wvec = ((reinterpret_cast<uintptr_t>(a.w) & 15) == 0) && ((a.ldw & 3) == 0);
+
+    f32x4 acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 an0, an1, bn[NB];
+
+    auto load_stage = [&](int it) {
+        int krow0;
+        if constexpr (!SLOW) {
+            const int tapi = it / nch, cc = it - tapi * nch;
+            const int kyi = tapi / nkx;
+            const int ky = ky0 + kst * kyi, kx = kx0 + kst * (tapi - kyi * nkx);
+            int iy = 0, ix = 0;
+            const bool oky = src_coord(poy, ky, a.stride, a.pad, a.tmode, a.Hi, iy);
+            const bool okx = src_coord(pox, kx, a.stride, a.pad, a.tmode, a.Wi, ix);
+            an0 = an1 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (mvalid & oky & okx) {
+                const float* p = a.in + ((size_t)(pb * a.Hi + iy) * a.Wi + ix) * a.ldin + cc * 32 + 4 * q;
+                an0 = *reinterpret_cast<const f32x4*>(p);
+                an1 = *reinterpret_cast<const f32x4*>(p + 16);
+            }
+            krow0 = (ky * a.kw + kx) * a.Cin + cc * 32;
+        } else {
+            krow0 = it * 32;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int kk = krow0 + 16 * c + 4 * q + s;
+                    float v = 0.f;
+                    if (mvalid && kk < K) {
+                        const int tap = kk / a.Cin, ci = kk - tap * a.Cin;
+                        const int ky = tap / a.kw, kx = tap - ky * a.kw;
+                        int iy = 0, ix = 0;
+                        if (src_coord(poy, ky, a.stride, a.pad, a.tmode, a.Hi, iy) &&
+                            src_coord(pox, kx, a.stride, a.pad, a.tmode, a.Wi, ix))
+                            v = a.in[((size_t)(pb * a.Hi + iy) * a.Wi + ix) * a.ldin + ci];
+                    }
+                    if (c == 0) an0[s] = v; else an1[s] = v;
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int row = tid / TPR + i * RPP, n = n0 + (tid % TPR) * 4;
+            const int krow = krow0 + row;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (krow < K) {
+                const float* p = a.w + (size_t)krow * a.ldw + n;
+                if (wvec && n + 3 < a.N) {
+                    v = *reinterpret_cast<const f32x4*>(p);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < a.N) v[e] = p[e];
+                }
+            }
+            bn[i] = v;
+        }
+    };
+
+    load_stage(0);
+    for (int it = 0; it < nstage; ++it) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            *reinterpret_cast<f32x4*>(&Bs[(tid / TPR + i * RPP) * LDB + (tid % TPR) * 4]) = bn[i];
+        const f32x4 ac0 = an0, ac1 = an1;
+        __syncthreads();
+        if (it + 1 < nstage) load_stage(it + 1);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float av = c == 0 ? ac0[s] : ac1[s];
+                const float* brow = &Bs[(16 * c + 4 * q + s) * LDB + r];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, brow[16 * j], acc[j], 0, 0, 0);
+            }
+        __syncthreads();
+    }
+
+    // D[4q + i][r]: output pixel 16*wave + 4q + i of the tile, output channel 16j + r
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + 16 * wave + 4 * q + i;
+        if (m >= M) continue;
+        size_t pl = (size_t)m;
+        if (pm) {
+            int b, oy, ox;
+            decode_m(m, a.Ho, a.Wo, pm, b, oy, ox);
+            pl = (size_t)(b * a.Ho + oy) * a.Wo + ox;
+        }
+        float* o = a.out + pl * a.ldout;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = n0 + 16 * j + r;
+            if (n < a.N) {
+                float v = acc[j][i];
+                if (a.bias) v += a.bias[n];
+                if (a.accumulate) v += o[n];
+                o[n] = v;
+            }
+        }
+    }
+}
+
+// Weight gradient tile TM (weight rows = (tap, cin)) x TN (cout) per workgroup, reduced over a contiguous range of
+// output pixels; 32 pixels per stage staged through LDS pixel-major for both operands (the MFMA's k index is the
+// pixel). Partial sums of the pixel splits meet in dw through hardware float atomics.
+template <int TM, int TN, bool SLOW>
+__global__ __launch_bounds__(256) void wgemm_kernel(const WGemmArgs a, const int M, const int chunk) {
+    constexpr int LDX = TM + 16, LDY = TN + 16, NI = TM / 32, NJ = TN / 32;
+    constexpr int TPX = TM / 4, PPX = 256 / TPX, NX = 32 / PPX;   // threads per pixel row, pixels per pass, passes
+    constexpr int TPY = TN / 4, PPY = 256 / TPY, NY = 32 / PPY;
+    __shared__ float Xs[32 * LDX], Ys[32 * LDY];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int K = a.kh * a.kw * a.Cin;
+    const int krow0 = blockIdx.y * TM, n0 = blockIdx.z * TN;
+    const int ms = blockIdx.x * chunk, me = min(M, ms + chunk);
+    int tky = 0, tkx = 0, ci0 = 0;
+    if constexpr (!SLOW) {
+        const int tap = krow0 / a.Cin;
+        ci0 = krow0 - tap * a.Cin;
+        tky = tap / a.kw;
+        tkx = tap - tky * a.kw;
+    }
+    const bool yvec = ((reinterpret_cast<uintptr_t>(a.dy) & 15) == 0) && ((a.lddy & 3) == 0);
+    const int hw = a.Ho * a.Wo;
+
+    f32x4 acc[NI][NJ];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 xn[NX], yn[NY];
+
+    auto load_stage = [&](int mb) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int m = mb + tid / TPX + i * PPX, c4 = (tid % TPX) * 4;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (m < me) {
+                const int b = m / hw, rem = m - b * hw;
+                const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+                if constexpr (!SLOW) {
+                    int iy = 0, ix = 0;
+                    if (src_coord(oy, tky, a.stride, a.pad, a.tmode, a.Hi, iy) && src_coord(ox, tkx, a.stride, a.pad, a.tmode, a.Wi, ix))
+                        v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(b * a.Hi + iy) * a.Wi + ix) * a.ldx + ci0 + c4);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int row = krow0 + c4 + e;
+                        if (row < K) {
+                            const int tap = row / a.Cin, ci = row - tap * a.Cin;
+                            const int ky = tap / a.kw, kx = tap - ky * a.kw;
+                            int iy = 0, ix = 0;
+                            if (src_coord(oy, ky, a.stride, a.pad, a.tmode, a.Hi, iy) && src_coord(ox, kx, a.stride, a.pad, a.tmode, a.Wi, ix))
+                                v[e] = a.x[((size_t)(b * a.Hi + iy) * a.Wi + ix) * a.ldx + ci];
+                        }
+                    }
+                }
+            }
+            xn[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NY; ++i) {
+            const int m = mb + tid / TPY + i * PPY, n = n0 + (tid % TPY) * 4;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (m < me) {
+                const float* p = a.dy + (size_t)m * a.lddy + n;
+                if (yvec && n + 3 < a.N) {
+                    v = *reinterpret_cast<const f32x4*>(p);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < a.N) v[e] = p[e];
+                }
+            }
+            yn[i] = v;
+        }
+    };
+
+    if (ms < me) load_stage(ms);
+    for (int mb = ms; mb < me; mb += 32) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) *reinterpret_cast<f32x4*>(&Xs[(tid / TPX + i * PPX) * LDX + (tid % TPX) * 4]) = xn[i];
+#pragma unroll
+        for (int i = 0; i < NY; ++i) *reinterpret_cast<f32x4*>(&Ys[(tid / TPY + i * PPY) * LDY + (tid % TPY) * 4]) = yn[i];
+        __syncthreads();
+        if (mb + 32 < me) load_stage(mb + 32);
+#pragma unroll
+        for (int k4 = 0; k4 < 8; ++k4) {
+            const int p = 4 * k4 + q;
+            float av[NI], bv[NJ];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) av[i] = Xs[p * LDX + wm * (TM / 2) + 16 * i + r];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bv[j] = Ys[p * LDY + wn * (TN / 2) + 16 * j + r];
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    if (ms >= me) return;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = krow0 + wm * (TM / 2) + 16 * i + 4 * q + e;
+            if (row >= K) continue;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int n = n0 + wn * (TN / 2) + 16 * j + r;
+                if (n < a.N) unsafeAtomicAdd(a.dw + (size_t)row * a.lddw + n, acc[i][j][e]);
+            }
+        }
+}
+
+}   // namespace
+
+#define DMN_LAUNCH_CHECK()                                                        \
+    do {                                                                          \
+        hipError_t _e = hipGetLastError();                                        \
+        if (_e != hipSuccess) {                                                   \
+            dmn_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+            return DMN_ERR_HIP;                                                   \
+        }                                                                         \
+    } while (0)
+
+int launch_pgemm(const PGemmArgs& a, hipStream_t s) {
+    DMN_REQUIRE(a.in && a.w && a.out && a.B > 0 && a.N > 0 && a.Cin > 0, DMN_ERR_INVALID, "pgemm: bad argument");
+    DMN_REQUIRE(a.bf16 == 0, DMN_ERR_INVALID, "pgemm: only the fp32 matrix path is built");
+    const long long Ml = (long long)a.B * a.Ho * a.Wo;
+    DMN_REQUIRE(Ml < (1ll << 31) - 64, DMN_ERR_LIMIT, "pgemm: %lld output pixels", Ml);
+    const int M = (int)Ml;
+    const bool slow = (a.Cin & 31) != 0 || (a.ldin & 3) != 0 || (reinterpret_cast<uintptr_t>(a.in) & 15) != 0;
+    const int hw = a.Ho * a.Wo;
+    const int pm = (!slow && a.tmode == 1 && a.stride == 2 && (a.Ho & 1) == 0 && (a.Wo & 1) == 0 && ((hw >> 2) % 64) == 0) ? 1 : 0;
+    const int bn = a.N > 32 ? 64 : 32;
+    dim3 grid((M + 63) / 64, (a.N + bn - 1) / bn);
+    if (bn == 64) {
+        if (slow) pgemm_kernel<64, true><<<grid, 256, 0, s>>>(a, M, pm);
+        else pgemm_kernel<64, false><<<grid, 256, 0, s>>>(a, M, pm);
+    } else {
+        if (slow) pgemm_kernel<32, true><<<grid, 256, 0, s>>>(a, M, pm);
+        else pgemm_kernel<32, false><<<grid, 256, 0, s>>>(a, M, pm);
+    }
+    DMN_LAUNCH_CHECK();
+    return DMN_OK;
+}
+
+int launch_wgemm(const WGemmArgs& a, hipStream_t s) {
+    DMN_REQUIRE(a.x && a.dy && a.dw && a.B > 0 && a.N > 0 && a.Cin > 0, DMN_ERR_INVALID, "wgemm: bad argument");
+    DMN_REQUIRE(a.bf16 == 0, DMN_ERR_INVALID, "wgemm: only the fp32 matrix path is built");
+    const long long Ml = (long long)a.B * a.Ho * a.Wo;
+    DMN_REQUIRE(Ml < (1ll << 31) - 64, DMN_ERR_LIMIT, "wgemm: %lld output pixels", Ml);
+    const int M = (int)Ml;
+    const int K = a.kh * a.kw * a.Cin;
+    const bool big_m = (a.Cin % 64) == 0, big_n = a.N > 32;
+    const bool slow = (a.Cin & 31) != 0 || (a.ldx & 3) != 0 || (reinterpret_cast<uintptr_t>(a.x) & 15) != 0;
+    const int tm = (!slow && big_m) ? 64 : 32, tn = big_n ? 64 : 32;
+    const int rt = (K + tm - 1) / tm, ct = (a.N + tn - 1) / tn;
+    int nsplit = 2048 / (rt * ct);
+    const int max_split = (M + 127) / 128;
+    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit < 1) nsplit = 1;
+    int chunk = (M + nsplit - 1) / nsplit;
+    chunk = (chunk + 31) & ~31;
+    nsplit = (M + chunk - 1) / chunk;
+    dim3 grid(nsplit, rt, ct);
+    DMN_REQUIRE(rt <= 65535 && ct <= 65535, DMN_ERR_LIMIT, "wgemm: grid %d x %d", rt, ct);
+    if (slow) {
+        if (tn == 64) wgemm_kernel<32, 64, true><<<grid, 256, 0, s>>>(a, M, chunk);
+        else wgemm_kernel<32, 32, true><<<grid, 256, 0, s>>>(a, M, chunk);
+    } else if (tm == 64) {
+        if (tn == 64) wgemm_kernel<64, 64, false><<<grid, 256, 0, s>>>(a, M, chunk);
+        else wgemm_kernel<64, 32, false><<<grid, 256, 0, s>>>(a, M, chunk);
+    } else {
+        if (tn == 64) wgemm_kernel<32, 64, false><<<grid, 256, 0, s>>>(a, M, chunk);
+        else wgemm_kernel<32, 32, false><<<grid, 256, 0, s>>>(a, M, chunk);
+    }
+    DMN_LAUNCH_CHECK();
+    return DMN_OK;
+}

@@ -1,0 +1,885 @@
+// Non-GEMM kernels of the training step: GroupNorm forward / backward, activations, the attention cores with their
+// backward passes, loss, layout changes and the optimiser. NHWC float32 throughout. Reference semantics:
+// torch.nn.GroupNorm / SiLU / GELU (diffusion_model_nemo/parts/convnext.py:11-23, modules/unet.py:61-66),
+// LinearAttention / Attention (parts/mha.py:16-30,44-59), DiffusionLoss (loss/simple_loss.py:37-45),
+// q_sample (modules/gaussian_diffusion.py:104-116).
+#include "dmn_common.h"
+#include "dmn_train.h"
+
+#define DMN_LAUNCH_CHECK()                                                        \
+    do {                                                                          \
+        hipError_t _e = hipGetLastError();                                        \
+        if (_e != hipSuccess) {                                                   \
+            dmn_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+            return DMN_ERR_HIP;                                                   \
+        }                                                                         \
+    } while (0)
+
+namespace {
+
+constexpr float kGnEps = 1e-5f;
+
+// sum over the 256 threads of a workgroup; every thread receives the result. sh: >= 4 floats, reusable after return.
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__device__ __forceinline__ float sigmoid_f(float z) { return 1.0f / (1.0f + expf(-z)); }
+__device__ __forceinline__ float silu_grad(float z) {
+    const float sg = sigmoid_f(z);
+    return sg * (1.0f + z * (1.0f - sg));
+}
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+}
+
+// ---- column sums --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int ld, long long rows, int C, int cw,
+                                                     float* __restrict__ out) {
+    __shared__ float sh[256];
+    const int tid = threadIdx.x, nrl = 256 / cw;
+    const int cl = tid % cw, rl = tid / cw;
+    const int col = blockIdx.y * 256 + cl;
+    float acc = 0.f;
+    if (rl < nrl && col < C)
+        for (long long row = (long long)blockIdx.x * nrl + rl; row < rows; row += (long long)gridDim.x * nrl) acc += in[row * ld + col];
+    sh[tid] = acc;
+    __syncthreads();
+    if (rl == 0 && col < C) {
+        float t = 0.f;
+        for (int i = 0; i < nrl; ++i) t += sh[i * cw + cl];
+        unsafeAtomicAdd(out + col, t);
+    }
+}
+
+// ---- GroupNorm ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, int HW, int C, int G, float* __restrict__ stats) {
+    __shared__ float sh[4];
+    const int bg = blockIdx.x, b = bg / G, g = bg - b * G;
+    const int cg4 = (C / G) >> 2;
+    const long long total = (long long)HW * cg4;
+    const float* base = x + (size_t)b * HW * C + g * (C / G);
+    float s = 0.f, ss = 0.f;
+    for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < total; i += (long long)gridDim.y * 256) {
+        const long long p = i / cg4;
+        const int c4 = (int)(i - p * cg4);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(base + p * C + 4 * c4);
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+        ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+    s = block_sum(s, sh);
+    ss = block_sum(ss, sh);
+    if (threadIdx.x == 0) {
+        unsafeAtomicAdd(stats + 2 * bg, s);
+        unsafeAtomicAdd(stats + 2 * bg + 1, ss);
+    }
+}
+
+__device__ __forceinline__ void gn_mean_rstd(const float* stats, int bg, float inv_cnt, float& mean, float& rstd) {
+    const float s = stats[2 * bg], ss = stats[2 * bg + 1];
+    mean = s * inv_cnt;
+    const float var = fmaxf(ss * inv_cnt - mean * mean, 0.f);
+    rstd = 1.0f / sqrtf(var + kGnEps);
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
+    const int c4n = a.C >> 2;
+    const long long total = (long long)a.B * a.HW * c4n;
+    const int Cg = a.C / a.G;
+    const float inv_cnt = 1.0f / ((float)Cg * (float)a.HW);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long pix = i / c4n;
+        const int c = 4 * (int)(i - pix * c4n);
+        const int b = (int)(pix / a.HW);
+        float mean, rstd;
+        gn_mean_rstd(a.stats, b * a.G + c / Cg, inv_cnt, mean, rstd);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + pix * a.C + c);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(a.gamma + c), be = *reinterpret_cast<const f32x4*>(a.beta + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float z = (v[e] - mean) * rstd * ga[e] + be[e];
+            if (a.act) z = z * sigmoid_f(z);
+            if (a.tb) z += a.tb[(size_t)b * a.tb_ld + c + e];
+            o[e] = z;
+        }
+        *reinterpret_cast<f32x4*>(a.y + pix * a.C + c) = o;
+    }
+}
+
+// per (image, channel): sum dz * xhat, sum dz, sum dy. grid (splits, B); thread = fixed 4 channels, strided pixels.
+__global__ __launch_bounds__(256) void gn_bwd_sums_kernel(const GnArgs a) {
+    __shared__ float sh[256 * 12];
+    const int b = blockIdx.y, c4n = a.C >> 2, tid = threadIdx.x;
+    const int c = 4 * (tid % c4n), pl = tid / c4n, npl = 256 / c4n;
+    const int Cg = a.C / a.G;
+    const float inv_cnt = 1.0f / ((float)Cg * (float)a.HW);
+    float mean, rstd;
+    gn_mean_rstd(a.stats, b * a.G + c / Cg, inv_cnt, mean, rstd);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(a.gamma + c), be = *reinterpret_cast<const f32x4*>(a.beta + c);
+    float s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    const size_t img = (size_t)b * a.HW * a.C;
+    for (int p = blockIdx.x * npl + pl; p < a.HW; p += gridDim.x * npl) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + img + (size_t)p * a.C + c);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(a.dy + img + (size_t)p * a.C + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (v[e] - mean) * rstd;
+            float dz = d[e];
+            if (a.act) dz *= silu_grad(xh * ga[e] + be[e]);
+            s0[e] += dz * xh;
+            s1[e] += dz;
+            s2[e] += d[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        sh[tid * 12 + e] = s0[e];
+        sh[tid * 12 + 4 + e] = s1[e];
+        sh[tid * 12 + 8 + e] = s2[e];
+    }
+    __syncthreads();
+    // thread (channel group, which of 12) sums over the pixel lanes
+    for (int o = tid; o < c4n * 12; o += 256) {
+        const int cg = o / 12, k = o - cg * 12;
+        float t = 0.f;
+        for (int l = 0; l < npl; ++l) t += sh[(l * c4n + cg) * 12 + k];
+        const int ch = 4 * cg + (k & 3), which = k >> 2;
+        unsafeAtomicAdd(a.sums + ((size_t)b * a.C + ch) * 3 + which, t);
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GnArgs a) {
+    __shared__ float S1[64], S2[64];
+    const int b = blockIdx.y, tid = threadIdx.x, Cg = a.C / a.G, c4n = a.C >> 2;
+    if (tid < a.G) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int c = tid * Cg; c < (tid + 1) * Cg; ++c) {
+            const float g = a.gamma[c];
+            t1 += g * a.sums[((size_t)b * a.C + c) * 3 + 1];
+            t2 += g * a.sums[((size_t)b * a.C + c) * 3 + 0];
+        }
+        S1[tid] = t1;
+        S2[tid] = t2;
+    }
+    __syncthreads();
+    const float inv_cnt = 1.0f / ((float)Cg * (float)a.HW);
+    const size_t img = (size_t)b * a.HW * a.C;
+    const long long total = (long long)a.HW * c4n;
+    for (long long i = (long long)blockIdx.x * 256 + tid; i < total; i += (long long)gridDim.x * 256) {
+        const long long p = i / c4n;
+        const int c = 4 * (int)(i - p * c4n), g = c / Cg;
+        float mean, rstd;
+        gn_mean_rstd(a.stats, b * a.G + g, inv_cnt, mean, rstd);
+        const float m1 = S1[g] * inv_cnt, m2 = S2[g] * inv_cnt;
+        const size_t off = img + (size_t)p * a.C + c;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + off), d = *reinterpret_cast<const f32x4*>(a.dy + off);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(a.gamma + c), be = *reinterpret_cast<const f32x4*>(a.beta + c);
+        f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.accumulate) o = *reinterpret_cast<const f32x4*>(a.dx + off);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (v[e] - mean) * rstd;
+            float dz = d[e];
+            if (a.act) dz *= silu_grad(xh * ga[e] + be[e]);
+            o[e] += rstd * (dz * ga[e] - m1 - xh * m2);
+        }
+        *reinterpret_cast<f32x4*>(a.dx + off) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_params_kernel(const GnArgs a) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= a.C) return;
+    float t0 = 0.f, t1 = 0.f;
+    for (int b = 0; b < a.B; ++b) {
+        const float* s = a.sums + ((size_t)b * a.C + c) * 3;
+        t0 += s[0];
+        t1 += s[1];
+        if (a.dtb) a.dtb[(size_t)b * a.tb_ld + c] += s[2];
+    }
+    a.dgamma[c] += t0;
+    a.dbeta[c] += t1;
+}
+
+// ---- elementwise --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void axpby_kernel(float* __restrict__ dst, const float* __restrict__ src, long long n, int acc) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        dst[i] = acc ? dst[i] + src[i] : src[i];
+}
+__global__ __launch_bounds__(256) void add_kernel(float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ b, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = a[i] + b[i];
+}
+__global__ __launch_bounds__(256) void copy_slice_kernel(float* __restrict__ dst, int ldd, int doff, const float* __restrict__ src, int lds,
+                                                         int soff, int C, long long rows, int acc) {
+    const long long total = rows * C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long row = i / C;
+        const int c = (int)(i - row * C);
+        const float v = src[row * lds + soff + c];
+        float* d = dst + row * ldd + doff + c;
+        *d = acc ? *d + v : v;
+    }
+}
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long n, int act) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float v = x[i];
+        y[i] = act == 0 ? v * sigmoid_f(v) : gelu_f(v);
+    }
+}
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                                      long long n, int act, int acc) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float v = x[i];
+        const float g = dy[i] * (act == 0 ? silu_grad(v) : gelu_grad(v));
+        dx[i] = acc ? dx[i] + g : g;
+    }
+}
+// parts/positional_encoding.py:11-18: frequencies exp(i * -(ln 1e4 / (half - 1))) in float32, [sin | cos]
+__global__ void sinus_kernel(const void* t, int t_is_float, int B, int dim, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * dim) return;
+    const int b = i / dim, j = i - b * dim, half = dim >> 1;
+    const float tv = t_is_float ? reinterpret_cast<const float*>(t)[b] : (float)reinterpret_cast<const long long*>(t)[b];
+    const float k = (float)(9.210340371976184 / (double)(half - 1));
+    const float f = expf((float)(j < half ? j : j - half) * -k);
+    const float arg = tv * f;
+    out[i] = j < half ? sinf(arg) : cosf(arg);
+}
+
+__global__ __launch_bounds__(256) void train_ingest_kernel(const float* __restrict__ x0, const float* __restrict__ eps,
+                                                           const long long* __restrict__ t, const float* __restrict__ sa,
+                                                           const float* __restrict__ sb, float* __restrict__ xt, float* __restrict__ tgt,
+                                                           int B, int C, int HW) {
+    const long long total = (long long)B * C * HW;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        // i indexes NHWC
+        const int c = (int)(i % C);
+        const long long pix = i / C;
+        const int b = (int)(pix / HW), p = (int)(pix - (long long)b * HW);
+        const size_t src = ((size_t)b * C + c) * HW + p;
+        const float e = eps ? eps[src] : 0.f;
+        float v = x0[src];
+        if (sa) {
+            const long long tb = t[b];
+            v = sa[tb] * v + sb[tb] * e;
+        }
+        xt[i] = v;
+        if (tgt) tgt[i] = e;
+    }
+}
+
+__global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ out, const float* __restrict__ tgt, long long n, int kind,
+                                                   float* __restrict__ loss, float* __restrict__ dout) {
+    __shared__ float sh[4];
+    const float inv = 1.0f / (float)n;
+    float acc = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float d = out[i] - tgt[i];
+        float l, g;
+        if (kind == 1) {
+            l = d * d;
+            g = 2.0f * d;
+        } else if (kind == 0) {
+            l = fabsf(d);
+            g = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        } else {
+            const float ad = fabsf(d);
+            l = ad < 1.f ? 0.5f * d * d : ad - 0.5f;
+            g = ad < 1.f ? d : (d > 0.f ? 1.f : -1.f);
+        }
+        acc += l;
+        dout[i] = g * inv;
+    }
+    acc = block_sum(acc, sh);
+    if (threadIdx.x == 0) unsafeAtomicAdd(loss, acc * inv);
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, int HW) {
+    const long long total = (long long)B * C * HW;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int p = (int)(i % HW);
+        const long long bc = i / HW;
+        const int c = (int)(bc % C), b = (int)(bc / C);
+        out[i] = in[((size_t)b * HW + p) * C + c];
+    }
+}
+
+// ---- linear attention core ------------------------------------------------------------------------------------
+// One workgroup per (image, head). qkv row of pixel n: [q (heads*32) | k (heads*32) | v (heads*32)].
+constexpr int kD = 32;
+constexpr float kScale = 0.17677669529663687f;   // 32^-0.5
+
+// softmax over the 32 channels of q for 64 pixels staged in LDS rows of 33 floats: thread (p = tid>>2, part = tid&3)
+// owns channels 8*part..+7; afterwards Qs holds the UNSCALED softmax.
+__device__ __forceinline__ void softmax_q_rows(float* Qs, int tid) {
+    const int p = tid >> 2, part = tid & 3;
+    float* row = Qs + p * 33 + 8 * part;
+    float mx = row[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) mx = fmaxf(mx, row[i]);
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+    float e[8], sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        e[i] = expf(row[i] - mx);
+        sum += e[i];
+    }
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) row[i] = e[i] * inv;
+}
+
+// loads a [64 pixels][32] slice (channel offset coff of the row) into LDS rows of 33 floats; pixels >= n become `fill`
+__device__ __forceinline__ void load_tile(float* S, const float* base, int ld, int coff, int p0, int n, int tid, float fill) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = tid + 256 * i, p = idx >> 5, d = idx & 31;
+        S[p * 33 + d] = (p0 + p < n) ? base[(size_t)(p0 + p) * ld + coff + d] : fill;
+    }
+}
+
+__global__ __launch_bounds__(256) void linattn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, float* __restrict__ ctx_out,
+                                                          float* __restrict__ kstat, int n, int heads) {
+    __shared__ float Ks[64 * 33], Vs[64 * 33], Cx[32 * 32], red[8 * 32], kmx[32];
+    const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads, tid = threadIdx.x;
+    const int hid = heads * kD, ld = 3 * hid;
+    const float* base = qkv + (size_t)b * n * ld;
+    // pass 1: max over pixels of every k channel
+    {
+        const int d = tid & 31, pl = tid >> 5;
+        float mx = -INFINITY;
+        for (int p = pl; p < n; p += 8) mx = fmaxf(mx, base[(size_t)p * ld + hid + h * kD + d]);
+        red[pl * 32 + d] = mx;
+        __syncthreads();
+        if (tid < 32) {
+            float m = red[tid];
+            for (int i = 1; i < 8; ++i) m = fmaxf(m, red[i * 32 + tid]);
+            kmx[tid] = m;
+        }
+        __syncthreads();
+    }
+    // pass 2: ctx[d][e] = sum_n exp(k[n][d] - max[d]) v[n][e], and the softmax denominators
+    const int d = tid >> 3, e4 = (tid & 7) * 4;
+    float acc[4] = {0, 0, 0, 0}, ks = 0.f;
+    for (int p0 = 0; p0 < n; p0 += 64) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + 256 * i, p = idx >> 5, dd = idx & 31;
+            const bool ok = p0 + p < n;
+            const float* row = base + (size_t)(p0 + p) * ld;
+            Ks[p * 33 + dd] = ok ? expf(row[hid + h * kD + dd] - kmx[dd]) : 0.f;
+            Vs[p * 33 + dd] = ok ? row[2 * hid + h * kD + dd] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int p = 0; p < 64; ++p) {
+            const float kv = Ks[p * 33 + d];
+            ks += kv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += kv * Vs[p * 33 + e4 + e];
+        }
+    }
+    {
+        const float inv = 1.0f / ks;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float c = acc[e] * inv;
+            Cx[d * 32 + e4 + e] = c;
+            ctx_out[(size_t)bh * 1024 + d * 32 + e4 + e] = c;
+        }
+        if ((tid & 7) == 0) {
+            kstat[(size_t)bh * 64 + d] = kmx[d];
+            kstat[(size_t)bh * 64 + 32 + d] = ks;
+        }
+    }
+    // pass 3: out[n][e] = sum_d ctx[d][e] * softmax_d(q[n])[d] * scale
+    float* Qs = Ks;
+    const int p = tid >> 2, e8 = (tid & 3) * 8;
+    for (int p0 = 0; p0 < n; p0 += 64) {
+        __syncthreads();
+        load_tile(Qs, base, ld, h * kD, p0, n, tid, 0.f);
+        __syncthreads();
+        softmax_q_rows(Qs, tid);
+        __syncthreads();
+        float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 8
+        for (int dd = 0; dd < 32; ++dd) {
+            const float qv = Qs[p * 33 + dd];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += qv * Cx[dd * 32 + e8 + e];
+        }
+        if (p0 + p < n) {
+            float* orow = out + ((size_t)b * n + p0 + p) * hid + h * kD + e8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) orow[e] = o[e] * kScale;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void linattn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                          const float* __restrict__ ctx_in, const float* __restrict__ kstat,
+                                                          float* __restrict__ dqkv, int n, int heads) {
+    __shared__ float As[64 * 33], Bs[64 * 33], Cs[64 * 33], Cx[32 * 32], Dc[32 * 32], sv[32], kmx[32], kin[32];
+    const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads, tid = threadIdx.x;
+    const int hid = heads * kD, ld = 3 * hid;
+    const float* base = qkv + (size_t)b * n * ld;
+    const float* dob = dout + (size_t)b * n * hid;
+    float* dqb = dqkv + (size_t)b * n * ld;
+    for (int i = tid; i < 1024; i += 256) Cx[i] = ctx_in[(size_t)bh * 1024 + i];
+    if (tid < 32) {
+        kmx[tid] = kstat[(size_t)bh * 64 + tid];
+        kin[tid] = 1.0f / kstat[(size_t)bh * 64 + 32 + tid];
+    }
+    // pass A: dctx[d][e] = scale * sum_n softmax(q[n])[d] * dout[n][e]
+    {
+        const int d = tid >> 3, e4 = (tid & 7) * 4;
+        float acc[4] = {0, 0, 0, 0};
+        for (int p0 = 0; p0 < n; p0 += 64) {
+            __syncthreads();
+            load_tile(As, base, ld, h * kD, p0, n, tid, 0.f);
+            load_tile(Bs, dob, hid, h * kD, p0, n, tid, 0.f);   // rows beyond n are zero: they add nothing
+            __syncthreads();
+            softmax_q_rows(As, tid);
+            __syncthreads();
+#pragma unroll 8
+            for (int p = 0; p < 64; ++p) {
+                const float qv = As[p * 33 + d];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += qv * Bs[p * 33 + e4 + e];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Dc[d * 32 + e4 + e] = acc[e] * kScale;
+        __syncthreads();
+        if (tid < 32) {
+            float t = 0.f;
+            for (int e = 0; e < 32; ++e) t += Dc[tid * 32 + e] * Cx[tid * 32 + e];
+            sv[tid] = t;
+        }
+    }
+    // pass B: per pixel dq, dk, dv. Thread (p = tid>>2, 8 channels j8 = 8*(tid&3)).
+    const int p = tid >> 2, j8 = (tid & 3) * 8;
+    for (int p0 = 0; p0 < n; p0 += 64) {
+        __syncthreads();
+        load_tile(As, base, ld, h * kD, p0, n, tid, 0.f);             // q -> softmax
+        load_tile(Bs, dob, hid, h * kD, p0, n, tid, 0.f);            // dout
+        load_tile(Cs, base, ld, 2 * hid + h * kD, p0, n, tid, 0.f);  // v
+        __syncthreads();
+        softmax_q_rows(As, tid);
+        __syncthreads();
+        const bool ok = p0 + p < n;
+        // dqhat[d] = sum_e ctx[d][e] dout[e]; dq = scale * s[d] * (dqhat[d] - sum_d' s[d'] dqhat[d'])
+        float dqh[8], dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float t = 0.f;
+#pragma unroll 8
+            for (int e = 0; e < 32; ++e) t += Cx[(j8 + i) * 32 + e] * Bs[p * 33 + e];
+            dqh[i] = t;
+            dot += As[p * 33 + j8 + i] * t;
+        }
+        dot += __shfl_xor(dot, 1, 64);
+        dot += __shfl_xor(dot, 2, 64);
+        // dkhat[d] = sum_e dctx[d][e] v[e]; dk = khat[d] * (dkhat[d] - sv[d])
+        float dk[8], kh[8];
+        const float* krow = base + (size_t)(p0 + p) * ld + hid + h * kD + j8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float t = 0.f;
+#pragma unroll 8
+            for (int e = 0; e < 32; ++e) t += Dc[(j8 + i) * 32 + e] * Cs[p * 33 + e];
+            kh[i] = ok ? expf(krow[i] - kmx[j8 + i]) * kin[j8 + i] : 0.f;
+            dk[i] = kh[i] * (t - sv[j8 + i]);
+        }
+        __syncthreads();
+        // khat of the pixel into Cs (v no longer needed) for the dv product
+#pragma unroll
+        for (int i = 0; i < 8; ++i) Cs[p * 33 + j8 + i] = kh[i];
+        __syncthreads();
+        float dv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 8
+        for (int dd = 0; dd < 32; ++dd) {
+            const float kv = Cs[p * 33 + dd];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dv[i] += kv * Dc[dd * 32 + j8 + i];
+        }
+        if (ok) {
+            float* row = dqb + (size_t)(p0 + p) * ld + h * kD + j8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                row[i] = kScale * As[p * 33 + j8 + i] * (dqh[i] - dot);
+                row[hid + i] = dk[i];
+                row[2 * hid + i] = dv[i];
+            }
+        }
+    }
+}
+
+// ---- softmax attention core (bottleneck) ------------------------------------------------------------------------
+// One workgroup per (image, head); thread = query row (rows beyond 256 in further rounds); keys in LDS tiles of 64.
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, float* __restrict__ lse,
+                                                       int n, int heads) {
+    __shared__ float Ks[64 * 33], Vs[64 * 33];
+    const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads, tid = threadIdx.x;
+    const int hid = heads * kD, ld = 3 * hid;
+    const float* base = qkv + (size_t)b * n * ld;
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        const int i = i0 + tid;
+        const bool ok = i < n;
+        float qv[32], acc[32], m = -INFINITY, l = 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) {
+            qv[d] = ok ? base[(size_t)i * ld + h * kD + d] * kScale : 0.f;
+            acc[d] = 0.f;
+        }
+        for (int j0 = 0; j0 < n; j0 += 64) {
+            __syncthreads();
+            load_tile(Ks, base, ld, hid + h * kD, j0, n, tid, 0.f);
+            load_tile(Vs, base, ld, 2 * hid + h * kD, j0, n, tid, 0.f);
+            __syncthreads();
+            const int jn = min(64, n - j0);
+            for (int j = 0; j < jn; ++j) {
+                float sc = 0.f;
+#pragma unroll
+                for (int d = 0; d < 32; ++d) sc += qv[d] * Ks[j * 33 + d];
+                const float mn = fmaxf(m, sc);
+                const float corr = expf(m - mn), pj = expf(sc - mn);
+                l = l * corr + pj;
+#pragma unroll
+                for (int d = 0; d < 32; ++d) acc[d] = acc[d] * corr + pj * Vs[j * 33 + d];
+                m = mn;
+            }
+        }
+        if (ok) {
+            const float inv = 1.0f / l;
+            float* orow = out + ((size_t)b * n + i) * hid + h * kD;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) orow[d] = acc[d] * inv;
+            lse[(size_t)bh * n + i] = m + logf(l);
+        }
+    }
+}
+
+// dq (thread = query) then dk, dv (thread = key). Dsh: per-query sum_e dout*out kept in global scratch `dsum`
+// ([B*heads][n], the tail of the lse allocation is not used for this: the caller passes a separate buffer).
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
+                                                       const float* __restrict__ dout, const float* __restrict__ lse,
+                                                       float* __restrict__ dqkv, float* __restrict__ dsum, int n, int heads) {
+    __shared__ float As[64 * 33], Bs[64 * 33], Ls[64], Ds[64];
+    const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads, tid = threadIdx.x;
+    const int hid = heads * kD, ld = 3 * hid;
+    const float* base = qkv + (size_t)b * n * ld;
+    const float* ob = out + (size_t)b * n * hid;
+    const float* dob = dout + (size_t)b * n * hid;
+    float* dqb = dqkv + (size_t)b * n * ld;
+    // phase 1: dq
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        const int i = i0 + tid;
+        const bool ok = i < n;
+        float qv[32], dov[32], dq[32], Di = 0.f;
+        const float li = ok ? lse[(size_t)bh * n + i] : 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) {
+            qv[d] = ok ? base[(size_t)i * ld + h * kD + d] * kScale : 0.f;
+            dov[d] = ok ? dob[(size_t)i * hid + h * kD + d] : 0.f;
+            Di += dov[d] * (ok ? ob[(size_t)i * hid + h * kD + d] : 0.f);
+            dq[d] = 0.f;
+        }
+        if (ok) dsum[(size_t)bh * n + i] = Di;
+        for (int j0 = 0; j0 < n; j0 += 64) {
+            __syncthreads();
+            load_tile(As, base, ld, hid + h * kD, j0, n, tid, 0.f);
+            load_tile(Bs, base, ld, 2 * hid + h * kD, j0, n, tid, 0.f);
+            __syncthreads();
+            const int jn = min(64, n - j0);
+            for (int j = 0; j < jn; ++j) {
+                float sc = 0.f, dp = 0.f;
+#pragma unroll
+                for (int d = 0; d < 32; ++d) {
+                    sc += qv[d] * As[j * 33 + d];
+                    dp += dov[d] * Bs[j * 33 + d];
+                }
+                const float ds = expf(sc - li) * (dp - Di);
+#pragma unroll
+                for (int d = 0; d < 32; ++d) dq[d] += ds * As[j * 33 + d];
+            }
+        }
+        if (ok) {
+            float* row = dqb + (size_t)i * ld + h * kD;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) row[d] = dq[d] * kScale;
+        }
+    }
+    __threadfence_block();
+    // phase 2: dk, dv
+    for (int j0 = 0; j0 < n; j0 += 256) {
+        const int j = j0 + tid;
+        const bool ok = j < n;
+        float kv[32], vv[32], dk[32], dv[32];
+#pragma unroll
+        for (int d = 0; d < 32; ++d) {
+            kv[d] = ok ? base[(size_t)j * ld + hid + h * kD + d] : 0.f;
+            vv[d] = ok ? base[(size_t)j * ld + 2 * hid + h * kD + d] : 0.f;
+            dk[d] = dv[d] = 0.f;
+        }
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            __syncthreads();
+            load_tile(As, base, ld, h * kD, i0, n, tid, 0.f);     // q (unscaled)
+            load_tile(Bs, dob, hid, h * kD, i0, n, tid, 0.f);    // dout
+            if (tid < 64) {
+                const bool in = i0 + tid < n;
+                Ls[tid] = in ? lse[(size_t)bh * n + i0 + tid] : 0.f;
+                Ds[tid] = in ? dsum[(size_t)bh * n + i0 + tid] : 0.f;
+            }
+            __syncthreads();
+            const int in_ = min(64, n - i0);
+            for (int i = 0; i < in_; ++i) {
+                float sc = 0.f, dp = 0.f;
+#pragma unroll
+                for (int d = 0; d < 32; ++d) {
+                    sc += As[i * 33 + d] * kv[d];
+                    dp += Bs[i * 33 + d] * vv[d];
+                }
+                const float pij = expf(sc * kScale - Ls[i]);
+                const float ds = pij * (dp - Ds[i]) * kScale;
+#pragma unroll
+                for (int d = 0; d < 32; ++d) {
+                    dv[d] += pij * Bs[i * 33 + d];
+                    dk[d] += ds * As[i * 33 + d];
+                }
+            }
+        }
+        if (ok) {
+            float* row = dqb + (size_t)j * ld + hid + h * kD;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) {
+                row[d] = dk[d];
+                row[hid + d] = dv[d];
+            }
+        }
+    }
+}
+
+// ---- parameter layout changes -----------------------------------------------------------------------------------
+__device__ __forceinline__ void repack_index(const RepackDesc& d, long long idx, int& co, int& ci, int& tap) {
+    tap = (int)(idx % d.taps);
+    const long long r = idx / d.taps;
+    if (d.transposed) {
+        co = (int)(r % d.n_out);
+        ci = (int)(r / d.n_out);
+    } else {
+        ci = (int)(r % d.n_in);
+        co = (int)(r / d.n_in);
+    }
+}
+__global__ __launch_bounds__(256) void repack_kernel(const RepackDesc* __restrict__ descs, const float* __restrict__ params,
+                                                     float* __restrict__ wf, float* __restrict__ wb) {
+    const RepackDesc d = descs[blockIdx.y];
+    const long long numel = (long long)d.n_out * d.n_in * d.taps;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < numel; idx += (long long)gridDim.x * 256) {
+        int co, ci, tap;
+        repack_index(d, idx, co, ci, tap);
+        const float v = params[d.src_off + idx];
+        wf[d.f_off + ((long long)tap * d.n_in + ci) * d.f_ld + co] = v;
+        wb[d.b_off + ((long long)tap * d.n_out + co) * d.b_ld + ci] = v;
+    }
+}
+__global__ __launch_bounds__(256) void unpack_grads_kernel(const RepackDesc* __restrict__ descs, const float* __restrict__ dwf,
+                                                           float* __restrict__ grads) {
+    const RepackDesc d = descs[blockIdx.y];
+    const long long numel = (long long)d.n_out * d.n_in * d.taps;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < numel; idx += (long long)gridDim.x * 256) {
+        int co, ci, tap;
+        repack_index(d, idx, co, ci, tap);
+        grads[d.src_off + idx] = dwf[d.f_off + ((long long)tap * d.n_in + ci) * d.f_ld + co];
+    }
+}
+
+// ---- optimiser ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, long long n, float* __restrict__ out) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) acc += g[i] * g[i];
+    acc = block_sum(acc, sh);
+    if (threadIdx.x == 0) unsafeAtomicAdd(out, acc);
+}
+__global__ __launch_bounds__(256) void adamw_kernel(const AdamWArgs a) {
+    float coef = a.grad_scale;
+    if (a.max_norm > 0.f) {
+        const float norm = sqrtf(*a.sq_norm) * a.grad_scale;
+        coef *= fminf(1.0f, a.max_norm / (norm + 1e-6f));
+    }
+    const float step_size = a.lr / a.bias1, inv_sqrt_b2 = 1.0f / sqrtf(a.bias2);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256) {
+        const float g = a.g[i] * coef;
+        float p = a.p[i] * (1.0f - a.lr * a.weight_decay);
+        const float m = a.beta1 * a.m[i] + (1.0f - a.beta1) * g;
+        const float v = a.beta2 * a.v[i] + (1.0f - a.beta2) * g * g;
+        a.m[i] = m;
+        a.v[i] = v;
+        p -= step_size * m / (sqrtf(v) * inv_sqrt_b2 + a.eps);
+        a.p[i] = p;
+    }
+}
+
+inline int grid_for(long long n, int per_block = 256, int cap = 8192) {
+    long long g = (n + per_block - 1) / per_block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}   // namespace
+
+int launch_colsum(const float* in, int ld, long long rows, int C, float* out, hipStream_t s) {
+    const int cw = C < 256 ? C : 256;
+    const int nrl = 256 / cw;
+    long long gx = (rows + nrl * 8 - 1) / (nrl * 8);
+    if (gx > 512) gx = 512;
+    if (gx < 1) gx = 1;
+    colsum_kernel<<<dim3((int)gx, (C + 255) / 256), 256, 0, s>>>(in, ld, rows, C, cw, out);
+    DMN_LAUNCH_CHECK();
+    return DMN_OK;
+}
+
+int launch_gn_stats(const float* x, int B, int HW, int C, int G, float* stats, hipStream_t s) {
+    DMN_REQUIRE(C % G == 0 && (C / G) % 4 == 0, DMN_ERR_INVALID, "gn: C=%d G=%d", C, G);
+    const long long per = (long long)HW * (C / G) / 4;
+    int split = (int)((per + 2047) / 2048);
+    const int cap = 2048 / (B * G) > 1 ? 2048 / (B * G) : 1;
+    if (split > cap) split = cap;
+    if (split < 1) split = 1;
+    gn_stats_kernel<<<dim3(B * G, split), 256, 0, s>>>(x, HW, C, G, stats);
+    DMN_LAUNCH_CHECK();
+    return DMN_OK;
+}
+
+int launch_gn_apply(const GnArgs& a, hipStream_t s) {
+    DMN_REQUIRE(a.C % 4 == 0 && a.C % a.G == 0 && (a.C / a.G) % 4 == 0, DMN_ERR_INVALID, "gn: C=%d G=%d", a.C, a.G);
+    gn_apply_kernel<<<grid_for((long long)a.B * a.HW * a.C / 4), 256, 0, s>>>(a);
+    DMN_LAUNCH_CHECK();
+    return DMN_OK;
+}
+
+int launch_gn_bwd(const GnArgs& a, hipStream_t s) {
+    const int c4n = a.C / 4;
+    DMN_REQUIRE(a.C % 4 == 0 && c4n <= 256 && 256 % c4n == 0 && a.G <= 64, DMN_ERR_INVALID, "gn backward: C=%d G=%d", a.C, a.G);
+    const int npl = 256 / c4n;
+    int split = (a.HW + npl * 8 - 1) / (npl * 8);
+    const int cap = 2048 / a.B > 1 ? 2048 / a.B : 1;
+    if (split > cap) split = cap;
+    if (split < 1) split = 1;
+    gn_bwd_sums_kernel<<<dim3(split, a.B), 256, 0, s>>>(a);
+    DMN_LAUNCH_CHECK();
+    if (a.dx) {
+        int nb = grid_for((long long)a.HW * c4n, 256 * 4, cap);
+        gn_bwd_apply_kernel<<<dim3(nb, a.B), 256, 0, s>>>(a);
+        DMN_LAUNCH_CHECK();
+    }
+    gn_bwd_params_kernel<<<(a.C + 255) / 256, 256, 0, s>>>(a);
+    DMN_LAUNCH_CHECK();
+    return DMN_OK;
+}
+
+int launch_axpby(float* dst, const float* src, long long n, int accumulate, hipStream_t s) {
+    axpby_kernel<<<grid_for(n, 1024), 256, 0, s>>>(dst, src, n, accumulate);
+    DMN_LAUNCH_CHECK();
+    return DMN_OK;
+}
+int launch_add(float* out, const float* a, const float* b, long long n, hipStream_t s) {
+    add_kernel<<<grid_for(n, 1024), 256, 0, s>>>(out, a, b, n);
+    DMN_LAUNCH_CHECK();
+    return DMN_OK;
+}
+int launch_copy_slice(float* dst, int ldd, int doff, const float* src, int lds, int soff, int C, long long rows, int accumulate,
+                      hipStream_t s) {
+    copy_slice_kernel<<<grid_for(rows * C, 1024), 256, 0, s>>>(dst, ldd, doff, src, lds, soff, C, rows, accumulate);
+    DMN_LAUNCH_CHECK();
+    return DMN_OK;
+}
+int launch_act_fwd(const float* x, float* y, long long n, int act, hipStream_t s) {
+    act_fwd_kernel<<<grid_for(n, 1024), 256, 0, s>>>(x, y, n, act);
+    DMN_LAUNCH_CHECK();
+    return DMN_OK;
+}
+int launch_act_bwd(const float* x, const float* dy, float* dx, long long n, int act, int accumulate, hipStream_t s) {
+    act_bwd_kernel<<<grid_for(n, 1024), 256, 0, s>>>(x, dy, dx, n, act, accumulate);
+    DMN_LAUNCH_CHECK();
+    return DMN_OK;
+}
+int launch_sinus(const void* t, int t_is_float, int B, int dim, float* out, hipStream_t s) {
+    sinus_kernel<<<(B * dim + 255) / 256, 256, 0, s>>>(t, t_is_float, B, dim, out);
+    DMN_LAUNCH_CHECK();
+    return DMN_OK;
+}
+int launch_train_ingest(const float* x0, const float* eps, const long long* t, const float* sa, const float* sb, float* xt,
+                        float* tgt, int B, int C, int H, int W, hipStream_t s) {
+    train_ingest_kernel<<<grid_for((long long)B * C * H * W, 1024), 256, 0, s>>>(x0, eps, t, sa, sb, xt, tgt, B, C, H * W);
+    DMN_LAUNCH_CHECK();
+    return DMN_OK;
+}
+int launch_loss(const float* out, const float* tgt, long long n, int kind, float* loss, float* dout, hipStream_t s) {
+    loss_kernel<<<grid_for(n, 1024, 1024), 256, 0, s>>>(out, tgt, n, kind, loss, dout);
+    DMN_LAUNCH_CHECK();
+    return DMN_OK;
+}
+int launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, hipStream_t s) {
+    nhwc_to_nchw_kernel<<<grid_for((long long)B * C * HW, 1024), 256, 0, s>>>(in, out, B, C, HW);
+    DMN_LAUNCH_CHECK();
+    return DMN_OK;
+}
+int launch_linattn_train_fwd(const float* qkv, float* out, float* ctx, float* kstat, int B, int n, int heads, hipStream_t s) {
+    linattn_fwd_kernel<<<B * heads, 256, 0, s>>>(qkv, out, ctx, kstat, n, heads);
+    DMN_LAUNCH_CHECK();
+    return DMN_OK;
+}
+int launch_linattn_train_bwd(const float* qkv, const float* dout, const float* ctx, const float* kstat, float* dqkv, int B, int n,
+                             int heads, hipStream_t s) {
+    linattn_bwd_kernel<<<B * heads, 256, 0, s>>>(qkv, dout, ctx, kstat, dqkv, n, heads);
+    DMN_LAUNCH_CHECK();
+    return DMN_OK;
+}
+int launch_attn_train_fwd(const float* qkv, float* out, float* lse, int B, int n, int heads, hipStream_t s) {
+    attn_fwd_kernel<<<B * heads, 256, 0, s>>>(qkv, out, lse, n, heads);
+    DMN_LAUNCH_CHECK();
+    return DMN_OK;
+}
+int launch_attn_train_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int B, int n,
+                          int heads, hipStream_t s) {
+    // lse: [B*heads][2][n] -- the second half is this kernel's per-query scratch
+    attn_bwd_kernel<<<B * heads, 256, 0, s>>>(qkv, out, dout, lse, dqkv, const_cast<float*>(lse) + (size_t)B * heads * n, n, heads);
+    DMN_LAUNCH_CHECK();
+    return DMN_OK;
+}
+int launch_repack(const RepackDesc* descs_dev, int n_desc, long long max_numel, const float* params, float* wf, float* wb,
+                  hipStream_t s) {
+    repack_kernel<<<dim3(grid_for(max_numel, 1024, 256), n_desc), 256, 0, s>>>(descs_dev, params, wf, wb);
+    DMN_LAUNCH_CHECK();
+    return DMN_OK;
+}
+int launch_unpack_grads(const RepackDesc* descs_dev, int n_desc, long long max_numel, const float* dwf, float* grads, hipStream_t s) {
+    unpack_grads_kernel<<<dim3(grid_for(max_numel, 1024, 256), n_desc), 256, 0, s>>>(descs_dev, dwf, grads);
+    DMN_LAUNCH_CHECK();
+    return DMN_OK;
+}
+int launch_sqnorm(const float* g, long long n, float* out_sq, hipStream_t s) {
+    sqnorm_kernel<<<grid_for(n, 2048, 1024), 256, 0, s>>>(g, n, out_sq);
+    DMN_LAUNCH_CHECK();
+    return DMN_OK;
+}
+int launch_adamw(const AdamWArgs& a, hipStream_t s) {
+    adamw_kernel<<<grid_for(a.n, 1024), 256, 0, s>>>(a);
+    DMN_LAUNCH_CHECK();
+    return DMN_OK;
+}

@@ -132,6 +132,36 @@ int dmn_loop_last_ms(DmnUnet* u, float* ms);
 int dmn_bench_dominant_kernel(DmnUnet* u, int B, int H, int W, int iters, void* workspace, size_t workspace_bytes,
                               void* stream, float* avg_ms, double* alg_bytes);
 
+/* ---- training step ------------------------------------------------------------------------------------------------
+ * DDPM.training_step (models/ddpm.py:43-57) and what its Lightning trainer does with the returned loss: backward
+ * through Unet.forward (modules/unet.py:131-168), gradient clipping (trainer.gradient_clip_val) and AdamW
+ * (examples/configs/ddpm/unet_small.yaml:65-78). Parameters and gradients are ONE flat float32 device buffer each,
+ * every tensor in the reference's own layout at the offset dmn_train_tensor_info reports (offsets are multiples of
+ * 4 floats), so a state_dict maps in by name and one all-reduce covers every gradient. float32 activations, exact-f32
+ * matrix cores. Unconditional networks with out_dim == channels only. */
+typedef struct DmnTrainer DmnTrainer;
+/* loss_kind: 0 'l1', 1 'l2', 2 'huber' with reduction 'mean' (loss/simple_loss.py:37-45). cfg->dtype is ignored. */
+int dmn_train_create(const DmnUnetCfg* cfg, int loss_kind, DmnTrainer** out);
+void dmn_train_destroy(DmnTrainer* tr);
+int dmn_train_num_tensors(const DmnTrainer* tr);
+int64_t dmn_train_flat_size(const DmnTrainer* tr);           /* floats in the flat parameter / gradient buffers */
+/* name as in Unet.state_dict(); shape in PyTorch order (shape4 receives 4 entries, unused ones 0). */
+int dmn_train_tensor_info(const DmnTrainer* tr, int idx, const char** name, int64_t* offset, int* ndim, int64_t* shape4);
+int dmn_train_workspace_bytes(DmnTrainer* tr, int B, int H, int W, size_t* bytes);
+/* x_t = sqrt_acp[t] x0 + sqrt_1m_acp[t] noise (gaussian_diffusion.py:104-116; both tables NULL: x_t = x0),
+ * out = Unet(x_t, t), *loss = DiffusionLoss(out, noise), grads = d loss / d params (overwritten, not accumulated).
+ * x0, noise: device [B][C][H][W]; t: device int64 [B]; tables: device float32 [T]; loss: device scalar;
+ * model_out: optional device [B][C][H][W]. workspace: 256-byte aligned, >= dmn_train_workspace_bytes. */
+int dmn_train_loss_and_grads(DmnTrainer* tr, const float* params, float* grads, const float* x0, const float* noise,
+                             const int64_t* t, const float* sqrt_acp, const float* sqrt_1m_acp, int B, int H, int W,
+                             float* loss, float* model_out, void* workspace, size_t workspace_bytes, void* stream);
+/* torch.nn.utils.clip_grad_norm_(max_norm) (max_norm <= 0: off) followed by one torch.optim.AdamW step on flat
+ * buffers, all on the device (no host read of the norm). grads are multiplied by grad_scale first (1/world_size after
+ * a summing all-reduce). step counts from 1. scratch: device, >= 4 bytes. */
+int dmn_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int step, float max_norm, float grad_scale, float* scratch,
+                   void* stream);
+
 /* N(0,1) * scale into x[B][per] with the library's generator (prior draws; tests). */
 int dmn_fill_normal(float* x, int B, int per, uint64_t seed, uint32_t step, int64_t img_offset, float scale, void* stream);
 
