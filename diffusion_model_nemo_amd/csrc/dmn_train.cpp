@@ -513,9 +513,12 @@ Ten* activation(Run& r, Ten* x, int act) {
 Ten* attn_core(Run& r, Ten* qkv, bool linear) {
     const int heads = r.tr->cfg.heads, hidden = heads * 32, n = qkv->H * qkv->W;
     Ten* y = r.nt(hidden, qkv->H, qkv->W);
-    float* ctx = linear ? r.alloc((size_t)r.B * heads * 1024) : nullptr;
-    float* st = linear ? r.alloc((size_t)r.B * heads * 64) : r.alloc((size_t)r.B * heads * n * 2);
-    if (linear) RUN(r, launch_linattn_train_fwd(qkv->p, y->p, ctx, st, r.B, n, heads, r.s));
+    float* ctx = linear ? r.zalloc((size_t)r.B * heads * 1024) : nullptr;
+    float* st = linear ? r.zalloc((size_t)r.B * heads * 64) : r.alloc((size_t)r.B * heads * n * 2);
+    if (linear) {
+        float* pmax = r.alloc((size_t)r.B * heads * linattn_train_splits(r.B, n, heads) * 32);
+        RUN(r, launch_linattn_train_fwd(qkv->p, y->p, ctx, st, pmax, r.B, n, heads, r.s));
+    }
     else RUN(r, launch_attn_train_fwd(qkv->p, y->p, st, r.B, n, heads, r.s));
     Run* rp = &r;
     r.tape.push_back([rp, qkv, y, ctx, st, linear, n, heads]() {
@@ -526,7 +529,10 @@ Ten* attn_core(Run& r, Ten* qkv, bool linear) {
             dmn_set_error("internal: attention input gradient already set");
             r.rc = DMN_ERR_INVALID;
         }
-        if (linear) RUN(r, launch_linattn_train_bwd(qkv->p, y->g, ctx, st, g, r.B, n, heads, r.s));
+        if (linear) {
+            float* dctx = r.zalloc((size_t)r.B * heads * 1024);
+            RUN(r, launch_linattn_train_bwd(qkv->p, y->g, ctx, st, dctx, g, r.B, n, heads, r.s));
+        }
         else RUN(r, launch_attn_train_bwd(qkv->p, y->p, y->g, st, g, r.B, n, heads, r.s));
     });
     return y;

@@ -84,11 +84,15 @@ int launch_loss(const float* out, const float* tgt, long long n, int kind, float
 // NHWC [B][HW][C] -> NCHW [B][C][HW]
 int launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, hipStream_t s);
 
-// LinearAttention core on qkv [B][n][3*heads*32] (parts/mha.py:48-56): out [B][n][heads*32].
-// saved: ctx [B][heads][32][32], kstat [B][heads][2][32] (max, sum of exp) for the backward.
-int launch_linattn_train_fwd(const float* qkv, float* out, float* ctx, float* kstat, int B, int n, int heads, hipStream_t s);
-int launch_linattn_train_bwd(const float* qkv, const float* dout, const float* ctx, const float* kstat, float* dqkv, int B,
-                             int n, int heads, hipStream_t s);
+// LinearAttention core on qkv [B][n][3*heads*32] (parts/mha.py:48-56): out [B][n][heads*32]. The pixels of an image
+// are split over linattn_train_splits() workgroups. ctx [B][heads][32][32] (unnormalised k^T v) and kstat
+// [B][heads][2][32] (max, sum of exp) must be ZEROED by the caller and are kept for the backward; pmax
+// [B][heads][splits][32] is scratch; dctx [B][heads][32][32] must be zeroed.
+int linattn_train_splits(int B, int n, int heads);
+int launch_linattn_train_fwd(const float* qkv, float* out, float* ctx, float* kstat, float* pmax, int B, int n, int heads,
+                             hipStream_t s);
+int launch_linattn_train_bwd(const float* qkv, const float* dout, const float* ctx, const float* kstat, float* dctx, float* dqkv,
+                             int B, int n, int heads, hipStream_t s);
 // Attention core (parts/mha.py:20-29): out [B][n][heads*32]; lse [B][heads][n] saved for the backward.
 int launch_attn_train_fwd(const float* qkv, float* out, float* lse, int B, int n, int heads, hipStream_t s);
 int launch_attn_train_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int B, int n,

@@ -347,35 +347,57 @@ __device__ __forceinline__ void load_tile(float* S, const float* base, int ld, i
     }
 }
 
-__global__ __launch_bounds__(256) void linattn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, float* __restrict__ ctx_out,
-                                                          float* __restrict__ kstat, int n, int heads) {
-    __shared__ float Ks[64 * 33], Vs[64 * 33], Cx[32 * 32], red[8 * 32], kmx[32];
+// Every kernel below runs on a grid (image * head, pixel split): a split owns the 64-pixel tiles
+// [split * per, (split + 1) * per) of its image; reductions over pixels meet through float atomics in zeroed memory.
+__device__ __forceinline__ void split_range(int n, int& p_begin, int& p_end) {
+    const int tiles = (n + 63) >> 6, per = (tiles + gridDim.y - 1) / gridDim.y;
+    p_begin = min(n, (int)blockIdx.y * per * 64);
+    p_end = min(n, ((int)blockIdx.y + 1) * per * 64);
+}
+
+// partial max over the split's pixels of every k channel: pmax[bh][split][32]
+__global__ __launch_bounds__(256) void linattn_kmax_kernel(const float* __restrict__ qkv, float* __restrict__ pmax, int n, int heads) {
+    __shared__ float red[8 * 32];
     const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads, tid = threadIdx.x;
     const int hid = heads * kD, ld = 3 * hid;
     const float* base = qkv + (size_t)b * n * ld;
-    // pass 1: max over pixels of every k channel
-    {
-        const int d = tid & 31, pl = tid >> 5;
-        float mx = -INFINITY;
-        for (int p = pl; p < n; p += 8) mx = fmaxf(mx, base[(size_t)p * ld + hid + h * kD + d]);
-        red[pl * 32 + d] = mx;
-        __syncthreads();
-        if (tid < 32) {
-            float m = red[tid];
-            for (int i = 1; i < 8; ++i) m = fmaxf(m, red[i * 32 + tid]);
-            kmx[tid] = m;
-        }
-        __syncthreads();
+    int pb, pe;
+    split_range(n, pb, pe);
+    const int d = tid & 31, pl = tid >> 5;
+    float mx = -INFINITY;
+    for (int p = pb + pl; p < pe; p += 8) mx = fmaxf(mx, base[(size_t)p * ld + hid + h * kD + d]);
+    red[pl * 32 + d] = mx;
+    __syncthreads();
+    if (tid < 32) {
+        float m = red[tid];
+        for (int i = 1; i < 8; ++i) m = fmaxf(m, red[i * 32 + tid]);
+        pmax[((size_t)bh * gridDim.y + blockIdx.y) * 32 + tid] = m;
     }
-    // pass 2: ctx[d][e] = sum_n exp(k[n][d] - max[d]) v[n][e], and the softmax denominators
+}
+
+// ctx_un[d][e] += sum_n exp(k[n][d] - max[d]) v[n][e];  kstat[bh] = {max[32], sum of exp[32]}
+__global__ __launch_bounds__(256) void linattn_ctx_kernel(const float* __restrict__ qkv, const float* __restrict__ pmax,
+                                                          float* __restrict__ ctx_un, float* __restrict__ kstat, int n, int heads) {
+    __shared__ float Ks[64 * 33], Vs[64 * 33], kmx[32];
+    const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads, tid = threadIdx.x;
+    const int hid = heads * kD, ld = 3 * hid;
+    const float* base = qkv + (size_t)b * n * ld;
+    int pb, pe;
+    split_range(n, pb, pe);
+    if (tid < 32) {
+        float m = -INFINITY;
+        for (int i = 0; i < (int)gridDim.y; ++i) m = fmaxf(m, pmax[((size_t)bh * gridDim.y + i) * 32 + tid]);
+        kmx[tid] = m;
+        if (blockIdx.y == 0) kstat[(size_t)bh * 64 + tid] = m;
+    }
     const int d = tid >> 3, e4 = (tid & 7) * 4;
     float acc[4] = {0, 0, 0, 0}, ks = 0.f;
-    for (int p0 = 0; p0 < n; p0 += 64) {
+    for (int p0 = pb; p0 < pe; p0 += 64) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int idx = tid + 256 * i, p = idx >> 5, dd = idx & 31;
-            const bool ok = p0 + p < n;
+            const bool ok = p0 + p < pe;
             const float* row = base + (size_t)(p0 + p) * ld;
             Ks[p * 33 + dd] = ok ? expf(row[hid + h * kD + dd] - kmx[dd]) : 0.f;
             Vs[p * 33 + dd] = ok ? row[2 * hid + h * kD + dd] : 0.f;
@@ -389,25 +411,27 @@ __global__ __launch_bounds__(256) void linattn_fwd_kernel(const float* __restric
             for (int e = 0; e < 4; ++e) acc[e] += kv * Vs[p * 33 + e4 + e];
         }
     }
-    {
-        const float inv = 1.0f / ks;
+    if (pb < pe) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float c = acc[e] * inv;
-            Cx[d * 32 + e4 + e] = c;
-            ctx_out[(size_t)bh * 1024 + d * 32 + e4 + e] = c;
-        }
-        if ((tid & 7) == 0) {
-            kstat[(size_t)bh * 64 + d] = kmx[d];
-            kstat[(size_t)bh * 64 + 32 + d] = ks;
-        }
+        for (int e = 0; e < 4; ++e) unsafeAtomicAdd(ctx_un + (size_t)bh * 1024 + d * 32 + e4 + e, acc[e]);
+        if ((tid & 7) == 0) unsafeAtomicAdd(kstat + (size_t)bh * 64 + 32 + d, ks);
     }
-    // pass 3: out[n][e] = sum_d ctx[d][e] * softmax_d(q[n])[d] * scale
-    float* Qs = Ks;
+}
+
+// out[n][e] = scale * sum_d ctx[d][e] * softmax_d(q[n])[d],  ctx = ctx_un / sum of exp
+__global__ __launch_bounds__(256) void linattn_out_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx_un,
+                                                          const float* __restrict__ kstat, float* __restrict__ out, int n, int heads) {
+    __shared__ float Qs[64 * 33], Cx[32 * 32];
+    const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads, tid = threadIdx.x;
+    const int hid = heads * kD, ld = 3 * hid;
+    const float* base = qkv + (size_t)b * n * ld;
+    int pb, pe;
+    split_range(n, pb, pe);
+    for (int i = tid; i < 1024; i += 256) Cx[i] = ctx_un[(size_t)bh * 1024 + i] / kstat[(size_t)bh * 64 + 32 + (i >> 5)];
     const int p = tid >> 2, e8 = (tid & 3) * 8;
-    for (int p0 = 0; p0 < n; p0 += 64) {
+    for (int p0 = pb; p0 < pe; p0 += 64) {
         __syncthreads();
-        load_tile(Qs, base, ld, h * kD, p0, n, tid, 0.f);
+        load_tile(Qs, base, ld, h * kD, p0, pe, tid, 0.f);
         __syncthreads();
         softmax_q_rows(Qs, tid);
         __syncthreads();
@@ -418,7 +442,7 @@ __global__ __launch_bounds__(256) void linattn_fwd_kernel(const float* __restric
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] += qv * Cx[dd * 32 + e8 + e];
         }
-        if (p0 + p < n) {
+        if (p0 + p < pe) {
             float* orow = out + ((size_t)b * n + p0 + p) * hid + h * kD + e8;
 #pragma unroll
             for (int e = 0; e < 8; ++e) orow[e] = o[e] * kScale;
@@ -426,59 +450,75 @@ __global__ __launch_bounds__(256) void linattn_fwd_kernel(const float* __restric
     }
 }
 
-__global__ __launch_bounds__(256) void linattn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
-                                                          const float* __restrict__ ctx_in, const float* __restrict__ kstat,
-                                                          float* __restrict__ dqkv, int n, int heads) {
+// dctx[d][e] += scale * sum_n softmax(q[n])[d] * dout[n][e]
+__global__ __launch_bounds__(256) void linattn_dctx_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                           float* __restrict__ dctx, int n, int heads) {
+    __shared__ float As[64 * 33], Bs[64 * 33];
+    const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads, tid = threadIdx.x;
+    const int hid = heads * kD, ld = 3 * hid;
+    const float* base = qkv + (size_t)b * n * ld;
+    const float* dob = dout + (size_t)b * n * hid;
+    int pb, pe;
+    split_range(n, pb, pe);
+    const int d = tid >> 3, e4 = (tid & 7) * 4;
+    float acc[4] = {0, 0, 0, 0};
+    for (int p0 = pb; p0 < pe; p0 += 64) {
+        __syncthreads();
+        load_tile(As, base, ld, h * kD, p0, pe, tid, 0.f);
+        load_tile(Bs, dob, hid, h * kD, p0, pe, tid, 0.f);   // rows beyond the range are zero: they add nothing
+        __syncthreads();
+        softmax_q_rows(As, tid);
+        __syncthreads();
+#pragma unroll 8
+        for (int p = 0; p < 64; ++p) {
+            const float qv = As[p * 33 + d];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += qv * Bs[p * 33 + e4 + e];
+        }
+    }
+    if (pb < pe) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dctx + (size_t)bh * 1024 + d * 32 + e4 + e, acc[e] * kScale);
+    }
+}
+
+// per pixel dq, dk, dv. Thread (p = tid>>2, 8 channels j8 = 8*(tid&3)).
+__global__ __launch_bounds__(256) void linattn_bwd_pix_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                              const float* __restrict__ ctx_un, const float* __restrict__ kstat,
+                                                              const float* __restrict__ dctx, float* __restrict__ dqkv, int n, int heads) {
     __shared__ float As[64 * 33], Bs[64 * 33], Cs[64 * 33], Cx[32 * 32], Dc[32 * 32], sv[32], kmx[32], kin[32];
     const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads, tid = threadIdx.x;
     const int hid = heads * kD, ld = 3 * hid;
     const float* base = qkv + (size_t)b * n * ld;
     const float* dob = dout + (size_t)b * n * hid;
     float* dqb = dqkv + (size_t)b * n * ld;
-    for (int i = tid; i < 1024; i += 256) Cx[i] = ctx_in[(size_t)bh * 1024 + i];
+    int pb, pe;
+    split_range(n, pb, pe);
     if (tid < 32) {
         kmx[tid] = kstat[(size_t)bh * 64 + tid];
         kin[tid] = 1.0f / kstat[(size_t)bh * 64 + 32 + tid];
     }
-    // pass A: dctx[d][e] = scale * sum_n softmax(q[n])[d] * dout[n][e]
-    {
-        const int d = tid >> 3, e4 = (tid & 7) * 4;
-        float acc[4] = {0, 0, 0, 0};
-        for (int p0 = 0; p0 < n; p0 += 64) {
-            __syncthreads();
-            load_tile(As, base, ld, h * kD, p0, n, tid, 0.f);
-            load_tile(Bs, dob, hid, h * kD, p0, n, tid, 0.f);   // rows beyond n are zero: they add nothing
-            __syncthreads();
-            softmax_q_rows(As, tid);
-            __syncthreads();
-#pragma unroll 8
-            for (int p = 0; p < 64; ++p) {
-                const float qv = As[p * 33 + d];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] += qv * Bs[p * 33 + e4 + e];
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 4; ++e) Dc[d * 32 + e4 + e] = acc[e] * kScale;
-        __syncthreads();
-        if (tid < 32) {
-            float t = 0.f;
-            for (int e = 0; e < 32; ++e) t += Dc[tid * 32 + e] * Cx[tid * 32 + e];
-            sv[tid] = t;
-        }
+    __syncthreads();
+    for (int i = tid; i < 1024; i += 256) {
+        Cx[i] = ctx_un[(size_t)bh * 1024 + i] * kin[i >> 5];
+        Dc[i] = dctx[(size_t)bh * 1024 + i];
     }
-    // pass B: per pixel dq, dk, dv. Thread (p = tid>>2, 8 channels j8 = 8*(tid&3)).
+    __syncthreads();
+    if (tid < 32) {
+        float t = 0.f;
+        for (int e = 0; e < 32; ++e) t += Dc[tid * 32 + e] * Cx[tid * 32 + e];
+        sv[tid] = t;
+    }
     const int p = tid >> 2, j8 = (tid & 3) * 8;
-    for (int p0 = 0; p0 < n; p0 += 64) {
+    for (int p0 = pb; p0 < pe; p0 += 64) {
         __syncthreads();
-        load_tile(As, base, ld, h * kD, p0, n, tid, 0.f);             // q -> softmax
-        load_tile(Bs, dob, hid, h * kD, p0, n, tid, 0.f);            // dout
-        load_tile(Cs, base, ld, 2 * hid + h * kD, p0, n, tid, 0.f);  // v
+        load_tile(As, base, ld, h * kD, p0, pe, tid, 0.f);             // q -> softmax
+        load_tile(Bs, dob, hid, h * kD, p0, pe, tid, 0.f);            // dout
+        load_tile(Cs, base, ld, 2 * hid + h * kD, p0, pe, tid, 0.f);  // v
         __syncthreads();
         softmax_q_rows(As, tid);
         __syncthreads();
-        const bool ok = p0 + p < n;
+        const bool ok = p0 + p < pe;
         // dqhat[d] = sum_e ctx[d][e] dout[e]; dq = scale * s[d] * (dqhat[d] - sum_d' s[d'] dqhat[d'])
         float dqh[8], dot = 0.f;
 #pragma unroll
@@ -839,14 +879,31 @@ int launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, hipSt
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }
-int launch_linattn_train_fwd(const float* qkv, float* out, float* ctx, float* kstat, int B, int n, int heads, hipStream_t s) {
-    linattn_fwd_kernel<<<B * heads, 256, 0, s>>>(qkv, out, ctx, kstat, n, heads);
+int linattn_train_splits(int B, int n, int heads) {
+    const int tiles = (n + 63) / 64;
+    int splits = 2048 / (B * heads);
+    if (splits > tiles) splits = tiles;
+    if (splits < 1) splits = 1;
+    if (splits > 256) splits = 256;
+    return splits;
+}
+int launch_linattn_train_fwd(const float* qkv, float* out, float* ctx, float* kstat, float* pmax, int B, int n, int heads,
+                             hipStream_t s) {
+    const dim3 grid(B * heads, linattn_train_splits(B, n, heads));
+    linattn_kmax_kernel<<<grid, 256, 0, s>>>(qkv, pmax, n, heads);
+    DMN_LAUNCH_CHECK();
+    linattn_ctx_kernel<<<grid, 256, 0, s>>>(qkv, pmax, ctx, kstat, n, heads);
+    DMN_LAUNCH_CHECK();
+    linattn_out_kernel<<<grid, 256, 0, s>>>(qkv, ctx, kstat, out, n, heads);
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }
-int launch_linattn_train_bwd(const float* qkv, const float* dout, const float* ctx, const float* kstat, float* dqkv, int B, int n,
-                             int heads, hipStream_t s) {
-    linattn_bwd_kernel<<<B * heads, 256, 0, s>>>(qkv, dout, ctx, kstat, dqkv, n, heads);
+int launch_linattn_train_bwd(const float* qkv, const float* dout, const float* ctx, const float* kstat, float* dctx, float* dqkv,
+                             int B, int n, int heads, hipStream_t s) {
+    const dim3 grid(B * heads, linattn_train_splits(B, n, heads));
+    linattn_dctx_kernel<<<grid, 256, 0, s>>>(qkv, dout, dctx, n, heads);
+    DMN_LAUNCH_CHECK();
+    linattn_bwd_pix_kernel<<<grid, 256, 0, s>>>(qkv, dout, ctx, kstat, dctx, dqkv, n, heads);
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }

@@ -174,10 +174,83 @@ class DDPM(AbstractDiffusionModel):
                 out, _ = out.chunk(2, dim=1)
             return self.loss(input=out, target=noise)
 
-    def training_step(self, batch, batch_nb):
-        raise NotImplementedError(
-            "training_step needs the backward pass, which is not implemented by the HIP kernels yet; "
-            "`training_loss(batch)` evaluates the forward half (q_sample + U-Net + L_simple) on the device")
+    # ---- training (models/ddpm.py:43-57 + the Lightning trainer's backward / clip / optimiser step) -------------
+    def native_trainer(self):
+        """The `UnetTrainer` that owns the flat parameter / gradient / AdamW buffers of `diffusion_model`."""
+        from ..training import UnetTrainer
+        tr = getattr(self, "_native_trainer", None)
+        if tr is None:
+            if getattr(self.diffusion_model, "learned_variance", False):
+                raise NotImplementedError("the training step is built for L_simple (out_dim == channels) only")
+            loss_type = getattr(self.loss, "loss_type", "l2")
+            if getattr(self.loss, "_reduction", "mean") != "mean":
+                raise NotImplementedError("the training step is built for reduction='mean'")
+            tr = UnetTrainer(self.diffusion_model, loss_type=loss_type)
+            object.__setattr__(self, "_native_trainer", tr)
+        return tr
+
+    def training_step(self, batch, batch_nb=0, t: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None):
+        """models/ddpm.py:43-57: t ~ U{0..T-1}, eps ~ N(0, I), x_t = q_sample(x_0, t, eps), loss(net(x_t, t), eps).
+        Forward AND backward run in the HIP kernels during this call; the returned scalar carries an autograd node
+        whose backward hands the finished gradients to every parameter's `.grad` (scaled by the incoming gradient),
+        so `loss.backward()` followed by any torch optimiser behaves like the reference. `train_batch` is the
+        all-device alternative (all-reduce + clip + AdamW without leaving the GPU)."""
+        samples = batch["pixel_values"]
+        B = samples.shape[0]
+        dev = samples.device
+        if t is None:
+            t = torch.randint(0, self.timesteps, size=(B,), device=dev, dtype=torch.long)
+        if noise is None:
+            noise = torch.randn_like(samples)
+        tr = self.native_trainer()
+        s = self.sampler
+        value = tr.loss_and_grads(samples, t, noise, s.sqrt_alphas_cumprod, s.sqrt_one_minus_alphas_cumprod)
+        params = [p for p in self.diffusion_model.parameters()]
+        names = [n for n, _ in self.diffusion_model.named_parameters()]
+        return _NativeLoss.apply(value, tr, names, *params)
+
+    def train_batch(self, batch, lr: Optional[float] = None, t=None, noise=None):
+        """One complete optimisation step on the device: loss + gradients, ONE all-reduce of the flat gradient
+        buffer when torch.distributed is initialised, gradient clipping (trainer.gradient_clip_val) and AdamW with
+        the `optim` section of the config (examples/configs/ddpm/unet_small.yaml:65-78). Returns the loss."""
+        samples = batch["pixel_values"]
+        B = samples.shape[0]
+        dev = samples.device
+        if t is None:
+            t = torch.randint(0, self.timesteps, size=(B,), device=dev, dtype=torch.long)
+        if noise is None:
+            noise = torch.randn_like(samples)
+        tr = self.native_trainer()
+        s = self.sampler
+        value = tr.loss_and_grads(samples, t, noise, s.sqrt_alphas_cumprod, s.sqrt_one_minus_alphas_cumprod)
+        scale = tr.all_reduce_grads()
+        optim = self.cfg.get('optim', None) or {}
+        name = optim.get('name', 'adamw')
+        if name != 'adamw':
+            raise NotImplementedError(f"optimizer '{name}': only adamw is built")
+        base_lr = float(optim.get('lr', 1e-3))
+        betas = tuple(optim.get('betas', (0.9, 0.999)))
+        tr.optimizer_step(lr=base_lr if lr is None else lr, betas=betas, eps=float(optim.get('eps', 1e-8)),
+                          weight_decay=float(optim.get('weight_decay', 0.01)),
+                          max_grad_norm=float(getattr(self, 'gradient_clip_val', 1.0)), grad_scale=scale)
+        return value
+
+
+class _NativeLoss(torch.autograd.Function):
+    """Ties the loss value computed by the HIP training step to the parameters: backward returns the gradients the
+    kernels already produced (views of the trainer's flat gradient buffer) times the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, value, trainer, names, *params):
+        ctx.trainer = trainer
+        ctx.names = names
+        return value.clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        tr = ctx.trainer
+        grads = tuple(tr.grad_of(n).clone() * grad_out for n in ctx.names)
+        return (None, None, None) + grads
 
 
 class ImprovedDDPM(DDPM):
