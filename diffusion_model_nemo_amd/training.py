@@ -19,6 +19,23 @@ from . import _native as N
 LOSS_KINDS = {"l1": 0, "l2": 1, "huber": 2}
 
 
+def flat_layout(unet_cfg: "N.DmnUnetCfg", loss_kind: int = 1):
+    """(layout, flat_size) of the library's flat parameter buffer for a network configuration:
+    layout[name] = (offset in floats, PyTorch shape). Needs the library but no GPU."""
+    lib = N.lib()
+    h = C.c_void_p()
+    N.check(lib.dmn_train_create(C.byref(unet_cfg), loss_kind, C.byref(h)))
+    try:
+        layout = {}
+        for i in range(lib.dmn_train_num_tensors(h)):
+            name, off, nd, sh = C.c_char_p(), C.c_int64(), C.c_int(), (C.c_int64 * 4)()
+            N.check(lib.dmn_train_tensor_info(h, i, C.byref(name), C.byref(off), C.byref(nd), C.byref(sh)))
+            layout[name.value.decode()] = (int(off.value), tuple(int(s) for s in sh[:nd.value]))
+        return layout, int(lib.dmn_train_flat_size(h))
+    finally:
+        lib.dmn_train_destroy(h)
+
+
 class UnetTrainer:
     def __init__(self, unet, loss_type: str = "l2", device=None):
         if loss_type not in LOSS_KINDS:
@@ -114,11 +131,8 @@ class UnetTrainer:
     def all_reduce_grads(self):
         """Data parallel: ONE summing all-reduce (RCCL over xGMI under backend 'nccl') of the flat gradient tensor.
         Returns the factor that turns the sum into the mean; `optimizer_step` applies it on the device."""
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM)
-            return 1.0 / dist.get_world_size()
-        return 1.0
+        from .parallel import all_reduce_flat_grads
+        return all_reduce_flat_grads(self.grads)
 
     def optimizer_step(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01,
                        max_grad_norm: float = 0.0, grad_scale: float = 1.0):

@@ -139,3 +139,41 @@ def test_rejects_bad_arguments():
         tr.loss_and_grads(torch.zeros(2, 3, 32, 32).cuda(), torch.zeros(3, dtype=torch.long), torch.zeros(2, 3, 32, 32).cuda())
     with pytest.raises(Exception):
         tr.loss_and_grads(torch.zeros(2, 3, 36, 36).cuda(), torch.zeros(2, dtype=torch.long), torch.zeros(2, 3, 36, 36).cuda())
+
+
+def test_ddpm_model_training_step_feeds_autograd_and_train_batch_learns():
+    """Model level (models/ddpm.py:43-57): `training_step` returns a loss whose backward fills every parameter's .grad
+    with the oracle's gradients; `train_batch` (loss + clip + AdamW on the device) lowers the loss on a fixed batch."""
+    from diffusion_model_nemo_amd.models import DDPM
+    cfg = {
+        "image_size": 32, "timesteps": 1000, "channels": 3, "num_classes": None,
+        "diffusion_model": {"_target_": "diffusion_model_nemo.modules.Unet", "input_dim": "${image_size}", "dim": 32,
+                            "channels": "${channels}", "num_classes": "${num_classes}", "dim_mults": [1, 2, 4, 8],
+                            "with_time_emb": True, "resnet_block_order": "bn_act_conv", "resnet_block_groups": 8,
+                            "use_convnext": False, "convnext_mult": 2, "out_dim": None, "dropout": 0.0},
+        "sampler": {"_target_": "diffusion_model_nemo.modules.GaussianDiffusion", "timesteps": "${timesteps}",
+                    "schedule_name": "cosine", "schedule_cfg": {"cosine": {"s": 0.008, "min_clip": 0.0001, "max_clip": 0.999}}},
+        "loss": {"_target_": "diffusion_model_nemo.loss.DiffusionLoss", "loss_type": "l2", "reduction": "mean"},
+        "optim": {"name": "adamw", "lr": 0.001, "betas": [0.9, 0.98], "weight_decay": 0.001},
+    }
+    m = DDPM(cfg)
+    sd = make_state_dict(unet_param_shapes())
+    m.diffusion_model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.cuda()
+    gen = torch.Generator().manual_seed(21)
+    x0 = torch.tanh(torch.randn(2, 3, 32, 32, generator=gen))
+    noise = torch.randn(2, 3, 32, 32, generator=gen)
+    t = torch.tensor([40, 900])
+    val, ref = oracle_grads(sd, x0, t, noise)
+    for p in m.parameters():
+        p.grad = None
+    loss = m.training_step({"pixel_values": x0.cuda()}, 0, t=t.cuda(), noise=noise.cuda())
+    assert abs(float(loss) - val) <= 1e-5 * abs(val)
+    (2.0 * loss).backward()
+    for name, p in m.diffusion_model.named_parameters():
+        g = ref[name]
+        assert float((p.grad.cpu() - 2.0 * g).abs().max()) <= 5e-5 * 2.0 * float(g.abs().max()) + 1e-7, name
+    first = float(m.train_batch({"pixel_values": x0.cuda()}, t=t.cuda(), noise=noise.cuda()))
+    for _ in range(20):
+        last = float(m.train_batch({"pixel_values": x0.cuda()}, t=t.cuda(), noise=noise.cuda()))
+    assert last < 0.9 * first, (first, last)

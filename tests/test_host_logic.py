@@ -262,3 +262,40 @@ def test_pixel_values_adapter_round_trip():
     # resize (shorter side) + centre crop to a square network input
     t = D.get_transform(8, center_crop=True)(imgs[0])
     assert tuple(t.shape) == (3, 8, 8)
+
+
+def test_training_parameter_table_matches_reference_state_dict_and_lr_schedule():
+    """The flat parameter buffer of the training step holds exactly the reference's state_dict entries (names and
+    PyTorch shapes; diffusion_model_nemo/modules/unet.py:41-120), 16-byte aligned and non-overlapping; creating the
+    trainer handle and sizing its workspace need no GPU."""
+    import ctypes as C
+    from diffusion_model_nemo_amd import _native as N
+    from diffusion_model_nemo_amd.training import cosine_annealing_lr, flat_layout
+    from oracle.weights import unet_param_shapes
+    for dim, mults, order in ((32, (1, 2, 4, 8), "bn_act_conv"), (64, (1, 2, 4), "conv_bn_act")):
+        cfg = N.DmnUnetCfg()
+        cfg.dim, cfg.n_mults, cfg.channels, cfg.out_dim, cfg.groups = dim, len(mults), 3, 3, 8
+        for i, m in enumerate(mults):
+            cfg.dim_mults[i] = m
+        cfg.heads, cfg.dim_head, cfg.with_time_emb = 4, 32, 1
+        cfg.tail_norm = 1 if order == "bn_act_conv" else 0
+        layout, n = flat_layout(cfg)
+        shapes = unet_param_shapes(dim=dim, dim_mults=mults, resnet_block_order=order)
+        assert {k: tuple(v) for k, v in shapes.items()} == {k: v[1] for k, v in layout.items()}
+        spans = sorted((off, off + int(np.prod(shape))) for off, shape in layout.values())
+        assert all(a % 4 == 0 for a, _ in spans) and spans[-1][1] <= n
+        assert all(spans[i][1] <= spans[i + 1][0] for i in range(len(spans) - 1))
+        h = C.c_void_p()
+        N.check(N.lib().dmn_train_create(C.byref(cfg), 1, C.byref(h)))
+        b = C.c_size_t()
+        N.check(N.lib().dmn_train_workspace_bytes(h, 2, 32, 32, C.byref(b)))
+        assert b.value > 4 * n
+        assert N.lib().dmn_train_workspace_bytes(h, 2, 34, 34, C.byref(b)) != 0   # not a multiple of 2^(levels-1)
+        N.lib().dmn_train_destroy(h)
+    # learned-variance / class-conditional networks are refused, not silently trained on a different loss
+    cfg.out_dim = 6
+    h = C.c_void_p()
+    assert N.lib().dmn_train_create(C.byref(cfg), 1, C.byref(h)) != 0
+    assert cosine_annealing_lr(0, 100, 1e-3, 1e-4) == pytest.approx(1e-3)
+    assert cosine_annealing_lr(50, 100, 1e-3, 1e-4) == pytest.approx(5.5e-4)
+    assert cosine_annealing_lr(100, 100, 1e-3, 1e-4) == pytest.approx(1e-4)

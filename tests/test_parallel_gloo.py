@@ -87,3 +87,69 @@ def test_shard_range_covers_batch_without_overlap():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---- data-parallel training: one all-reduce of the flat gradient buffer ------------------------------------------------
+def _train_shapes():
+    from oracle.weights import unet_param_shapes
+    return unet_param_shapes(dim=32, dim_mults=(1, 2))
+
+
+def _oracle_flat_grads(x0, t, noise, layout, flat_size):
+    """Gradient of the mean L_simple loss over the given images, packed like the library's flat buffer."""
+    from oracle import ref_cpu as R
+    from oracle.weights import make_state_dict
+    torch.set_num_threads(2)
+    p = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in make_state_dict(_train_shapes()).items()}
+    c = R.ddpm_constants(1000, "cosine")
+    R.ddpm_training_loss(lambda x, tt: R.unet_forward(p, x, tt, dim=32), c, x0, t, noise).backward()
+    flat = torch.zeros(flat_size)
+    for name, (off, shape) in layout.items():
+        flat[off:off + p[name].numel()] = p[name].grad.reshape(-1)
+    return flat
+
+
+def _train_inputs(global_batch):
+    gen = torch.Generator().manual_seed(5)
+    x0 = torch.tanh(torch.randn(global_batch, 3, SIDE, SIDE, generator=gen))
+    noise = torch.randn(global_batch, 3, SIDE, SIDE, generator=gen)
+    t = torch.randint(0, 1000, (global_batch,), generator=gen)
+    return x0, t, noise
+
+
+def _train_layout():
+    from diffusion_model_nemo_amd import _native as N
+    from diffusion_model_nemo_amd.training import flat_layout
+    cfg = N.DmnUnetCfg()
+    cfg.dim, cfg.n_mults, cfg.channels, cfg.out_dim, cfg.groups = 32, 2, 3, 3, 8
+    cfg.dim_mults[0], cfg.dim_mults[1] = 1, 2
+    cfg.heads, cfg.dim_head, cfg.tail_norm, cfg.with_time_emb = 4, 32, 1, 1
+    return flat_layout(cfg)
+
+
+def _train_worker(rank, world, port, global_batch, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from diffusion_model_nemo_amd.parallel import all_reduce_flat_grads, shard_range
+        layout, n = _train_layout()
+        x0, t, noise = _train_inputs(global_batch)
+        a, b = shard_range(global_batch, rank, world)
+        flat = _oracle_flat_grads(x0[a:b], t[a:b], noise[a:b], layout, n)
+        scale = all_reduce_flat_grads(flat)
+        if rank == 0:
+            np.save(out_path, (flat * scale).numpy())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gradient_all_reduce_equals_full_batch_gradient(tmp_path):
+    out = str(tmp_path / "grads.npy")
+    mp.spawn(_train_worker, args=(2, _free_port(), 4, out), nprocs=2, join=True)
+    layout, n = _train_layout()
+    assert set(layout) == set(_train_shapes())
+    want = _oracle_flat_grads(*_train_inputs(4), layout, n).numpy()
+    got = np.load(out)
+    assert np.abs(got - want).max() <= 1e-6 + 1e-4 * np.abs(want).max()
