@@ -296,6 +296,7 @@ struct Run {
     hipStream_t s;
     bool dry;
     int B;
+    int bf16 = 0;
     int rc = DMN_OK;
     Bump a, z;
     const float* params;
@@ -376,6 +377,7 @@ Ten* conv(Run& r, Ten* x, const ConvP& w, bool need_dx = true, const float* bias
     a.out = y->p;
     a.ldout = w.Cout;
     a.N = w.Cout;
+    a.bf16 = r.bf16;
     RUN(r, launch_pgemm(a, r.s));
     Run* rp = &r;
     const ConvP* wp = &w;
@@ -401,6 +403,7 @@ Ten* conv(Run& r, Ten* x, const ConvP& w, bool need_dx = true, const float* bias
         g.N = w.Cout;
         g.dw = r.dwf + w.f_off;
         g.lddw = w.f_ld;
+        g.bf16 = r.bf16;
         RUN(r, launch_wgemm(g, r.s));
         if (dbias) RUN(r, launch_colsum(y->g, w.Cout, (long long)r.B * Ho * Wo, w.Cout, dbias, r.s));
         if (need_dx) {
@@ -423,6 +426,7 @@ Ten* conv(Run& r, Ten* x, const ConvP& w, bool need_dx = true, const float* bias
             d.out = r.G(x, &d.accumulate);
             d.ldout = x->C;
             d.N = w.Cin;
+            d.bf16 = r.bf16;
             RUN(r, launch_pgemm(d, r.s));
         }
     });
@@ -581,6 +585,7 @@ int run_step(DmnTrainer* tr, const float* params, float* grads, const StepIO& io
     r.s = s;
     r.dry = dry;
     r.B = B;
+    r.bf16 = c.dtype == 1 ? 1 : 0;
     r.params = params;
     r.grads = grads;
     // workspace: [wf | wb | zero region: dwf + zero arena | arena]

@@ -50,7 +50,17 @@ __device__ __forceinline__ bool src_coord(int o, int k, int stride, int pad, int
 // while the current one is multiplied.
 // SLOW: Cin is not a multiple of 32 (the 7x7 ingest on 3 channels): k runs over the flattened (tap, channel) index
 // and every element is gathered by itself.
-template <int BN, bool SLOW>
+// BF: both operands are rounded to bfloat16 on their way into the matrix core and one v_mfma_f32_16x16x32_bf16 per
+// stage replaces the eight fp32 instructions: k slot i of lane group q stands for channel 16*(i>>2) + 4q + (i&3) of
+// the stage, so the global loads and the LDS reads are those of the fp32 variant.
+__device__ __forceinline__ bf16x8 pack_bf16(const float* v) {
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (__bf16)v[i];
+    return o;
+}
+
+template <int BN, bool SLOW, bool BF>
 __global__ __launch_bounds__(256) void pgemm_kernel(const PGemmArgs a, const int M, const int pm) {
     constexpr int LDB = BN + 4, NJ = BN / 16, TPR = BN / 4, RPP = 256 / TPR, NB = 32 / RPP;
     __shared__ float Bs[32 * LDB];
@@ -140,15 +150,27 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const PGemmArgs a, const int
         const f32x4 ac0 = an0, ac1 = an1;
         __syncthreads();
         if (it + 1 < nstage) load_stage(it + 1);
+        if constexpr (BF) {
+            const float af[8] = {ac0[0], ac0[1], ac0[2], ac0[3], ac1[0], ac1[1], ac1[2], ac1[3]};
+            const bf16x8 a8 = pack_bf16(af);
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+            for (int j = 0; j < NJ; ++j) {
+                float bf[8];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const float av = c == 0 ? ac0[s] : ac1[s];
-                const float* brow = &Bs[(16 * c + 4 * q + s) * LDB + r];
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, brow[16 * j], acc[j], 0, 0, 0);
+                for (int i = 0; i < 8; ++i) bf[i] = Bs[(16 * (i >> 2) + 4 * q + (i & 3)) * LDB + r + 16 * j];
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, pack_bf16(bf), acc[j], 0, 0, 0);
             }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float av = c == 0 ? ac0[s] : ac1[s];
+                    const float* brow = &Bs[(16 * c + 4 * q + s) * LDB + r];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, brow[16 * j], acc[j], 0, 0, 0);
+                }
+        }
         __syncthreads();
     }
 
@@ -180,7 +202,7 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const PGemmArgs a, const int
 // Weight gradient tile TM (weight rows = (tap, cin)) x TN (cout) per workgroup, reduced over a contiguous range of
 // output pixels; 32 pixels per stage staged through LDS pixel-major for both operands (the MFMA's k index is the
 // pixel). Partial sums of the pixel splits meet in dw through hardware float atomics.
-template <int TM, int TN, bool SLOW>
+template <int TM, int TN, bool SLOW, bool BF>
 __global__ __launch_bounds__(256) void wgemm_kernel(const WGemmArgs a, const int M, const int chunk) {
     constexpr int LDX = TM + 16, LDY = TN + 16, NI = TM / 32, NJ = TN / 32;
     constexpr int TPX = TM / 4, PPX = 256 / TPX, NX = 32 / PPX;   // threads per pixel row, pixels per pass, passes
@@ -262,18 +284,40 @@ __global__ __launch_bounds__(256) void wgemm_kernel(const WGemmArgs a, const int
         for (int i = 0; i < NY; ++i) *reinterpret_cast<f32x4*>(&Ys[(tid / TPY + i * PPY) * LDY + (tid % TPY) * 4]) = yn[i];
         __syncthreads();
         if (mb + 32 < me) load_stage(mb + 32);
+        if constexpr (BF) {   // k slot i of lane group q = pixel 4i + q of the stage, for both operands
+            bf16x8 a8[NI], b8[NJ];
 #pragma unroll
-        for (int k4 = 0; k4 < 8; ++k4) {
-            const int p = 4 * k4 + q;
-            float av[NI], bv[NJ];
+            for (int i = 0; i < NI; ++i) {
+                float v[8];
 #pragma unroll
-            for (int i = 0; i < NI; ++i) av[i] = Xs[p * LDX + wm * (TM / 2) + 16 * i + r];
+                for (int k = 0; k < 8; ++k) v[k] = Xs[(4 * k + q) * LDX + wm * (TM / 2) + 16 * i + r];
+                a8[i] = pack_bf16(v);
+            }
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) bv[j] = Ys[p * LDY + wn * (TN / 2) + 16 * j + r];
+            for (int j = 0; j < NJ; ++j) {
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = Ys[(4 * k + q) * LDY + wn * (TN / 2) + 16 * j + r];
+                b8[j] = pack_bf16(v);
+            }
 #pragma unroll
             for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8[i], b8[j], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int k4 = 0; k4 < 8; ++k4) {
+                const int p = 4 * k4 + q;
+                float av[NI], bv[NJ];
+#pragma unroll
+                for (int i = 0; i < NI; ++i) av[i] = Xs[p * LDX + wm * (TM / 2) + 16 * i + r];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) bv[j] = Ys[p * LDY + wn * (TN / 2) + 16 * j + r];
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            }
         }
         __syncthreads();
     }
@@ -303,9 +347,18 @@ __global__ __launch_bounds__(256) void wgemm_kernel(const WGemmArgs a, const int
         }                                                                         \
     } while (0)
 
+template <bool BF> static void pgemm_dispatch(const PGemmArgs& a, int M, int pm, bool slow, int bn, dim3 grid, hipStream_t s) {
+    if (bn == 64) {
+        if (slow) pgemm_kernel<64, true, BF><<<grid, 256, 0, s>>>(a, M, pm);
+        else pgemm_kernel<64, false, BF><<<grid, 256, 0, s>>>(a, M, pm);
+    } else {
+        if (slow) pgemm_kernel<32, true, BF><<<grid, 256, 0, s>>>(a, M, pm);
+        else pgemm_kernel<32, false, BF><<<grid, 256, 0, s>>>(a, M, pm);
+    }
+}
+
 int launch_pgemm(const PGemmArgs& a, hipStream_t s) {
     DMN_REQUIRE(a.in && a.w && a.out && a.B > 0 && a.N > 0 && a.Cin > 0, DMN_ERR_INVALID, "pgemm: bad argument");
-    DMN_REQUIRE(a.bf16 == 0, DMN_ERR_INVALID, "pgemm: only the fp32 matrix path is built");
     const long long Ml = (long long)a.B * a.Ho * a.Wo;
     DMN_REQUIRE(Ml < (1ll << 31) - 64, DMN_ERR_LIMIT, "pgemm: %lld output pixels", Ml);
     const int M = (int)Ml;
@@ -314,20 +367,27 @@ int launch_pgemm(const PGemmArgs& a, hipStream_t s) {
     const int pm = (!slow && a.tmode == 1 && a.stride == 2 && (a.Ho & 1) == 0 && (a.Wo & 1) == 0 && ((hw >> 2) % 64) == 0) ? 1 : 0;
     const int bn = a.N > 32 ? 64 : 32;
     dim3 grid((M + 63) / 64, (a.N + bn - 1) / bn);
-    if (bn == 64) {
-        if (slow) pgemm_kernel<64, true><<<grid, 256, 0, s>>>(a, M, pm);
-        else pgemm_kernel<64, false><<<grid, 256, 0, s>>>(a, M, pm);
-    } else {
-        if (slow) pgemm_kernel<32, true><<<grid, 256, 0, s>>>(a, M, pm);
-        else pgemm_kernel<32, false><<<grid, 256, 0, s>>>(a, M, pm);
-    }
+    if (a.bf16) pgemm_dispatch<true>(a, M, pm, slow, bn, grid, s);
+    else pgemm_dispatch<false>(a, M, pm, slow, bn, grid, s);
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }
 
+template <bool BF> static void wgemm_dispatch(const WGemmArgs& a, int M, int chunk, bool slow, int tm, int tn, dim3 grid, hipStream_t s) {
+    if (slow) {
+        if (tn == 64) wgemm_kernel<32, 64, true, BF><<<grid, 256, 0, s>>>(a, M, chunk);
+        else wgemm_kernel<32, 32, true, BF><<<grid, 256, 0, s>>>(a, M, chunk);
+    } else if (tm == 64) {
+        if (tn == 64) wgemm_kernel<64, 64, false, BF><<<grid, 256, 0, s>>>(a, M, chunk);
+        else wgemm_kernel<64, 32, false, BF><<<grid, 256, 0, s>>>(a, M, chunk);
+    } else {
+        if (tn == 64) wgemm_kernel<32, 64, false, BF><<<grid, 256, 0, s>>>(a, M, chunk);
+        else wgemm_kernel<32, 32, false, BF><<<grid, 256, 0, s>>>(a, M, chunk);
+    }
+}
+
 int launch_wgemm(const WGemmArgs& a, hipStream_t s) {
     DMN_REQUIRE(a.x && a.dy && a.dw && a.B > 0 && a.N > 0 && a.Cin > 0, DMN_ERR_INVALID, "wgemm: bad argument");
-    DMN_REQUIRE(a.bf16 == 0, DMN_ERR_INVALID, "wgemm: only the fp32 matrix path is built");
     const long long Ml = (long long)a.B * a.Ho * a.Wo;
     DMN_REQUIRE(Ml < (1ll << 31) - 64, DMN_ERR_LIMIT, "wgemm: %lld output pixels", Ml);
     const int M = (int)Ml;
@@ -345,16 +405,8 @@ int launch_wgemm(const WGemmArgs& a, hipStream_t s) {
     nsplit = (M + chunk - 1) / chunk;
     dim3 grid(nsplit, rt, ct);
     DMN_REQUIRE(rt <= 65535 && ct <= 65535, DMN_ERR_LIMIT, "wgemm: grid %d x %d", rt, ct);
-    if (slow) {
-        if (tn == 64) wgemm_kernel<32, 64, true><<<grid, 256, 0, s>>>(a, M, chunk);
-        else wgemm_kernel<32, 32, true><<<grid, 256, 0, s>>>(a, M, chunk);
-    } else if (tm == 64) {
-        if (tn == 64) wgemm_kernel<64, 64, false><<<grid, 256, 0, s>>>(a, M, chunk);
-        else wgemm_kernel<64, 32, false><<<grid, 256, 0, s>>>(a, M, chunk);
-    } else {
-        if (tn == 64) wgemm_kernel<32, 64, false><<<grid, 256, 0, s>>>(a, M, chunk);
-        else wgemm_kernel<32, 32, false><<<grid, 256, 0, s>>>(a, M, chunk);
-    }
+    if (a.bf16) wgemm_dispatch<true>(a, M, chunk, slow, tm, tn, grid, s);
+    else wgemm_dispatch<false>(a, M, chunk, slow, tm, tn, grid, s);
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }

@@ -65,7 +65,8 @@ class UnetTrainer:
         self._ws = None
         self._ws_key = None
         self.step_count = 0
-        # the module's parameters become views of the flat buffer (and their .grad views of the flat gradients)
+        # the module's parameters become views of the flat buffer; their .grad stays untouched (the autograd route of
+        # DDPM.training_step accumulates there like torch does, `grad_of` reads the kernels' own buffer)
         named = dict(unet.named_parameters())
         for name, (off, shape) in self.layout.items():
             n = int(math.prod(shape))
@@ -73,7 +74,6 @@ class UnetTrainer:
             view.copy_(state[name].to(self.device, torch.float32))
             p = named[name]
             p.data = view
-            p.grad = self.grads[off:off + n].view(shape)
 
     def __del__(self):
         try:

@@ -137,10 +137,12 @@ int dmn_bench_dominant_kernel(DmnUnet* u, int B, int H, int W, int iters, void* 
  * through Unet.forward (modules/unet.py:131-168), gradient clipping (trainer.gradient_clip_val) and AdamW
  * (examples/configs/ddpm/unet_small.yaml:65-78). Parameters and gradients are ONE flat float32 device buffer each,
  * every tensor in the reference's own layout at the offset dmn_train_tensor_info reports (offsets are multiples of
- * 4 floats), so a state_dict maps in by name and one all-reduce covers every gradient. float32 activations, exact-f32
- * matrix cores. Unconditional networks with out_dim == channels only. */
+ * 4 floats), so a state_dict maps in by name and one all-reduce covers every gradient. float32 activations.
+ * Unconditional networks with out_dim == channels only. */
 typedef struct DmnTrainer DmnTrainer;
-/* loss_kind: 0 'l1', 1 'l2', 2 'huber' with reduction 'mean' (loss/simple_loss.py:37-45). cfg->dtype is ignored. */
+/* loss_kind: 0 'l1', 1 'l2', 2 'huber' with reduction 'mean' (loss/simple_loss.py:37-45).
+ * cfg->dtype selects the matrix-core operand type of the convolutions / linears: 0 exact float32, 1 operands rounded to
+ * bfloat16 (float32 accumulate); activations, gradients, norms, attention and the optimiser stay float32 either way. */
 int dmn_train_create(const DmnUnetCfg* cfg, int loss_kind, DmnTrainer** out);
 void dmn_train_destroy(DmnTrainer* tr);
 int dmn_train_num_tensors(const DmnTrainer* tr);

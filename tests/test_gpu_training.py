@@ -17,11 +17,11 @@ from oracle import ref_cpu as R  # noqa: E402
 from oracle.weights import make_state_dict, unet_param_shapes  # noqa: E402
 
 
-def build(dim=32, mults=(1, 2, 4, 8), groups=8, order="bn_act_conv", loss="l2"):
+def build(dim=32, mults=(1, 2, 4, 8), groups=8, order="bn_act_conv", loss="l2", dtype="fp32"):
     from diffusion_model_nemo_amd.modules import Unet
     from diffusion_model_nemo_amd.training import UnetTrainer
     u = Unet(input_dim=32, dim=dim, dim_mults=list(mults), channels=3, resnet_block_groups=groups, use_convnext=False,
-             resnet_block_order=order, dropout=0.0, compute_dtype="fp32")
+             resnet_block_order=order, dropout=0.0, compute_dtype=dtype)
     sd = make_state_dict(unet_param_shapes(dim=dim, dim_mults=mults, resnet_block_order=order))
     u.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     u = u.cuda()
@@ -131,6 +131,29 @@ def test_clip_and_adamw_match_torch_and_sampling_sees_the_update():
     assert float((got.cpu() - want).abs().max()) <= 5e-4
 
 
+def test_bf16_operand_mode_stays_close_to_fp32_gradients():
+    """bf16 matrix-core operands (fp32 accumulate, everything else fp32): loss within 2e-3 relative of the oracle and
+    every gradient tensor within 4e-2 of its largest entry with cosine similarity >= 0.995 (report-only band in the
+    spirit of the reference's own bf16-autocast deviation; the fp32 mode above is the parity mode)."""
+    u, tr, sd = build(dtype="bf16")
+    gen = torch.Generator().manual_seed(9)
+    x0 = torch.tanh(torch.randn(2, 3, 32, 32, generator=gen))
+    noise = torch.randn(2, 3, 32, 32, generator=gen)
+    t = torch.tensor([100, 700])
+    c = R.ddpm_constants(1000, "cosine")
+    val, ref = oracle_grads(sd, x0, t, noise)
+    got = tr.loss_and_grads(x0.cuda(), t.cuda(), noise.cuda(), c["sqrt_alphas_cumprod"], c["sqrt_one_minus_alphas_cumprod"])
+    assert abs(float(got) - val) <= 2e-3 * abs(val), (float(got), val)
+    worst_rel, worst_cos = 0.0, 1.0
+    for name, g in ref.items():
+        mine = tr.grad_of(name).cpu()
+        rel = float((mine - g).abs().max()) / (float(g.abs().max()) + 1e-30)
+        cos = float((mine * g).sum() / (mine.norm() * g.norm() + 1e-30))
+        worst_rel, worst_cos = max(worst_rel, rel), min(worst_cos, cos)
+        assert rel <= 4e-2 and cos >= 0.995, (name, rel, cos)
+    print("bf16 operands: worst relative error", worst_rel, "worst cosine", worst_cos)
+
+
 def test_rejects_bad_arguments():
     u, tr, sd = build()
     with pytest.raises(RuntimeError):
@@ -157,6 +180,7 @@ def test_ddpm_model_training_step_feeds_autograd_and_train_batch_learns():
         "optim": {"name": "adamw", "lr": 0.001, "betas": [0.9, 0.98], "weight_decay": 0.001},
     }
     m = DDPM(cfg)
+    m.set_compute_dtype("fp32")   # parity mode; the default 'bf16' rounds the matrix-core operands
     sd = make_state_dict(unet_param_shapes())
     m.diffusion_model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     m = m.cuda()
