@@ -404,8 +404,8 @@ Ten* conv(Run& r, Ten* x, const ConvP& w, bool need_dx = true, const float* bias
         g.dw = r.dwf + w.f_off;
         g.lddw = w.f_ld;
         g.bf16 = r.bf16;
+        g.dbias = dbias;
         RUN(r, launch_wgemm(g, r.s));
-        if (dbias) RUN(r, launch_colsum(y->g, w.Cout, (long long)r.B * Ho * Wo, w.Cout, dbias, r.s));
         if (need_dx) {
             PGemmArgs d;
             memset(&d, 0, sizeof(d));
@@ -433,8 +433,19 @@ Ten* conv(Run& r, Ten* x, const ConvP& w, bool need_dx = true, const float* bias
     return y;
 }
 
-// y = act(GroupNorm(x)) + tb
-Ten* gnorm(Run& r, Ten* x, const NormP& n, int G, int act, const float* tb, float* dtb, int tb_ld) {
+// the gradient of `t` receives `src` (a gradient buffer nothing reads after the calling closure): the first writer
+// simply takes the buffer over, later ones accumulate
+void pass_grad(Run& r, Ten* t, float* src) {
+    if (!t->gset) {
+        t->g = src;
+        t->gset = true;
+        return;
+    }
+    RUN(r, launch_axpby(t->g, src, (long long)r.numel(t), 1, r.s));
+}
+
+// y = act(GroupNorm(x)) + tb + res
+Ten* gnorm(Run& r, Ten* x, const NormP& n, int G, int act, const float* tb, float* dtb, int tb_ld, Ten* res = nullptr) {
     Ten* y = r.nt(x->C, x->H, x->W);
     float* stats = r.zalloc((size_t)r.B * G * 2);
     GnArgs a;
@@ -445,6 +456,7 @@ Ten* gnorm(Run& r, Ten* x, const NormP& n, int G, int act, const float* tb, floa
     a.beta = r.P(n.b);
     a.tb = tb;
     a.tb_ld = tb_ld;
+    a.res = res ? res->p : nullptr;
     a.y = y->p;
     a.B = r.B;
     a.HW = x->H * x->W;
@@ -456,7 +468,7 @@ Ten* gnorm(Run& r, Ten* x, const NormP& n, int G, int act, const float* tb, floa
     Run* rp = &r;
     float* dgamma = r.GP(n.g);
     float* dbeta = r.GP(n.b);
-    r.tape.push_back([rp, x, y, a, dgamma, dbeta, dtb]() mutable {
+    r.tape.push_back([rp, x, y, a, dgamma, dbeta, dtb, res]() mutable {
         Run& r = *rp;
         a.dy = y->g;
         a.sums = r.zalloc((size_t)r.B * a.C * 3);
@@ -465,6 +477,7 @@ Ten* gnorm(Run& r, Ten* x, const NormP& n, int G, int act, const float* tb, floa
         a.dtb = dtb;
         a.dx = r.G(x, &a.accumulate);
         RUN(r, launch_gn_bwd(a, r.s));
+        if (res) pass_grad(r, res, y->g);   // after the kernels above are queued: they read y->g before anything adds to it
     });
     return y;
 }
@@ -476,10 +489,9 @@ Ten* add(Run& r, Ten* a, Ten* b) {
     r.tape.push_back([rp, a, b, y]() {
         Run& r = *rp;
         int acc;
-        float* ga = r.G(a, &acc);
-        RUN(r, launch_axpby(ga, y->g, (long long)r.numel(y), acc, r.s));
         float* gb = r.G(b, &acc);
         RUN(r, launch_axpby(gb, y->g, (long long)r.numel(y), acc, r.s));
+        pass_grad(r, a, y->g);
     });
     return y;
 }
@@ -548,9 +560,9 @@ Ten* resblock(Run& r, Ten* x, const ResP& w, Ten* tb) {
     const bool time = tb && w.tb_off >= 0;
     h = gnorm(r, h, w.n1, G, 1, time ? tb->p + w.tb_off : nullptr, time ? tb->g + w.tb_off : nullptr, r.tr->tb_total);
     h = conv(r, h, w.c2);
-    h = gnorm(r, h, w.n2, G, 1, nullptr, nullptr, 0);
+    // the shortcut is computed first so that its sum with the block's tail comes out of the GroupNorm kernel
     Ten* res = w.has_res ? conv(r, x, w.res) : x;
-    return add(r, h, res);
+    return gnorm(r, h, w.n2, G, 1, nullptr, nullptr, 0, res);
 }
 
 Ten* attention(Run& r, Ten* x, const AttnP& w) {

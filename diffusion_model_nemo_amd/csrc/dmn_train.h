@@ -35,6 +35,7 @@ struct WGemmArgs {
     float* dw;
     int lddw;
     int bf16;
+    float* dbias;           // optional [N]: += column sums of dy (the bias gradient), taken from the staged tiles
 };
 int launch_wgemm(const WGemmArgs& a, hipStream_t s);
 
@@ -50,6 +51,7 @@ struct GnArgs {
     const float *gamma, *beta;
     const float* tb;
     int tb_ld;
+    const float* res;       // optional residual added after the activation (same shape as y)
     float* y;
     int B, HW, C, G, act;
     // backward
@@ -59,6 +61,7 @@ struct GnArgs {
     float* sums;            // [B][C][3] zeroed: sum dz*xhat, sum dz, sum dy
     float *dgamma, *dbeta;  // [C] accumulated atomically
     float* dtb;             // [B][tb_ld] slice, accumulated
+    // the residual's gradient is dy itself: the caller aliases or accumulates it
 };
 int launch_gn_apply(const GnArgs& a, hipStream_t s);
 int launch_gn_bwd(const GnArgs& a, hipStream_t s);

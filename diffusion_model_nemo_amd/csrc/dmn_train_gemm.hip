@@ -229,6 +229,8 @@ __global__ __launch_bounds__(256) void wgemm_kernel(const WGemmArgs a, const int
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 xn[NX], yn[NY];
+    const bool do_bias = a.dbias != nullptr && blockIdx.y == 0 && tid < TN;
+    float bsum = 0.f;
 
     auto load_stage = [&](int mb) {
 #pragma unroll
@@ -284,6 +286,10 @@ __global__ __launch_bounds__(256) void wgemm_kernel(const WGemmArgs a, const int
         for (int i = 0; i < NY; ++i) *reinterpret_cast<f32x4*>(&Ys[(tid / TPY + i * PPY) * LDY + (tid % TPY) * 4]) = yn[i];
         __syncthreads();
         if (mb + 32 < me) load_stage(mb + 32);
+        if (do_bias) {
+#pragma unroll 8
+            for (int p = 0; p < 32; ++p) bsum += Ys[p * LDY + tid];
+        }
         if constexpr (BF) {   // k slot i of lane group q = pixel 4i + q of the stage, for both operands
             bf16x8 a8[NI], b8[NJ];
 #pragma unroll
@@ -322,6 +328,7 @@ __global__ __launch_bounds__(256) void wgemm_kernel(const WGemmArgs a, const int
         __syncthreads();
     }
     if (ms >= me) return;
+    if (do_bias && n0 + tid < a.N) unsafeAtomicAdd(a.dbias + n0 + tid, bsum);
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll

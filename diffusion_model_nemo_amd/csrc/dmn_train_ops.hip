@@ -108,6 +108,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
             if (a.tb) z += a.tb[(size_t)b * a.tb_ld + c + e];
             o[e] = z;
         }
+        if (a.res) {
+            const f32x4 rv = *reinterpret_cast<const f32x4*>(a.res + pix * a.C + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += rv[e];
+        }
         *reinterpret_cast<f32x4*>(a.y + pix * a.C + c) = o;
     }
 }
@@ -167,6 +172,14 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GnArgs a) {
         S1[tid] = t1;
         S2[tid] = t2;
     }
+    if (blockIdx.x == 0) {   // parameter gradients of this image (summed over images by the atomics) and its time-bias share
+        for (int c = tid; c < a.C; c += 256) {
+            const float* sm = a.sums + ((size_t)b * a.C + c) * 3;
+            unsafeAtomicAdd(a.dgamma + c, sm[0]);
+            unsafeAtomicAdd(a.dbeta + c, sm[1]);
+            if (a.dtb) a.dtb[(size_t)b * a.tb_ld + c] += sm[2];
+        }
+    }
     __syncthreads();
     const float inv_cnt = 1.0f / ((float)Cg * (float)a.HW);
     const size_t img = (size_t)b * a.HW * a.C;
@@ -191,20 +204,6 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GnArgs a) {
         }
         *reinterpret_cast<f32x4*>(a.dx + off) = o;
     }
-}
-
-__global__ __launch_bounds__(256) void gn_bwd_params_kernel(const GnArgs a) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= a.C) return;
-    float t0 = 0.f, t1 = 0.f;
-    for (int b = 0; b < a.B; ++b) {
-        const float* s = a.sums + ((size_t)b * a.C + c) * 3;
-        t0 += s[0];
-        t1 += s[1];
-        if (a.dtb) a.dtb[(size_t)b * a.tb_ld + c] += s[2];
-    }
-    a.dgamma[c] += t0;
-    a.dbeta[c] += t1;
 }
 
 // ---- elementwise --------------------------------------------------------------------------------------------
@@ -822,12 +821,9 @@ int launch_gn_bwd(const GnArgs& a, hipStream_t s) {
     if (split < 1) split = 1;
     gn_bwd_sums_kernel<<<dim3(split, a.B), 256, 0, s>>>(a);
     DMN_LAUNCH_CHECK();
-    if (a.dx) {
-        int nb = grid_for((long long)a.HW * c4n, 256 * 4, cap);
-        gn_bwd_apply_kernel<<<dim3(nb, a.B), 256, 0, s>>>(a);
-        DMN_LAUNCH_CHECK();
-    }
-    gn_bwd_params_kernel<<<(a.C + 255) / 256, 256, 0, s>>>(a);
+    DMN_REQUIRE(a.dx && a.dgamma && a.dbeta, DMN_ERR_INVALID, "gn backward: null output");
+    int nb = grid_for((long long)a.HW * c4n, 256 * 4, cap);
+    gn_bwd_apply_kernel<<<dim3(nb, a.B), 256, 0, s>>>(a);
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }
