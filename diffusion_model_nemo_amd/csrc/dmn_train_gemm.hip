@@ -199,6 +199,115 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const PGemmArgs a, const int
     }
 }
 
+// 3x3, stride 1, pad 1 (forward of the ResnetBlock convolutions and, with the taps mirrored, their input gradient):
+// one workgroup = 8x8 output pixels. For every 32-channel chunk the 10x10 halo of the tile is staged in LDS once and
+// all nine taps read their A operand from it (1.56 x the input instead of 9 x through L2); weights as in pgemm_kernel.
+template <int BN, bool BF>
+__global__ __launch_bounds__(256) void pgemm_halo_kernel(const PGemmArgs a) {
+    constexpr int LDB = BN + 4, NJ = BN / 16, TPR = BN / 4, RPP = 256 / TPR, NB = 32 / RPP, LDH = 36;
+    __shared__ float Bs[32 * LDB];
+    __shared__ float Hs[100 * LDH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+    const int tw = a.Wo >> 3, th = a.Ho >> 3;
+    const int tile = blockIdx.x, b = tile / (tw * th), trem = tile - b * tw * th;
+    const int oy0 = (trem / tw) * 8, ox0 = (trem % tw) * 8;
+    const int n0 = blockIdx.y * BN;
+    const int pA = 16 * wave + r, py = pA >> 3, px = pA & 7;
+    const int nch = a.Cin >> 5, nstage = nch * 9;
+    const bool wvec = ((reinterpret_cast<uintptr_t>(a.w) & 15) == 0) && ((a.ldw & 3) == 0);
+
+    f32x4 acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 bn[NB];
+
+    auto load_b = [&](int it) {
+        const int cc = it / 9, tap = it - cc * 9;
+        const int krow0 = tap * a.Cin + cc * 32;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int row = tid / TPR + i * RPP, n = n0 + (tid % TPR) * 4;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* p = a.w + (size_t)(krow0 + row) * a.ldw + n;
+            if (wvec && n + 3 < a.N) {
+                v = *reinterpret_cast<const f32x4*>(p);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < a.N) v[e] = p[e];
+            }
+            bn[i] = v;
+        }
+    };
+    auto load_halo = [&](int cc) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < 800) {
+                const int pix = idx >> 3, c4 = (idx & 7) * 4;
+                const int hy = pix / 10, hx = pix - hy * 10;
+                const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi)
+                    v = *reinterpret_cast<const f32x4*>(a.in + ((size_t)(b * a.Hi + iy) * a.Wi + ix) * a.ldin + cc * 32 + c4);
+                *reinterpret_cast<f32x4*>(&Hs[pix * LDH + c4]) = v;
+            }
+        }
+    };
+
+    load_b(0);
+    for (int it = 0; it < nstage; ++it) {
+        const int cc = it / 9, tap = it - cc * 9;
+        if (tap == 0) load_halo(cc);   // the previous chunk's last reads ended at the barrier that closed its stage
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            *reinterpret_cast<f32x4*>(&Bs[(tid / TPR + i * RPP) * LDB + (tid % TPR) * 4]) = bn[i];
+        __syncthreads();
+        if (it + 1 < nstage) load_b(it + 1);
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int hy = py + (a.tmode ? 2 - ky : ky), hx = px + (a.tmode ? 2 - kx : kx);
+        const float* hp = &Hs[(hy * 10 + hx) * LDH + 4 * q];
+        const f32x4 ac0 = *reinterpret_cast<const f32x4*>(hp), ac1 = *reinterpret_cast<const f32x4*>(hp + 16);
+        if constexpr (BF) {
+            const float af[8] = {ac0[0], ac0[1], ac0[2], ac0[3], ac1[0], ac1[1], ac1[2], ac1[3]};
+            const bf16x8 a8 = pack_bf16(af);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                float bf[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) bf[i] = Bs[(16 * (i >> 2) + 4 * q + (i & 3)) * LDB + r + 16 * j];
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, pack_bf16(bf), acc[j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float av = c == 0 ? ac0[s] : ac1[s];
+                    const float* brow = &Bs[(16 * c + 4 * q + s) * LDB + r];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, brow[16 * j], acc[j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pO = 16 * wave + 4 * q + i;
+        float* o = a.out + ((size_t)(b * a.Ho + oy0 + (pO >> 3)) * a.Wo + ox0 + (pO & 7)) * a.ldout;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = n0 + 16 * j + r;
+            if (n < a.N) {
+                float v = acc[j][i];
+                if (a.bias) v += a.bias[n];
+                if (a.accumulate) v += o[n];
+                o[n] = v;
+            }
+        }
+    }
+}
+
 // Weight gradient tile TM (weight rows = (tap, cin)) x TN (cout) per workgroup, reduced over a contiguous range of
 // output pixels; 32 pixels per stage staged through LDS pixel-major for both operands (the MFMA's k index is the
 // pixel). Partial sums of the pixel splits meet in dw through hardware float atomics.
@@ -373,6 +482,19 @@ int launch_pgemm(const PGemmArgs& a, hipStream_t s) {
     const int hw = a.Ho * a.Wo;
     const int pm = (!slow && a.tmode == 1 && a.stride == 2 && (a.Ho & 1) == 0 && (a.Wo & 1) == 0 && ((hw >> 2) % 64) == 0) ? 1 : 0;
     const int bn = a.N > 32 ? 64 : 32;
+    if (!slow && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && (a.Ho & 7) == 0 && (a.Wo & 7) == 0 && a.Hi == a.Ho &&
+        a.Wi == a.Wo) {
+        dim3 hgrid(a.B * (a.Ho >> 3) * (a.Wo >> 3), (a.N + bn - 1) / bn);
+        if (bn == 64) {
+            if (a.bf16) pgemm_halo_kernel<64, true><<<hgrid, 256, 0, s>>>(a);
+            else pgemm_halo_kernel<64, false><<<hgrid, 256, 0, s>>>(a);
+        } else {
+            if (a.bf16) pgemm_halo_kernel<32, true><<<hgrid, 256, 0, s>>>(a);
+            else pgemm_halo_kernel<32, false><<<hgrid, 256, 0, s>>>(a);
+        }
+        DMN_LAUNCH_CHECK();
+        return DMN_OK;
+    }
     dim3 grid((M + 63) / 64, (a.N + bn - 1) / bn);
     if (a.bf16) pgemm_dispatch<true>(a, M, pm, slow, bn, grid, s);
     else pgemm_dispatch<false>(a, M, pm, slow, bn, grid, s);
