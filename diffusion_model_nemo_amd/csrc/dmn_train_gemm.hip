@@ -3,6 +3,8 @@
 // (what torch.nn.functional.conv2d / conv_transpose2d / linear and their autograd do in the reference:
 // diffusion_model_nemo/parts/convnext.py:11-13, utils.py:77-82, parts/mha.py:13-14,40-42, modules/unet.py:41,61-66).
 // gfx950, 256-thread workgroups = 4 wave64, v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate).
+#include <stdlib.h>
+
 #include "dmn_common.h"
 #include "dmn_train.h"
 
@@ -452,6 +454,122 @@ __global__ __launch_bounds__(256) void wgemm_kernel(const WGemmArgs a, const int
         }
 }
 
+// Weight gradient of a 3x3 / stride 1 / pad 1 convolution, all nine taps of a 32 (cin) x 32 (cout) block per workgroup:
+// per 8x8 pixel tile the 10x10 halo of x and the tile of dy are staged once and every tap takes its A operand from the
+// halo at its own offset (the per-tap kernel above reads both tensors nine times). Wave w owns the 16x16 block
+// (w >> 1, w & 1) of every tap: nine accumulators.
+template <bool BF>
+__global__ __launch_bounds__(256) void wgemm_halo_kernel(const WGemmArgs a, const int tiles, const int per) {
+    constexpr int LDX = 48, LDY = 48;
+    __shared__ float Xs[100 * LDX], Ys[64 * LDY];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ci0 = blockIdx.y * 32, n0 = blockIdx.z * 32;
+    const int t0 = blockIdx.x * per, t1 = min(tiles, t0 + per);
+    const int tw = a.Wo >> 3, th = a.Ho >> 3;
+    const bool do_bias = a.dbias != nullptr && blockIdx.y == 0 && tid < 32;
+    float bsum = 0.f;
+    f32x4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    f32x4 xr[4], yr[2];
+    auto load_tile = [&](int tile) {
+        const int b = tile / (tw * th), trem = tile - b * tw * th;
+        const int oy0 = (trem / tw) * 8, ox0 = (trem % tw) * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (idx < 800) {
+                const int pix = idx >> 3, c4 = (idx & 7) * 4;
+                const int hy = pix / 10, hx = pix - hy * 10;
+                const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+                if (iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi)
+                    v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(b * a.Hi + iy) * a.Wi + ix) * a.ldx + ci0 + c4);
+            }
+            xr[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i, pix = idx >> 3, c4 = (idx & 7) * 4;
+            const int n = n0 + c4;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* p = a.dy + ((size_t)(b * a.Ho + oy0 + (pix >> 3)) * a.Wo + ox0 + (pix & 7)) * a.lddy + n;
+            if (n + 3 < a.N) {
+                v = *reinterpret_cast<const f32x4*>(p);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < a.N) v[e] = p[e];
+            }
+            yr[i] = v;
+        }
+    };
+    if (t0 < t1) load_tile(t0);
+    for (int tile = t0; tile < t1; ++tile) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < 800) *reinterpret_cast<f32x4*>(&Xs[(idx >> 3) * LDX + (idx & 7) * 4]) = xr[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            *reinterpret_cast<f32x4*>(&Ys[(idx >> 3) * LDY + (idx & 7) * 4]) = yr[i];
+        }
+        __syncthreads();
+        if (tile + 1 < t1) load_tile(tile + 1);
+        if (do_bias) {
+#pragma unroll 8
+            for (int p = 0; p < 64; ++p) bsum += Ys[p * LDY + tid];
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            // k slot i of lane group q = pixel 32*st + 4i + q of the tile
+            float yv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) yv[i] = Ys[(32 * st + 4 * i + q) * LDY + 16 * wn + r];
+            if constexpr (BF) {
+                const bf16x8 b8 = pack_bf16(yv);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int ky = t / 3, kx = t - ky * 3;
+                    float xv[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int p = 32 * st + 4 * i + q;
+                        xv[i] = Xs[(((p >> 3) + ky) * 10 + (p & 7) + kx) * LDX + 16 * wm + r];
+                    }
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pack_bf16(xv), b8, acc[t], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int ky = t / 3, kx = t - ky * 3;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int p = 32 * st + 4 * i + q;
+                        const float xv = Xs[(((p >> 3) + ky) * 10 + (p & 7) + kx) * LDX + 16 * wm + r];
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, yv[i], acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    if (t0 >= t1) return;
+    if (do_bias && n0 + tid < a.N) unsafeAtomicAdd(a.dbias + n0 + tid, bsum);
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = t * a.Cin + ci0 + 16 * wm + 4 * q + e;
+            const int n = n0 + 16 * wn + r;
+            if (n < a.N) unsafeAtomicAdd(a.dw + (size_t)row * a.lddw + n, acc[t][e]);
+        }
+}
+
 }   // namespace
 
 #define DMN_LAUNCH_CHECK()                                                        \
@@ -515,6 +633,18 @@ template <bool BF> static void wgemm_dispatch(const WGemmArgs& a, int M, int chu
     }
 }
 
+// Workgroups a weight-gradient launch aims for: every workgroup ends with one float atomic per element of its output
+// tile, so more pixel splits buy occupancy with atomic traffic (2048 splits of a 64x64 tile are 8 M atomics).
+static int wgemm_wg_target() {
+    static int v = 0;
+    if (!v) {
+        const char* e = getenv("DMN_WGEMM_WGS");
+        v = e ? atoi(e) : 768;
+        if (v < 64) v = 64;
+    }
+    return v;
+}
+
 int launch_wgemm(const WGemmArgs& a, hipStream_t s) {
     DMN_REQUIRE(a.x && a.dy && a.dw && a.B > 0 && a.N > 0 && a.Cin > 0, DMN_ERR_INVALID, "wgemm: bad argument");
     const long long Ml = (long long)a.B * a.Ho * a.Wo;
@@ -523,9 +653,23 @@ int launch_wgemm(const WGemmArgs& a, hipStream_t s) {
     const int K = a.kh * a.kw * a.Cin;
     const bool big_m = (a.Cin % 64) == 0, big_n = a.N > 32;
     const bool slow = (a.Cin & 31) != 0 || (a.ldx & 3) != 0 || (reinterpret_cast<uintptr_t>(a.x) & 15) != 0;
+    if (!slow && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.tmode == 0 && (a.Ho & 7) == 0 && (a.Wo & 7) == 0 &&
+        a.Hi == a.Ho && a.Wi == a.Wo && (a.lddy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.dy) & 15) == 0) {
+        const int tiles = a.B * (a.Ho >> 3) * (a.Wo >> 3), cit = a.Cin / 32, cot = (a.N + 31) / 32;
+        int ns = wgemm_wg_target() / (cit * cot);
+        if (ns > tiles) ns = tiles;
+        if (ns < 1) ns = 1;
+        const int per = (tiles + ns - 1) / ns;
+        ns = (tiles + per - 1) / per;
+        DMN_REQUIRE(cit <= 65535 && cot <= 65535, DMN_ERR_LIMIT, "wgemm: grid %d x %d", cit, cot);
+        if (a.bf16) wgemm_halo_kernel<true><<<dim3(ns, cit, cot), 256, 0, s>>>(a, tiles, per);
+        else wgemm_halo_kernel<false><<<dim3(ns, cit, cot), 256, 0, s>>>(a, tiles, per);
+        DMN_LAUNCH_CHECK();
+        return DMN_OK;
+    }
     const int tm = (!slow && big_m) ? 64 : 32, tn = big_n ? 64 : 32;
     const int rt = (K + tm - 1) / tm, ct = (a.N + tn - 1) / tn;
-    int nsplit = 2048 / (rt * ct);
+    int nsplit = wgemm_wg_target() / (rt * ct);
     const int max_split = (M + 127) / 128;
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;
