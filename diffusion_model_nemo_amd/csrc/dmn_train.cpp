@@ -533,7 +533,7 @@ Ten* attn_core(Run& r, Ten* qkv, bool linear) {
     float* st = linear ? r.zalloc((size_t)r.B * heads * 64) : r.alloc((size_t)r.B * heads * n * 2);
     if (linear) {
         float* pmax = r.alloc((size_t)r.B * heads * linattn_train_splits(r.B, n, heads) * 32);
-        RUN(r, launch_linattn_train_fwd(qkv->p, y->p, ctx, st, pmax, r.B, n, heads, r.s));
+        RUN(r, launch_linattn_train_fwd(qkv->p, y->p, ctx, st, pmax, r.B, n, heads, r.bf16, r.s));
     }
     else RUN(r, launch_attn_train_fwd(qkv->p, y->p, st, r.B, n, heads, r.s));
     Run* rp = &r;
@@ -547,7 +547,7 @@ Ten* attn_core(Run& r, Ten* qkv, bool linear) {
         }
         if (linear) {
             float* dctx = r.zalloc((size_t)r.B * heads * 1024);
-            RUN(r, launch_linattn_train_bwd(qkv->p, y->g, ctx, st, dctx, g, r.B, n, heads, r.s));
+            RUN(r, launch_linattn_train_bwd(qkv->p, y->g, ctx, st, dctx, g, r.B, n, heads, r.bf16, r.s));
         }
         else RUN(r, launch_attn_train_bwd(qkv->p, y->p, y->g, st, g, r.B, n, heads, r.s));
     });

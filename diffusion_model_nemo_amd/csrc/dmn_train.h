@@ -92,10 +92,11 @@ int launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, hipSt
 // [B][heads][2][32] (max, sum of exp) must be ZEROED by the caller and are kept for the backward; pmax
 // [B][heads][splits][32] is scratch; dctx [B][heads][32][32] must be zeroed.
 int linattn_train_splits(int B, int n, int heads);
+// bf16: the per-pixel 32x32 products take bfloat16 operands (fp32 accumulate) instead of exact fp32.
 int launch_linattn_train_fwd(const float* qkv, float* out, float* ctx, float* kstat, float* pmax, int B, int n, int heads,
-                             hipStream_t s);
+                             int bf16, hipStream_t s);
 int launch_linattn_train_bwd(const float* qkv, const float* dout, const float* ctx, const float* kstat, float* dctx, float* dqkv,
-                             int B, int n, int heads, hipStream_t s);
+                             int B, int n, int heads, int bf16, hipStream_t s);
 // Attention core (parts/mha.py:20-29): out [B][n][heads*32]; lse [B][heads][n] saved for the backward.
 int launch_attn_train_fwd(const float* qkv, float* out, float* lse, int B, int n, int heads, hipStream_t s);
 int launch_attn_train_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int B, int n,

@@ -417,35 +417,112 @@ __global__ __launch_bounds__(256) void linattn_ctx_kernel(const float* __restric
     }
 }
 
+// ---- per-pixel 32x32 products on the matrix cores ----------------------------------------------------------------
+// A wave owns 16 pixels; lane (r = lane & 15, q = lane >> 4) holds, for pixel r, the eight channels
+// 16c + 4q + s (c < 2, s < 4) of a 32-channel head, in slot order t = 4c + s: two float4 of its row. For a 32x32 matrix
+// Wm, y = Wm x of every pixel comes out of the MFMA in the SAME slot layout when the matrix is the A operand and the
+// lanes' own values the B operand: D[4q + i][r] is channel 16j + 4q + i of pixel r. Everything between the products
+// (softmax, its backward) is therefore lane-local plus reductions over the four q lanes; no LDS for pixel data and no
+// barrier in the pixel loop. Wm sits in LDS with row pitch 33 and its columns permuted so that the 32 lanes of a
+// half-wave read 32 different banks.
+__device__ __forceinline__ int perm_col(int ch) {
+    const int c = ch >> 4, q = (ch >> 2) & 3, s = ch & 3;
+    return ((q & 1) << 4) + ((q >> 1) << 3) + 4 * c + s;
+}
+__device__ __forceinline__ bf16x8 pack8_bf16(const float* v) {
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (__bf16)v[i];
+    return o;
+}
+template <bool BF> __device__ __forceinline__ void mat32_apply(const float* Wm, const float* x, float* y, int r, int q) {
+    const int cb = ((q & 1) << 4) + ((q >> 1) << 3);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* row = Wm + (16 * j + r) * 33 + cb;
+        if constexpr (BF) {
+            float a8[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) a8[t] = row[t];
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pack8_bf16(a8), pack8_bf16(x), acc, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(row[t], x[t], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[4 * j + i] = acc[i];
+    }
+}
+__device__ __forceinline__ float qsum(float v) {   // over the four lanes that share a pixel
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__device__ __forceinline__ float qmax(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+__device__ __forceinline__ void load8(const float* row, int q, bool ok, float* x) {
+    f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, b = a;
+    if (ok) {
+        a = *reinterpret_cast<const f32x4*>(row + 4 * q);
+        b = *reinterpret_cast<const f32x4*>(row + 16 + 4 * q);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        x[i] = a[i];
+        x[4 + i] = b[i];
+    }
+}
+__device__ __forceinline__ void store8(float* row, int q, const float* x) {
+    *reinterpret_cast<f32x4*>(row + 4 * q) = f32x4{x[0], x[1], x[2], x[3]};
+    *reinterpret_cast<f32x4*>(row + 16 + 4 * q) = f32x4{x[4], x[5], x[6], x[7]};
+}
+// unscaled softmax over the 32 channels of the lane's pixel
+__device__ __forceinline__ void softmax8(const float* x, float* sm) {
+    float mx = x[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) mx = fmaxf(mx, x[i]);
+    mx = qmax(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        sm[i] = expf(x[i] - mx);
+        sum += sm[i];
+    }
+    const float inv = 1.0f / qsum(sum);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sm[i] *= inv;
+}
+
 // out[n][e] = scale * sum_d ctx[d][e] * softmax_d(q[n])[d],  ctx = ctx_un / sum of exp
+template <bool BF>
 __global__ __launch_bounds__(256) void linattn_out_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx_un,
                                                           const float* __restrict__ kstat, float* __restrict__ out, int n, int heads) {
-    __shared__ float Qs[64 * 33], Cx[32 * 32];
+    __shared__ float CxT[32 * 33];
     const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
     const int hid = heads * kD, ld = 3 * hid;
     const float* base = qkv + (size_t)b * n * ld;
     int pb, pe;
     split_range(n, pb, pe);
-    for (int i = tid; i < 1024; i += 256) Cx[i] = ctx_un[(size_t)bh * 1024 + i] / kstat[(size_t)bh * 64 + 32 + (i >> 5)];
-    const int p = tid >> 2, e8 = (tid & 3) * 8;
-    for (int p0 = pb; p0 < pe; p0 += 64) {
-        __syncthreads();
-        load_tile(Qs, base, ld, h * kD, p0, pe, tid, 0.f);
-        __syncthreads();
-        softmax_q_rows(Qs, tid);
-        __syncthreads();
-        float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 8
-        for (int dd = 0; dd < 32; ++dd) {
-            const float qv = Qs[p * 33 + dd];
+    for (int i = tid; i < 1024; i += 256) {
+        const int d = i >> 5, e = i & 31;
+        CxT[e * 33 + perm_col(d)] = ctx_un[(size_t)bh * 1024 + i] / kstat[(size_t)bh * 64 + 32 + d];
+    }
+    __syncthreads();
+    for (int p0 = pb + 16 * wave; p0 < pe; p0 += 64) {
+        const int pix = p0 + r;
+        const bool ok = pix < pe;
+        float qv[8], qs[8], o[8];
+        load8(base + (size_t)pix * ld + h * kD, q, ok, qv);
+        softmax8(qv, qs);
+        mat32_apply<BF>(CxT, qs, o, r, q);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] += qv * Cx[dd * 32 + e8 + e];
-        }
-        if (p0 + p < pe) {
-            float* orow = out + ((size_t)b * n + p0 + p) * hid + h * kD + e8;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) orow[e] = o[e] * kScale;
-        }
+        for (int i = 0; i < 8; ++i) o[i] *= kScale;
+        if (ok) store8(out + ((size_t)b * n + pix) * hid + h * kD, q, o);
     }
 }
 
@@ -481,87 +558,74 @@ __global__ __launch_bounds__(256) void linattn_dctx_kernel(const float* __restri
     }
 }
 
-// per pixel dq, dk, dv. Thread (p = tid>>2, 8 channels j8 = 8*(tid&3)).
+// per pixel dq, dk, dv on the matrix cores (layout: see mat32_apply)
+template <bool BF>
 __global__ __launch_bounds__(256) void linattn_bwd_pix_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                               const float* __restrict__ ctx_un, const float* __restrict__ kstat,
                                                               const float* __restrict__ dctx, float* __restrict__ dqkv, int n, int heads) {
-    __shared__ float As[64 * 33], Bs[64 * 33], Cs[64 * 33], Cx[32 * 32], Dc[32 * 32], sv[32], kmx[32], kin[32];
+    __shared__ float Cx[32 * 33], Dc[32 * 33], DcT[32 * 33], sv[32];
     const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
     const int hid = heads * kD, ld = 3 * hid;
     const float* base = qkv + (size_t)b * n * ld;
     const float* dob = dout + (size_t)b * n * hid;
     float* dqb = dqkv + (size_t)b * n * ld;
     int pb, pe;
     split_range(n, pb, pe);
-    if (tid < 32) {
-        kmx[tid] = kstat[(size_t)bh * 64 + tid];
-        kin[tid] = 1.0f / kstat[(size_t)bh * 64 + 32 + tid];
-    }
-    __syncthreads();
     for (int i = tid; i < 1024; i += 256) {
-        Cx[i] = ctx_un[(size_t)bh * 1024 + i] * kin[i >> 5];
-        Dc[i] = dctx[(size_t)bh * 1024 + i];
+        const int d = i >> 5, e = i & 31;
+        const float g = dctx[(size_t)bh * 1024 + i];
+        Cx[d * 33 + perm_col(e)] = ctx_un[(size_t)bh * 1024 + i] / kstat[(size_t)bh * 64 + 32 + d];
+        Dc[d * 33 + perm_col(e)] = g;
+        DcT[e * 33 + perm_col(d)] = g;
     }
     __syncthreads();
     if (tid < 32) {
         float t = 0.f;
-        for (int e = 0; e < 32; ++e) t += Dc[tid * 32 + e] * Cx[tid * 32 + e];
+        for (int e = 0; e < 32; ++e) t += Dc[tid * 33 + e] * Cx[tid * 33 + e];
         sv[tid] = t;
     }
-    const int p = tid >> 2, j8 = (tid & 3) * 8;
-    for (int p0 = pb; p0 < pe; p0 += 64) {
-        __syncthreads();
-        load_tile(As, base, ld, h * kD, p0, pe, tid, 0.f);             // q -> softmax
-        load_tile(Bs, dob, hid, h * kD, p0, pe, tid, 0.f);            // dout
-        load_tile(Cs, base, ld, 2 * hid + h * kD, p0, pe, tid, 0.f);  // v
-        __syncthreads();
-        softmax_q_rows(As, tid);
-        __syncthreads();
-        const bool ok = p0 + p < pe;
+    __syncthreads();
+    float kmx8[8], kin8[8], sv8[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int ch = 16 * (t >> 2) + 4 * q + (t & 3);
+        kmx8[t] = kstat[(size_t)bh * 64 + ch];
+        kin8[t] = 1.0f / kstat[(size_t)bh * 64 + 32 + ch];
+        sv8[t] = sv[ch];
+    }
+    for (int p0 = pb + 16 * wave; p0 < pe; p0 += 64) {
+        const int pix = p0 + r;
+        const bool ok = pix < pe;
+        const float* row = base + (size_t)pix * ld + h * kD;
+        float qv[8], kv[8], vv[8], dov[8], qs[8], y[8], res[8];
+        load8(row, q, ok, qv);
+        load8(row + hid, q, ok, kv);
+        load8(row + 2 * hid, q, ok, vv);
+        load8(dob + (size_t)pix * hid + h * kD, q, ok, dov);
+        softmax8(qv, qs);
         // dqhat[d] = sum_e ctx[d][e] dout[e]; dq = scale * s[d] * (dqhat[d] - sum_d' s[d'] dqhat[d'])
-        float dqh[8], dot = 0.f;
+        mat32_apply<BF>(Cx, dov, y, r, q);
+        float dot = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float t = 0.f;
-#pragma unroll 8
-            for (int e = 0; e < 32; ++e) t += Cx[(j8 + i) * 32 + e] * Bs[p * 33 + e];
-            dqh[i] = t;
-            dot += As[p * 33 + j8 + i] * t;
-        }
-        dot += __shfl_xor(dot, 1, 64);
-        dot += __shfl_xor(dot, 2, 64);
+        for (int i = 0; i < 8; ++i) dot += qs[i] * y[i];
+        dot = qsum(dot);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) res[i] = kScale * qs[i] * (y[i] - dot);
+        float* orow = dqb + (size_t)pix * ld + h * kD;
+        if (ok) store8(orow, q, res);
         // dkhat[d] = sum_e dctx[d][e] v[e]; dk = khat[d] * (dkhat[d] - sv[d])
-        float dk[8], kh[8];
-        const float* krow = base + (size_t)(p0 + p) * ld + hid + h * kD + j8;
+        mat32_apply<BF>(Dc, vv, y, r, q);
+        float kh[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            float t = 0.f;
-#pragma unroll 8
-            for (int e = 0; e < 32; ++e) t += Dc[(j8 + i) * 32 + e] * Cs[p * 33 + e];
-            kh[i] = ok ? expf(krow[i] - kmx[j8 + i]) * kin[j8 + i] : 0.f;
-            dk[i] = kh[i] * (t - sv[j8 + i]);
+            kh[i] = ok ? expf(kv[i] - kmx8[i]) * kin8[i] : 0.f;
+            res[i] = kh[i] * (y[i] - sv8[i]);
         }
-        __syncthreads();
-        // khat of the pixel into Cs (v no longer needed) for the dv product
-#pragma unroll
-        for (int i = 0; i < 8; ++i) Cs[p * 33 + j8 + i] = kh[i];
-        __syncthreads();
-        float dv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 8
-        for (int dd = 0; dd < 32; ++dd) {
-            const float kv = Cs[p * 33 + dd];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) dv[i] += kv * Dc[dd * 32 + j8 + i];
-        }
-        if (ok) {
-            float* row = dqb + (size_t)(p0 + p) * ld + h * kD + j8;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                row[i] = kScale * As[p * 33 + j8 + i] * (dqh[i] - dot);
-                row[hid + i] = dk[i];
-                row[2 * hid + i] = dv[i];
-            }
-        }
+        if (ok) store8(orow + hid, q, res);
+        // dv[e] = sum_d khat[d] dctx[d][e]
+        mat32_apply<BF>(DcT, kh, y, r, q);
+        if (ok) store8(orow + 2 * hid, q, y);
     }
 }
 
@@ -884,22 +948,24 @@ int linattn_train_splits(int B, int n, int heads) {
     return splits;
 }
 int launch_linattn_train_fwd(const float* qkv, float* out, float* ctx, float* kstat, float* pmax, int B, int n, int heads,
-                             hipStream_t s) {
+                             int bf16, hipStream_t s) {
     const dim3 grid(B * heads, linattn_train_splits(B, n, heads));
     linattn_kmax_kernel<<<grid, 256, 0, s>>>(qkv, pmax, n, heads);
     DMN_LAUNCH_CHECK();
     linattn_ctx_kernel<<<grid, 256, 0, s>>>(qkv, pmax, ctx, kstat, n, heads);
     DMN_LAUNCH_CHECK();
-    linattn_out_kernel<<<grid, 256, 0, s>>>(qkv, ctx, kstat, out, n, heads);
+    if (bf16) linattn_out_kernel<true><<<grid, 256, 0, s>>>(qkv, ctx, kstat, out, n, heads);
+    else linattn_out_kernel<false><<<grid, 256, 0, s>>>(qkv, ctx, kstat, out, n, heads);
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }
 int launch_linattn_train_bwd(const float* qkv, const float* dout, const float* ctx, const float* kstat, float* dctx, float* dqkv,
-                             int B, int n, int heads, hipStream_t s) {
+                             int B, int n, int heads, int bf16, hipStream_t s) {
     const dim3 grid(B * heads, linattn_train_splits(B, n, heads));
     linattn_dctx_kernel<<<grid, 256, 0, s>>>(qkv, dout, dctx, n, heads);
     DMN_LAUNCH_CHECK();
-    linattn_bwd_pix_kernel<<<grid, 256, 0, s>>>(qkv, dout, ctx, kstat, dctx, dqkv, n, heads);
+    if (bf16) linattn_bwd_pix_kernel<true><<<grid, 256, 0, s>>>(qkv, dout, ctx, kstat, dctx, dqkv, n, heads);
+    else linattn_bwd_pix_kernel<false><<<grid, 256, 0, s>>>(qkv, dout, ctx, kstat, dctx, dqkv, n, heads);
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }
