@@ -289,6 +289,8 @@ struct Ten {
     float* g = nullptr;
     int C = 0, H = 0, W = 0;
     bool gset = false;
+    float* stats = nullptr;   // {sum, sum of squares} per (image, group) left by the producing kernel
+    int statsG = 0;
 };
 
 struct Run {
@@ -351,7 +353,9 @@ struct Run {
         if ((r).live()) (r).L(expr); \
     } while (0)
 
-Ten* conv(Run& r, Ten* x, const ConvP& w, bool need_dx = true, const float* bias_override = nullptr, float* dbias_override = nullptr) {
+// statsG > 0: the consumer is a GroupNorm with that many groups; the producing kernel leaves its statistics when it can
+Ten* conv(Run& r, Ten* x, const ConvP& w, bool need_dx = true, const float* bias_override = nullptr, float* dbias_override = nullptr,
+          int statsG = 0) {
     const int Ho = w.transposed ? (x->H - 1) * w.stride - 2 * w.pad + w.k : (x->H + 2 * w.pad - w.k) / w.stride + 1;
     const int Wo = w.transposed ? (x->W - 1) * w.stride - 2 * w.pad + w.k : (x->W + 2 * w.pad - w.k) / w.stride + 1;
     Ten* y = r.nt(w.Cout, Ho, Wo);
@@ -378,6 +382,11 @@ Ten* conv(Run& r, Ten* x, const ConvP& w, bool need_dx = true, const float* bias
     a.ldout = w.Cout;
     a.N = w.Cout;
     a.bf16 = r.bf16;
+    a.statsG = statsG;
+    if (statsG > 0 && pgemm_stats_supported(a)) {
+        y->stats = a.stats = r.zalloc((size_t)r.B * statsG * 2);
+        y->statsG = statsG;
+    }
     RUN(r, launch_pgemm(a, r.s));
     Run* rp = &r;
     const ConvP* wp = &w;
@@ -445,9 +454,16 @@ void pass_grad(Run& r, Ten* t, float* src) {
 }
 
 // y = act(GroupNorm(x)) + tb + res
-Ten* gnorm(Run& r, Ten* x, const NormP& n, int G, int act, const float* tb, float* dtb, int tb_ld, Ten* res = nullptr) {
+// ystats: also leave the per-image statistics of y for a following GroupNorm(1)
+Ten* gnorm(Run& r, Ten* x, const NormP& n, int G, int act, const float* tb, float* dtb, int tb_ld, Ten* res = nullptr,
+           bool ystats = false) {
     Ten* y = r.nt(x->C, x->H, x->W);
-    float* stats = r.zalloc((size_t)r.B * G * 2);
+    const bool have = x->stats && x->statsG == G;
+    float* stats = have ? x->stats : r.zalloc((size_t)r.B * G * 2);
+    if (ystats) {
+        y->stats = r.zalloc((size_t)r.B * 2);
+        y->statsG = 1;
+    }
     GnArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x->p;
@@ -463,7 +479,8 @@ Ten* gnorm(Run& r, Ten* x, const NormP& n, int G, int act, const float* tb, floa
     a.C = x->C;
     a.G = G;
     a.act = act;
-    RUN(r, launch_gn_stats(x->p, r.B, a.HW, a.C, G, stats, r.s));
+    a.ystats = y->stats;
+    if (!have) RUN(r, launch_gn_stats(x->p, r.B, a.HW, a.C, G, stats, r.s));
     RUN(r, launch_gn_apply(a, r.s));
     Run* rp = &r;
     float* dgamma = r.GP(n.g);
@@ -554,22 +571,23 @@ Ten* attn_core(Run& r, Ten* qkv, bool linear) {
     return y;
 }
 
-Ten* resblock(Run& r, Ten* x, const ResP& w, Ten* tb) {
+// out_stats: the block's output feeds a GroupNorm(1) (the PreNorm of an attention)
+Ten* resblock(Run& r, Ten* x, const ResP& w, Ten* tb, bool out_stats = false) {
     const int G = r.tr->cfg.groups;
-    Ten* h = conv(r, x, w.c1);
+    Ten* h = conv(r, x, w.c1, true, nullptr, nullptr, G);
     const bool time = tb && w.tb_off >= 0;
     h = gnorm(r, h, w.n1, G, 1, time ? tb->p + w.tb_off : nullptr, time ? tb->g + w.tb_off : nullptr, r.tr->tb_total);
-    h = conv(r, h, w.c2);
+    h = conv(r, h, w.c2, true, nullptr, nullptr, G);
     // the shortcut is computed first so that its sum with the block's tail comes out of the GroupNorm kernel
     Ten* res = w.has_res ? conv(r, x, w.res) : x;
-    return gnorm(r, h, w.n2, G, 1, nullptr, nullptr, 0, res);
+    return gnorm(r, h, w.n2, G, 1, nullptr, nullptr, 0, res, out_stats);
 }
 
 Ten* attention(Run& r, Ten* x, const AttnP& w) {
     Ten* xn = gnorm(r, x, w.pre, 1, 0, nullptr, nullptr, 0);
     Ten* qkv = conv(r, xn, w.qkv);
     Ten* o = attn_core(r, qkv, w.linear);
-    Ten* y = conv(r, o, w.out);
+    Ten* y = conv(r, o, w.out, true, nullptr, nullptr, w.linear ? 1 : 0);
     if (w.linear) y = gnorm(r, y, w.post, 1, 0, nullptr, nullptr, 0);
     return add(r, y, x);
 }
@@ -660,12 +678,12 @@ int run_step(DmnTrainer* tr, const float* params, float* grads, const StepIO& io
     std::vector<Ten*> skips;
     for (int i = 0; i < nlev; ++i) {
         cur = resblock(r, cur, tr->downs[i].rb[0], tb);
-        cur = resblock(r, cur, tr->downs[i].rb[1], tb);
+        cur = resblock(r, cur, tr->downs[i].rb[1], tb, true);
         cur = attention(r, cur, tr->downs[i].attn);
         if (i > 0) skips.push_back(cur);   // the top-level skip is never consumed (unet.py:95)
         if (tr->downs[i].has_resample) cur = conv(r, cur, tr->downs[i].resample);
     }
-    cur = resblock(r, cur, tr->mid1, tb);
+    cur = resblock(r, cur, tr->mid1, tb, true);
     cur = attention(r, cur, tr->mid_attn);
     cur = resblock(r, cur, tr->mid2, tb);
     for (int i = 0; i < nlev - 1; ++i) {
@@ -673,7 +691,7 @@ int run_step(DmnTrainer* tr, const float* params, float* grads, const StepIO& io
         skips.pop_back();
         cur = cat(r, cur, sk);
         cur = resblock(r, cur, tr->ups[i].rb[0], tb);
-        cur = resblock(r, cur, tr->ups[i].rb[1], tb);
+        cur = resblock(r, cur, tr->ups[i].rb[1], tb, true);
         cur = attention(r, cur, tr->ups[i].attn);
         cur = conv(r, cur, tr->ups[i].resample);
     }

@@ -21,8 +21,12 @@ struct PGemmArgs {
     int ldout, N;
     int accumulate;
     int bf16;               // 1: operands rounded to bf16 for the matrix cores (fp32 accumulate)
+    float* stats;           // optional [B][statsG][2], zeroed: += {sum, sum of squares} of the output per GroupNorm group
+    int statsG;
 };
 int launch_pgemm(const PGemmArgs& a, hipStream_t s);
+// whether launch_pgemm can produce `stats` for these shapes (64-pixel tiles must not straddle images)
+int pgemm_stats_supported(const PGemmArgs& a);
 
 // Weight gradient: dw[(tap*Cin + c)][n] += sum_m gather(x, m, tap)[c] * dy[m][n]   (atomic over pixel splits)
 struct WGemmArgs {
@@ -53,6 +57,7 @@ struct GnArgs {
     int tb_ld;
     const float* res;       // optional residual added after the activation (same shape as y)
     float* y;
+    float* ystats;          // optional [B][2], zeroed: += {sum, sum of squares} of y per image (a following GroupNorm(1))
     int B, HW, C, G, act;
     // backward
     const float* dy;

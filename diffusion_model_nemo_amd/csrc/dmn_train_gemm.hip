@@ -62,6 +62,43 @@ __device__ __forceinline__ bf16x8 pack_bf16(const float* v) {
     return o;
 }
 
+// GroupNorm statistics of a workgroup's 64-pixel x BN-channel output tile (all pixels in image b): per-lane sums over
+// its four pixels, the four lane groups of a wave, the four waves (through `red`, >= 8 * BN floats of LDS that
+// nothing reads any more), then one atomic pair per group the tile touches.
+template <int BN>
+__device__ __forceinline__ void tile_stats(const float (&s1)[BN / 16], const float (&s2)[BN / 16], float* red, int n0, int N, int Cg,
+                                           float* stats_b) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < BN / 16; ++j) {
+        float a = s1[j], b = s2[j];
+        a += __shfl_xor(a, 16, 64);
+        a += __shfl_xor(a, 32, 64);
+        b += __shfl_xor(b, 16, 64);
+        b += __shfl_xor(b, 32, 64);
+        if (q == 0) {
+            red[(wave * BN + 16 * j + r) * 2] = a;
+            red[(wave * BN + 16 * j + r) * 2 + 1] = b;
+        }
+    }
+    __syncthreads();
+    if (tid < BN) {
+        const int n = n0 + tid;
+        if (n < N && (tid == 0 || n % Cg == 0)) {
+            float a = 0.f, b = 0.f;
+            const int g = n / Cg;
+            for (int t = tid; t < BN && n0 + t < N && (n0 + t) / Cg == g; ++t)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    a += red[(w * BN + t) * 2];
+                    b += red[(w * BN + t) * 2 + 1];
+                }
+            unsafeAtomicAdd(stats_b + 2 * g, a);
+            unsafeAtomicAdd(stats_b + 2 * g + 1, b);
+        }
+    }
+}
+
 template <int BN, bool SLOW, bool BF>
 __global__ __launch_bounds__(256) void pgemm_kernel(const PGemmArgs a, const int M, const int pm) {
     constexpr int LDB = BN + 4, NJ = BN / 16, TPR = BN / 4, RPP = 256 / TPR, NB = 32 / RPP;
@@ -177,6 +214,9 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const PGemmArgs a, const int
     }
 
     // D[4q + i][r]: output pixel 16*wave + 4q + i of the tile, output channel 16j + r
+    float s1[NJ], s2[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) s1[j] = s2[j] = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + 16 * wave + 4 * q + i;
@@ -194,11 +234,14 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const PGemmArgs a, const int
             if (n < a.N) {
                 float v = acc[j][i];
                 if (a.bias) v += a.bias[n];
+                s1[j] += v;
+                s2[j] += v * v;
                 if (a.accumulate) v += o[n];
                 o[n] = v;
             }
         }
     }
+    if (a.stats) tile_stats<BN>(s1, s2, Bs, n0, a.N, a.N / a.statsG, a.stats + (size_t)(m0 / (a.Ho * a.Wo)) * a.statsG * 2);
 }
 
 // 3x3, stride 1, pad 1 (forward of the ResnetBlock convolutions and, with the taps mirrored, their input gradient):
@@ -293,6 +336,9 @@ __global__ __launch_bounds__(256) void pgemm_halo_kernel(const PGemmArgs a) {
         }
         __syncthreads();
     }
+    float s1[NJ], s2[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) s1[j] = s2[j] = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int pO = 16 * wave + 4 * q + i;
@@ -303,11 +349,14 @@ __global__ __launch_bounds__(256) void pgemm_halo_kernel(const PGemmArgs a) {
             if (n < a.N) {
                 float v = acc[j][i];
                 if (a.bias) v += a.bias[n];
+                s1[j] += v;
+                s2[j] += v * v;
                 if (a.accumulate) v += o[n];
                 o[n] = v;
             }
         }
     }
+    if (a.stats) tile_stats<BN>(s1, s2, Bs, n0, a.N, a.N / a.statsG, a.stats + (size_t)b * a.statsG * 2);
 }
 
 // Weight gradient tile TM (weight rows = (tap, cin)) x TN (cout) per workgroup, reduced over a contiguous range of
@@ -591,8 +640,15 @@ template <bool BF> static void pgemm_dispatch(const PGemmArgs& a, int M, int pm,
     }
 }
 
+int pgemm_stats_supported(const PGemmArgs& a) {
+    const int hw = a.Ho * a.Wo;
+    const bool halo = a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && (a.Ho & 7) == 0 && (a.Wo & 7) == 0;
+    return a.statsG > 0 && a.N % a.statsG == 0 && !a.accumulate && (halo || (hw % 64 == 0 && !(a.tmode == 1 && a.stride == 2)));
+}
+
 int launch_pgemm(const PGemmArgs& a, hipStream_t s) {
     DMN_REQUIRE(a.in && a.w && a.out && a.B > 0 && a.N > 0 && a.Cin > 0, DMN_ERR_INVALID, "pgemm: bad argument");
+    DMN_REQUIRE(!a.stats || pgemm_stats_supported(a), DMN_ERR_INVALID, "pgemm: statistics not supported for this shape");
     const long long Ml = (long long)a.B * a.Ho * a.Wo;
     DMN_REQUIRE(Ml < (1ll << 31) - 64, DMN_ERR_LIMIT, "pgemm: %lld output pixels", Ml);
     const int M = (int)Ml;

@@ -87,18 +87,22 @@ __device__ __forceinline__ void gn_mean_rstd(const float* stats, int bg, float i
     rstd = 1.0f / sqrtf(var + kGnEps);
 }
 
+// grid (blocks, B): a workgroup stays inside one image, so the statistics of its output need one atomic pair
 __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
-    const int c4n = a.C >> 2;
-    const long long total = (long long)a.B * a.HW * c4n;
+    __shared__ float sh[4];
+    const int c4n = a.C >> 2, b = blockIdx.y;
+    const long long total = (long long)a.HW * c4n;
     const int Cg = a.C / a.G;
     const float inv_cnt = 1.0f / ((float)Cg * (float)a.HW);
+    const size_t img = (size_t)b * a.HW * a.C;
+    float s1 = 0.f, s2 = 0.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const long long pix = i / c4n;
         const int c = 4 * (int)(i - pix * c4n);
-        const int b = (int)(pix / a.HW);
         float mean, rstd;
         gn_mean_rstd(a.stats, b * a.G + c / Cg, inv_cnt, mean, rstd);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + pix * a.C + c);
+        const size_t off = img + pix * a.C + c;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + off);
         const f32x4 ga = *reinterpret_cast<const f32x4*>(a.gamma + c), be = *reinterpret_cast<const f32x4*>(a.beta + c);
         f32x4 o;
 #pragma unroll
@@ -109,11 +113,21 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
             o[e] = z;
         }
         if (a.res) {
-            const f32x4 rv = *reinterpret_cast<const f32x4*>(a.res + pix * a.C + c);
+            const f32x4 rv = *reinterpret_cast<const f32x4*>(a.res + off);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] += rv[e];
         }
-        *reinterpret_cast<f32x4*>(a.y + pix * a.C + c) = o;
+        *reinterpret_cast<f32x4*>(a.y + off) = o;
+        s1 += (o[0] + o[1]) + (o[2] + o[3]);
+        s2 += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+    }
+    if (a.ystats) {
+        s1 = block_sum(s1, sh);
+        s2 = block_sum(s2, sh);
+        if (threadIdx.x == 0) {
+            unsafeAtomicAdd(a.ystats + 2 * b, s1);
+            unsafeAtomicAdd(a.ystats + 2 * b + 1, s2);
+        }
     }
 }
 
@@ -870,7 +884,8 @@ int launch_gn_stats(const float* x, int B, int HW, int C, int G, float* stats, h
 
 int launch_gn_apply(const GnArgs& a, hipStream_t s) {
     DMN_REQUIRE(a.C % 4 == 0 && a.C % a.G == 0 && (a.C / a.G) % 4 == 0, DMN_ERR_INVALID, "gn: C=%d G=%d", a.C, a.G);
-    gn_apply_kernel<<<grid_for((long long)a.B * a.HW * a.C / 4), 256, 0, s>>>(a);
+    const int cap = 4096 / a.B > 1 ? 4096 / a.B : 1;
+    gn_apply_kernel<<<dim3(grid_for((long long)a.HW * a.C / 4, 256 * 2, cap), a.B), 256, 0, s>>>(a);
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }
