@@ -51,6 +51,7 @@ SIGNATURES = {
     "dmn_bench_dominant_kernel": (_i, [_vp, _i, _i, _i, _i, _vp, _sz, _vp, C.POINTER(_f), C.POINTER(C.c_double)]),
     "dmn_train_create": (_i, [C.POINTER(DmnUnetCfg), _i, C.POINTER(_vp)]),
     "dmn_train_destroy": (None, [_vp]),
+    "dmn_train_set_class_labels": (_i, [_vp, _vp]),
     "dmn_train_num_tensors": (_i, [_vp]),
     "dmn_train_flat_size": (_i64, [_vp]),
     "dmn_train_tensor_info": (_i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(_i64), C.POINTER(_i), C.POINTER(_i64 * 4)]),

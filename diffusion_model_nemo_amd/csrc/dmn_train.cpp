@@ -72,6 +72,8 @@ struct DmnTrainer {
     std::vector<LevelP> downs, ups;
     ResP mid1, mid2, final_rb;
     AttnP mid_attn;
+    int class_embed = -1;                 // parameter index of class_embed.weight (class-conditional networks)
+    const long long* labels = nullptr;    // borrowed device labels of the coming steps
     int tb_total = 0;
     long long tb_bias_off = 0;   // the per-block time-linear biases are consecutive in the flat buffer
     // workspace region sizes of the last shape
@@ -233,6 +235,7 @@ int build_structure(DmnTrainer* tr) {
     } else {
         tr->tail = b.conv("final_conv.1", c.out_dim, dim, 1, 1, 0, true);
     }
+    if (c.num_classes > 0) tr->class_embed = b.add_param("class_embed.weight", {c.num_classes + 1, dim});
     // per-block time linears: weights as column blocks of one [td][tb_total] matrix, biases consecutive
     int total = 0;
     for (auto& t : tl) total += t.cout;
@@ -675,6 +678,14 @@ int run_step(DmnTrainer* tr, const float* params, float* grads, const StepIO& io
     (void)td;
 
     Ten* cur = conv(r, xt, tr->init, false);
+    if (tr->class_embed >= 0) {   // x = init_conv(x) + class_embed(classes)[:, :, None, None]  (unet.py:134-141), in place
+        RUN(r, launch_class_bias_fwd(cur->p, r.P(tr->class_embed), tr->labels, c.num_classes, B, H * W, c.dim, s));
+        Run* rp = &r;
+        r.tape.push_back([rp, cur, tr, H, W]() {
+            Run& r = *rp;
+            RUN(r, launch_class_bias_bwd(cur->g, tr->labels, tr->cfg.num_classes, r.GP(tr->class_embed), r.B, H * W, tr->cfg.dim, r.s));
+        });
+    }
     std::vector<Ten*> skips;
     for (int i = 0; i < nlev; ++i) {
         cur = resblock(r, cur, tr->downs[i].rb[0], tb);
@@ -727,7 +738,7 @@ extern "C" int dmn_train_create(const DmnUnetCfg* cfg, int loss_kind, DmnTrainer
     DMN_REQUIRE(cfg->dim % 32 == 0 && cfg->dim >= 32, DMN_ERR_LIMIT, "dim=%d must be a multiple of 32", cfg->dim);
     DMN_REQUIRE(cfg->dim_head == 32 && cfg->heads >= 1, DMN_ERR_INVALID, "dim_head=%d (only 32 supported)", cfg->dim_head);
     DMN_REQUIRE(cfg->with_time_emb == 1, DMN_ERR_INVALID, "training needs the time embedding");
-    DMN_REQUIRE(cfg->num_classes == 0, DMN_ERR_INVALID, "class-conditional training is not built");
+    DMN_REQUIRE(cfg->num_classes >= 0 && (cfg->num_classes == 0 || cfg->dim <= 256), DMN_ERR_INVALID, "num_classes=%d", cfg->num_classes);
     DMN_REQUIRE(cfg->out_dim == cfg->channels, DMN_ERR_INVALID, "L_simple needs out_dim == channels (got %d, %d)", cfg->out_dim, cfg->channels);
     DMN_REQUIRE(cfg->groups >= 1 && cfg->groups <= 64 && cfg->dim % cfg->groups == 0 && (cfg->dim / cfg->groups) % 4 == 0,
                 DMN_ERR_INVALID, "groups=%d", cfg->groups);
@@ -755,6 +766,13 @@ extern "C" void dmn_train_destroy(DmnTrainer* tr) {
     if (!tr) return;
     if (tr->descs_dev) (void)hipFree(tr->descs_dev);
     delete tr;
+}
+
+extern "C" int dmn_train_set_class_labels(DmnTrainer* tr, const int64_t* labels) {
+    DMN_REQUIRE(tr, DMN_ERR_INVALID, "dmn_train_set_class_labels: null handle");
+    DMN_REQUIRE(tr->cfg.num_classes > 0 || labels == nullptr, DMN_ERR_INVALID, "the network has no class embedding");
+    tr->labels = reinterpret_cast<const long long*>(labels);
+    return DMN_OK;
 }
 
 extern "C" int dmn_train_num_tensors(const DmnTrainer* tr) { return tr ? (int)tr->params.size() : 0; }

@@ -80,6 +80,11 @@ int launch_copy_slice(float* dst, int ldd, int doff, const float* src, int lds, 
 // act: 0 SiLU, 1 exact GELU. Forward y = act(x); backward dx (+)= dy * act'(x).
 int launch_act_fwd(const float* x, float* y, long long n, int act, hipStream_t s);
 int launch_act_bwd(const float* x, const float* dy, float* dx, long long n, int act, int accumulate, hipStream_t s);
+// Class conditioning (modules/unet.py:134-141): x[b][p][c] += table[label_b][c] in place (labels null: every image takes
+// row `pad`, the "no class" row); backward: dtable[label_b][c] += sum_p dy[b][p][c] except for row `pad`
+// (nn.Embedding's padding_idx keeps that row's gradient at zero).
+int launch_class_bias_fwd(float* x, const float* table, const long long* labels, int pad, int B, int HW, int C, hipStream_t s);
+int launch_class_bias_bwd(const float* dy, const long long* labels, int pad, float* dtable, int B, int HW, int C, hipStream_t s);
 // Sinusoidal embedding of integer or float labels: out[b][dim]
 int launch_sinus(const void* t, int t_is_float, int B, int dim, float* out, hipStream_t s);
 

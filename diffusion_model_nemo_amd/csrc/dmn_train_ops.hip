@@ -253,6 +253,35 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
         dx[i] = acc ? dx[i] + g : g;
     }
 }
+__global__ __launch_bounds__(256) void class_bias_fwd_kernel(float* __restrict__ x, const float* __restrict__ table,
+                                                             const long long* __restrict__ labels, int pad, int HW, int C) {
+    const int b = blockIdx.y;
+    const long long row = labels ? labels[b] : pad;
+    const float* e = table + row * C;
+    float* xb = x + (size_t)b * HW * C;
+    const long long total = (long long)HW * C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) xb[i] += e[i % C];
+}
+// grid (splits, B); thread = channel (c = tid % C) x pixel lane
+__global__ __launch_bounds__(256) void class_bias_bwd_kernel(const float* __restrict__ dy, const long long* __restrict__ labels, int pad,
+                                                             float* __restrict__ dtable, int HW, int C) {
+    __shared__ float sh[256];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const long long row = labels ? labels[b] : pad;
+    if (row == pad) return;
+    const int c = tid % C, pl = tid / C, npl = 256 / C;
+    float acc = 0.f;
+    if (pl < npl)
+        for (int p = blockIdx.x * npl + pl; p < HW; p += gridDim.x * npl) acc += dy[((size_t)b * HW + p) * C + c];
+    sh[tid] = acc;
+    __syncthreads();
+    if (pl == 0) {
+        float t = 0.f;
+        for (int l = 0; l < npl; ++l) t += sh[l * C + c];
+        unsafeAtomicAdd(dtable + row * C + c, t);
+    }
+}
+
 // parts/positional_encoding.py:11-18: frequencies exp(i * -(ln 1e4 / (half - 1))) in float32, [sin | cos]
 __global__ void sinus_kernel(const void* t, int t_is_float, int B, int dim, float* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -930,6 +959,20 @@ int launch_act_fwd(const float* x, float* y, long long n, int act, hipStream_t s
 }
 int launch_act_bwd(const float* x, const float* dy, float* dx, long long n, int act, int accumulate, hipStream_t s) {
     act_bwd_kernel<<<grid_for(n, 1024), 256, 0, s>>>(x, dy, dx, n, act, accumulate);
+    DMN_LAUNCH_CHECK();
+    return DMN_OK;
+}
+int launch_class_bias_fwd(float* x, const float* table, const long long* labels, int pad, int B, int HW, int C, hipStream_t s) {
+    class_bias_fwd_kernel<<<dim3(grid_for((long long)HW * C, 1024, 256), B), 256, 0, s>>>(x, table, labels, pad, HW, C);
+    DMN_LAUNCH_CHECK();
+    return DMN_OK;
+}
+int launch_class_bias_bwd(const float* dy, const long long* labels, int pad, float* dtable, int B, int HW, int C, hipStream_t s) {
+    DMN_REQUIRE(C <= 256, DMN_ERR_LIMIT, "class embedding width %d", C);
+    const int npl = 256 / C;
+    int split = (HW + npl * 16 - 1) / (npl * 16);
+    if (split > 64) split = 64;
+    class_bias_bwd_kernel<<<dim3(split, B), 256, 0, s>>>(dy, labels, pad, dtable, HW, C);
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }

@@ -189,6 +189,12 @@ class DDPM(AbstractDiffusionModel):
             object.__setattr__(self, "_native_trainer", tr)
         return tr
 
+    def _training_classes(self, batch):
+        """Class labels of a training batch: what `get_diffusion_model(batch)` binds to `classes` (none here; the
+        class-conditional subclass applies its label drop-out there, models/conditional_ddpm.py:51-67)."""
+        fn = self.get_diffusion_model(batch)
+        return getattr(fn, "keywords", {}).get("classes") if hasattr(fn, "keywords") else None
+
     def training_step(self, batch, batch_nb=0, t: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None):
         """models/ddpm.py:43-57: t ~ U{0..T-1}, eps ~ N(0, I), x_t = q_sample(x_0, t, eps), loss(net(x_t, t), eps).
         Forward AND backward run in the HIP kernels during this call; the returned scalar carries an autograd node
@@ -204,7 +210,8 @@ class DDPM(AbstractDiffusionModel):
             noise = torch.randn_like(samples)
         tr = self.native_trainer()
         s = self.sampler
-        value = tr.loss_and_grads(samples, t, noise, s.sqrt_alphas_cumprod, s.sqrt_one_minus_alphas_cumprod)
+        value = tr.loss_and_grads(samples, t, noise, s.sqrt_alphas_cumprod, s.sqrt_one_minus_alphas_cumprod,
+                                  classes=self._training_classes(batch))
         params = [p for p in self.diffusion_model.parameters()]
         names = [n for n, _ in self.diffusion_model.named_parameters()]
         return _NativeLoss.apply(value, tr, names, *params)
@@ -222,7 +229,8 @@ class DDPM(AbstractDiffusionModel):
             noise = torch.randn_like(samples)
         tr = self.native_trainer()
         s = self.sampler
-        value = tr.loss_and_grads(samples, t, noise, s.sqrt_alphas_cumprod, s.sqrt_one_minus_alphas_cumprod)
+        value = tr.loss_and_grads(samples, t, noise, s.sqrt_alphas_cumprod, s.sqrt_one_minus_alphas_cumprod,
+                                  classes=self._training_classes(batch))
         scale = tr.all_reduce_grads()
         optim = self.cfg.get('optim', None) or {}
         name = optim.get('name', 'adamw')

@@ -98,7 +98,7 @@ class UnetTrainer:
     def loss_and_grads(self, x0: torch.Tensor, t: torch.Tensor, noise: torch.Tensor,
                        sqrt_alphas_cumprod: Optional[torch.Tensor] = None,
                        sqrt_one_minus_alphas_cumprod: Optional[torch.Tensor] = None,
-                       model_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                       model_out: Optional[torch.Tensor] = None, classes: Optional[torch.Tensor] = None) -> torch.Tensor:
         """loss = DiffusionLoss(Unet(q_sample(x0, t, noise), t), noise) and its gradient into `self.grads`
         (overwritten). Without the two schedule tables x0 is taken as x_t. Returns the loss as a device scalar."""
         if not x0.is_cuda:
@@ -117,6 +117,15 @@ class UnetTrainer:
             sb = sqrt_one_minus_alphas_cumprod.to(self.device, torch.float32).contiguous()
             if int(t.max()) >= sa.numel() or int(t.min()) < 0:
                 raise IndexError("timestep out of range")
+        labels = None
+        if self.unet.num_classes is not None:
+            if classes is not None:
+                labels = classes.to(self.device, torch.int64).contiguous()
+                if labels.shape != (B,):
+                    raise ValueError("classes must have shape [B]")
+                if int(labels.min()) < 0 or int(labels.max()) > self.unet.num_classes:
+                    raise IndexError("class label out of range")
+            N.check(N.lib().dmn_train_set_class_labels(self._handle, N.ptr(labels)))
         ws = self._workspace(B, H, W)
         base = ws.data_ptr()
         aligned = (base + 255) & ~255
@@ -125,7 +134,7 @@ class UnetTrainer:
             self._handle, self.params.data_ptr(), self.grads.data_ptr(), x0.data_ptr(), noise.data_ptr(), t.data_ptr(),
             N.ptr(sa), N.ptr(sb), B, H, W, loss.data_ptr(), N.ptr(model_out), aligned, ws.numel() - (aligned - base),
             N.current_stream_handle(self.device)))
-        self._keep = (x0, noise, t, sa, sb)   # borrowed by the kernels until the stream has run them
+        self._keep = (x0, noise, t, sa, sb, labels)   # borrowed by the kernels until the stream has run them
         return loss[0]
 
     def all_reduce_grads(self):

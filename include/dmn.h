@@ -138,13 +138,17 @@ int dmn_bench_dominant_kernel(DmnUnet* u, int B, int H, int W, int iters, void* 
  * (examples/configs/ddpm/unet_small.yaml:65-78). Parameters and gradients are ONE flat float32 device buffer each,
  * every tensor in the reference's own layout at the offset dmn_train_tensor_info reports (offsets are multiples of
  * 4 floats), so a state_dict maps in by name and one all-reduce covers every gradient. float32 activations.
- * Unconditional networks with out_dim == channels only. */
+ * Networks with out_dim == channels only. */
 typedef struct DmnTrainer DmnTrainer;
 /* loss_kind: 0 'l1', 1 'l2', 2 'huber' with reduction 'mean' (loss/simple_loss.py:37-45).
  * cfg->dtype selects the matrix-core operand type of the convolutions / linears: 0 exact float32, 1 operands rounded to
  * bfloat16 (float32 accumulate); activations, gradients, norms, attention and the optimiser stay float32 either way. */
 int dmn_train_create(const DmnUnetCfg* cfg, int loss_kind, DmnTrainer** out);
 void dmn_train_destroy(DmnTrainer* tr);
+/* Class labels of the next steps (unet.py:134-141; ConditionalDDPM.get_diffusion_model, models/conditional_ddpm.py:51-67,
+ * applies the label drop-out before): DEVICE int64 [B], borrowed until replaced; NULL = the "no class" row for every
+ * image. The gradient of that row stays zero (padding_idx of the reference's nn.Embedding). */
+int dmn_train_set_class_labels(DmnTrainer* tr, const int64_t* labels);
 int dmn_train_num_tensors(const DmnTrainer* tr);
 int64_t dmn_train_flat_size(const DmnTrainer* tr);           /* floats in the flat parameter / gradient buffers */
 /* name as in Unet.state_dict(); shape in PyTorch order (shape4 receives 4 entries, unused ones 0). */

@@ -154,6 +154,42 @@ def test_bf16_operand_mode_stays_close_to_fp32_gradients():
     print("bf16 operands: worst relative error", worst_rel, "worst cosine", worst_cos)
 
 
+def test_class_conditional_gradients_match_oracle_and_null_row_stays_frozen():
+    """Class-conditional network (modules/unet.py:118-141): gradients with labels, including the embedding table; the
+    "no class" row keeps a zero gradient like the reference's nn.Embedding(padding_idx=num_classes)."""
+    from diffusion_model_nemo_amd.modules import Unet
+    from diffusion_model_nemo_amd.training import UnetTrainer
+    K = 10
+    u = Unet(input_dim=32, dim=32, dim_mults=[1, 2, 4, 8], channels=3, resnet_block_groups=8, use_convnext=False,
+             dropout=0.0, num_classes=K, compute_dtype="fp32")
+    sd = make_state_dict(unet_param_shapes(num_classes=K))
+    sd["class_embed.weight"][K] = 0.0   # the padding row of nn.Embedding is zero
+    u.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    tr = UnetTrainer(u.cuda())
+    gen = torch.Generator().manual_seed(31)
+    x0 = torch.tanh(torch.randn(3, 3, 32, 32, generator=gen))
+    noise = torch.randn(3, 3, 32, 32, generator=gen)
+    t = torch.tensor([7, 450, 990])
+    classes = torch.tensor([3, K, 3])   # one dropped label
+    c = R.ddpm_constants(1000, "cosine")
+    p = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in sd.items()}
+    val = R.ddpm_training_loss(lambda x, tt: R.unet_forward(p, x, tt, classes=classes), c, x0, t, noise)
+    val.backward()
+    ref = {k: v.grad.clone() for k, v in p.items()}
+    ref["class_embed.weight"][K] = 0.0   # padding_idx: the reference never updates that row
+    got = tr.loss_and_grads(x0.cuda(), t.cuda(), noise.cuda(), c["sqrt_alphas_cumprod"], c["sqrt_one_minus_alphas_cumprod"],
+                            classes=classes.cuda())
+    assert abs(float(got) - float(val)) <= 1e-5 * abs(float(val))
+    check_all(tr, ref)
+    assert float(tr.grad_of("class_embed.weight")[K].abs().max()) == 0.0
+    assert float(tr.grad_of("class_embed.weight")[3].abs().max()) > 0.0
+    # classes=None: every image takes the "no class" row
+    val0 = R.ddpm_training_loss(lambda x, tt: R.unet_forward({k: v.detach() for k, v in p.items()}, x, tt), c, x0, t, noise)
+    got0 = tr.loss_and_grads(x0.cuda(), t.cuda(), noise.cuda(), c["sqrt_alphas_cumprod"], c["sqrt_one_minus_alphas_cumprod"])
+    assert abs(float(got0) - float(val0)) <= 1e-5 * abs(float(val0))
+    assert float(tr.grad_of("class_embed.weight").abs().max()) == 0.0
+
+
 def test_rejects_bad_arguments():
     u, tr, sd = build()
     with pytest.raises(RuntimeError):

@@ -292,7 +292,7 @@ def test_training_parameter_table_matches_reference_state_dict_and_lr_schedule()
         assert b.value > 4 * n
         assert N.lib().dmn_train_workspace_bytes(h, 2, 34, 34, C.byref(b)) != 0   # not a multiple of 2^(levels-1)
         N.lib().dmn_train_destroy(h)
-    # learned-variance / class-conditional networks are refused, not silently trained on a different loss
+    # learned-variance networks are refused, not silently trained on a different loss
     cfg.out_dim = 6
     h = C.c_void_p()
     assert N.lib().dmn_train_create(C.byref(cfg), 1, C.byref(h)) != 0
