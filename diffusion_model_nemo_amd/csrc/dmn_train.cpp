@@ -288,8 +288,9 @@ struct Bump {
 };
 
 struct Ten {
-    float* p = nullptr;
-    float* g = nullptr;
+    void* p = nullptr;
+    void* g = nullptr;
+    int adt = 0;              // 0 float32, 1 bfloat16 storage (value and gradient alike)
     int C = 0, H = 0, W = 0;
     bool gset = false;
     float* stats = nullptr;   // {sum, sum of squares} per (image, group) left by the producing kernel
@@ -301,7 +302,8 @@ struct Run {
     hipStream_t s;
     bool dry;
     int B;
-    int bf16 = 0;
+    int bf16 = 0;             // matrix-core operand type of the GEMMs
+    int img_adt = 0;          // storage type of the image-shaped activations (the time path's small tensors stay float32)
     int rc = DMN_OK;
     Bump a, z;
     const float* params;
@@ -327,18 +329,24 @@ struct Run {
         return p;
     }
     size_t numel(const Ten* t) const { return (size_t)B * t->H * t->W * t->C; }
-    Ten* nt(int C, int H, int W) {
+    void* alloc_elems(size_t n, int adt) {
+        void* p = a.alloc(n * (adt == 1 ? 2 : 4));
+        if (!p) fail_ws();
+        return p;
+    }
+    Ten* nt(int C, int H, int W, int adt) {
         tens.emplace_back();
         Ten* t = &tens.back();
         t->C = C;
         t->H = H;
         t->W = W;
-        t->p = alloc(numel(t));
+        t->adt = adt;
+        t->p = alloc_elems(numel(t), adt);
         return t;
     }
     // gradient buffer of t and whether the coming write must accumulate
-    float* G(Ten* t, int* acc) {
-        if (!t->g) t->g = alloc(numel(t));
+    void* G(Ten* t, int* acc) {
+        if (!t->g) t->g = alloc_elems(numel(t), t->adt);
         *acc = t->gset ? 1 : 0;
         t->gset = true;
         return t->g;
@@ -361,7 +369,7 @@ Ten* conv(Run& r, Ten* x, const ConvP& w, bool need_dx = true, const float* bias
           int statsG = 0) {
     const int Ho = w.transposed ? (x->H - 1) * w.stride - 2 * w.pad + w.k : (x->H + 2 * w.pad - w.k) / w.stride + 1;
     const int Wo = w.transposed ? (x->W - 1) * w.stride - 2 * w.pad + w.k : (x->W + 2 * w.pad - w.k) / w.stride + 1;
-    Ten* y = r.nt(w.Cout, Ho, Wo);
+    Ten* y = r.nt(w.Cout, Ho, Wo, x->adt);
     const float* bias = bias_override ? bias_override : r.P(w.b);
     float* dbias = dbias_override ? dbias_override : r.GP(w.b);
     PGemmArgs a;
@@ -385,6 +393,7 @@ Ten* conv(Run& r, Ten* x, const ConvP& w, bool need_dx = true, const float* bias
     a.ldout = w.Cout;
     a.N = w.Cout;
     a.bf16 = r.bf16;
+    a.adt = x->adt;
     a.statsG = statsG;
     if (statsG > 0 && pgemm_stats_supported(a)) {
         y->stats = a.stats = r.zalloc((size_t)r.B * statsG * 2);
@@ -416,6 +425,7 @@ Ten* conv(Run& r, Ten* x, const ConvP& w, bool need_dx = true, const float* bias
         g.dw = r.dwf + w.f_off;
         g.lddw = w.f_ld;
         g.bf16 = r.bf16;
+        g.adt = x->adt;
         g.dbias = dbias;
         RUN(r, launch_wgemm(g, r.s));
         if (need_dx) {
@@ -439,6 +449,7 @@ Ten* conv(Run& r, Ten* x, const ConvP& w, bool need_dx = true, const float* bias
             d.ldout = x->C;
             d.N = w.Cin;
             d.bf16 = r.bf16;
+            d.adt = x->adt;
             RUN(r, launch_pgemm(d, r.s));
         }
     });
@@ -447,20 +458,20 @@ Ten* conv(Run& r, Ten* x, const ConvP& w, bool need_dx = true, const float* bias
 
 // the gradient of `t` receives `src` (a gradient buffer nothing reads after the calling closure): the first writer
 // simply takes the buffer over, later ones accumulate
-void pass_grad(Run& r, Ten* t, float* src) {
+void pass_grad(Run& r, Ten* t, void* src) {
     if (!t->gset) {
         t->g = src;
         t->gset = true;
         return;
     }
-    RUN(r, launch_axpby(t->g, src, (long long)r.numel(t), 1, r.s));
+    RUN(r, launch_axpby(t->g, src, t->adt, (long long)r.numel(t), 1, r.s));
 }
 
 // y = act(GroupNorm(x)) + tb + res
 // ystats: also leave the per-image statistics of y for a following GroupNorm(1)
 Ten* gnorm(Run& r, Ten* x, const NormP& n, int G, int act, const float* tb, float* dtb, int tb_ld, Ten* res = nullptr,
            bool ystats = false) {
-    Ten* y = r.nt(x->C, x->H, x->W);
+    Ten* y = r.nt(x->C, x->H, x->W, x->adt);
     const bool have = x->stats && x->statsG == G;
     float* stats = have ? x->stats : r.zalloc((size_t)r.B * G * 2);
     if (ystats) {
@@ -482,8 +493,9 @@ Ten* gnorm(Run& r, Ten* x, const NormP& n, int G, int act, const float* tb, floa
     a.C = x->C;
     a.G = G;
     a.act = act;
+    a.adt = x->adt;
     a.ystats = y->stats;
-    if (!have) RUN(r, launch_gn_stats(x->p, r.B, a.HW, a.C, G, stats, r.s));
+    if (!have) RUN(r, launch_gn_stats(x->p, x->adt, r.B, a.HW, a.C, G, stats, r.s));
     RUN(r, launch_gn_apply(a, r.s));
     Run* rp = &r;
     float* dgamma = r.GP(n.g);
@@ -503,73 +515,73 @@ Ten* gnorm(Run& r, Ten* x, const NormP& n, int G, int act, const float* tb, floa
 }
 
 Ten* add(Run& r, Ten* a, Ten* b) {
-    Ten* y = r.nt(a->C, a->H, a->W);
-    RUN(r, launch_add(y->p, a->p, b->p, (long long)r.numel(y), r.s));
+    Ten* y = r.nt(a->C, a->H, a->W, a->adt);
+    RUN(r, launch_add(y->p, a->p, b->p, y->adt, (long long)r.numel(y), r.s));
     Run* rp = &r;
     r.tape.push_back([rp, a, b, y]() {
         Run& r = *rp;
         int acc;
-        float* gb = r.G(b, &acc);
-        RUN(r, launch_axpby(gb, y->g, (long long)r.numel(y), acc, r.s));
+        void* gb = r.G(b, &acc);
+        RUN(r, launch_axpby(gb, y->g, y->adt, (long long)r.numel(y), acc, r.s));
         pass_grad(r, a, y->g);
     });
     return y;
 }
 
 Ten* cat(Run& r, Ten* a, Ten* b) {
-    Ten* y = r.nt(a->C + b->C, a->H, a->W);
+    Ten* y = r.nt(a->C + b->C, a->H, a->W, a->adt);
     const long long rows = (long long)r.B * a->H * a->W;
-    RUN(r, launch_copy_slice(y->p, y->C, 0, a->p, a->C, 0, a->C, rows, 0, r.s));
-    RUN(r, launch_copy_slice(y->p, y->C, a->C, b->p, b->C, 0, b->C, rows, 0, r.s));
+    RUN(r, launch_copy_slice(y->p, y->C, 0, a->p, a->C, 0, a->C, rows, y->adt, 0, r.s));
+    RUN(r, launch_copy_slice(y->p, y->C, a->C, b->p, b->C, 0, b->C, rows, y->adt, 0, r.s));
     Run* rp = &r;
     r.tape.push_back([rp, a, b, y, rows]() {
         Run& r = *rp;
         int acc;
-        float* ga = r.G(a, &acc);
-        RUN(r, launch_copy_slice(ga, a->C, 0, y->g, y->C, 0, a->C, rows, acc, r.s));
-        float* gb = r.G(b, &acc);
-        RUN(r, launch_copy_slice(gb, b->C, 0, y->g, y->C, a->C, b->C, rows, acc, r.s));
+        void* ga = r.G(a, &acc);
+        RUN(r, launch_copy_slice(ga, a->C, 0, y->g, y->C, 0, a->C, rows, y->adt, acc, r.s));
+        void* gb = r.G(b, &acc);
+        RUN(r, launch_copy_slice(gb, b->C, 0, y->g, y->C, a->C, b->C, rows, y->adt, acc, r.s));
     });
     return y;
 }
 
 Ten* activation(Run& r, Ten* x, int act) {
-    Ten* y = r.nt(x->C, x->H, x->W);
-    RUN(r, launch_act_fwd(x->p, y->p, (long long)r.numel(x), act, r.s));
+    Ten* y = r.nt(x->C, x->H, x->W, x->adt);
+    RUN(r, launch_act_fwd(x->p, y->p, x->adt, (long long)r.numel(x), act, r.s));
     Run* rp = &r;
     r.tape.push_back([rp, x, y, act]() {
         Run& r = *rp;
         int acc;
-        float* gx = r.G(x, &acc);
-        RUN(r, launch_act_bwd(x->p, y->g, gx, (long long)r.numel(x), act, acc, r.s));
+        void* gx = r.G(x, &acc);
+        RUN(r, launch_act_bwd(x->p, y->g, gx, x->adt, (long long)r.numel(x), act, acc, r.s));
     });
     return y;
 }
 
 Ten* attn_core(Run& r, Ten* qkv, bool linear) {
     const int heads = r.tr->cfg.heads, hidden = heads * 32, n = qkv->H * qkv->W;
-    Ten* y = r.nt(hidden, qkv->H, qkv->W);
+    Ten* y = r.nt(hidden, qkv->H, qkv->W, qkv->adt);
     float* ctx = linear ? r.zalloc((size_t)r.B * heads * 1024) : nullptr;
     float* st = linear ? r.zalloc((size_t)r.B * heads * 64) : r.alloc((size_t)r.B * heads * n * 2);
     if (linear) {
         float* pmax = r.alloc((size_t)r.B * heads * linattn_train_splits(r.B, n, heads) * 32);
-        RUN(r, launch_linattn_train_fwd(qkv->p, y->p, ctx, st, pmax, r.B, n, heads, r.bf16, r.s));
+        RUN(r, launch_linattn_train_fwd(qkv->p, y->p, qkv->adt, ctx, st, pmax, r.B, n, heads, r.bf16, r.s));
     }
-    else RUN(r, launch_attn_train_fwd(qkv->p, y->p, st, r.B, n, heads, r.s));
+    else RUN(r, launch_attn_train_fwd(qkv->p, y->p, qkv->adt, st, r.B, n, heads, r.s));
     Run* rp = &r;
     r.tape.push_back([rp, qkv, y, ctx, st, linear, n, heads]() {
         Run& r = *rp;
         int acc;
-        float* g = r.G(qkv, &acc);   // qkv has this single consumer: the kernels overwrite
+        void* g = r.G(qkv, &acc);   // qkv has this single consumer: the kernels overwrite
         if (acc && r.rc == DMN_OK) {
             dmn_set_error("internal: attention input gradient already set");
             r.rc = DMN_ERR_INVALID;
         }
         if (linear) {
             float* dctx = r.zalloc((size_t)r.B * heads * 1024);
-            RUN(r, launch_linattn_train_bwd(qkv->p, y->g, ctx, st, dctx, g, r.B, n, heads, r.bf16, r.s));
+            RUN(r, launch_linattn_train_bwd(qkv->p, y->g, qkv->adt, ctx, st, dctx, g, r.B, n, heads, r.bf16, r.s));
         }
-        else RUN(r, launch_attn_train_bwd(qkv->p, y->p, y->g, st, g, r.B, n, heads, r.s));
+        else RUN(r, launch_attn_train_bwd(qkv->p, y->p, y->g, qkv->adt, st, g, r.B, n, heads, r.s));
     });
     return y;
 }
@@ -579,7 +591,8 @@ Ten* resblock(Run& r, Ten* x, const ResP& w, Ten* tb, bool out_stats = false) {
     const int G = r.tr->cfg.groups;
     Ten* h = conv(r, x, w.c1, true, nullptr, nullptr, G);
     const bool time = tb && w.tb_off >= 0;
-    h = gnorm(r, h, w.n1, G, 1, time ? tb->p + w.tb_off : nullptr, time ? tb->g + w.tb_off : nullptr, r.tr->tb_total);
+    h = gnorm(r, h, w.n1, G, 1, time ? (const float*)tb->p + w.tb_off : nullptr, time ? (float*)tb->g + w.tb_off : nullptr,
+              r.tr->tb_total);
     h = conv(r, h, w.c2, true, nullptr, nullptr, G);
     // the shortcut is computed first so that its sum with the block's tail comes out of the GroupNorm kernel
     Ten* res = w.has_res ? conv(r, x, w.res) : x;
@@ -618,7 +631,8 @@ int run_step(DmnTrainer* tr, const float* params, float* grads, const StepIO& io
     r.s = s;
     r.dry = dry;
     r.B = B;
-    r.bf16 = c.dtype == 1 ? 1 : 0;
+    r.bf16 = c.dtype >= 1 ? 1 : 0;
+    r.img_adt = c.dtype == 2 ? 1 : 0;
     r.params = params;
     r.grads = grads;
     // workspace: [wf | wb | zero region: dwf + zero arena | arena]
@@ -662,12 +676,12 @@ int run_step(DmnTrainer* tr, const float* params, float* grads, const StepIO& io
 
     const int td = 4 * c.dim;
     // inputs
-    Ten* xt = r.nt(c.channels, H, W);
-    Ten* tgt = r.nt(c.channels, H, W);
-    RUN(r, launch_train_ingest(io.x0, io.noise, io.t, io.sa, io.sb, xt->p, tgt->p, B, c.channels, H, W, s));
+    Ten* xt = r.nt(c.channels, H, W, r.img_adt);
+    Ten* tgt = r.nt(c.channels, H, W, 0);
+    RUN(r, launch_train_ingest(io.x0, io.noise, io.t, io.sa, io.sb, xt->p, xt->adt, (float*)tgt->p, B, c.channels, H, W, s));
     // time path (modules/unet.py:61-66, parts/convnext.py:68-72,81-83)
-    Ten* emb = r.nt(c.dim, 1, 1);
-    RUN(r, launch_sinus(io.t, 0, B, c.dim, emb->p, s));
+    Ten* emb = r.nt(c.dim, 1, 1, 0);
+    RUN(r, launch_sinus(io.t, 0, B, c.dim, (float*)emb->p, s));
     Ten* h1 = conv(r, emb, tr->t1, false);
     Ten* h2 = activation(r, h1, 1);
     Ten* temb = conv(r, h2, tr->t2);
@@ -679,11 +693,12 @@ int run_step(DmnTrainer* tr, const float* params, float* grads, const StepIO& io
 
     Ten* cur = conv(r, xt, tr->init, false);
     if (tr->class_embed >= 0) {   // x = init_conv(x) + class_embed(classes)[:, :, None, None]  (unet.py:134-141), in place
-        RUN(r, launch_class_bias_fwd(cur->p, r.P(tr->class_embed), tr->labels, c.num_classes, B, H * W, c.dim, s));
+        RUN(r, launch_class_bias_fwd(cur->p, cur->adt, r.P(tr->class_embed), tr->labels, c.num_classes, B, H * W, c.dim, s));
         Run* rp = &r;
         r.tape.push_back([rp, cur, tr, H, W]() {
             Run& r = *rp;
-            RUN(r, launch_class_bias_bwd(cur->g, tr->labels, tr->cfg.num_classes, r.GP(tr->class_embed), r.B, H * W, tr->cfg.dim, r.s));
+            RUN(r, launch_class_bias_bwd(cur->g, cur->adt, tr->labels, tr->cfg.num_classes, r.GP(tr->class_embed), r.B, H * W, tr->cfg.dim,
+                                         r.s));
         });
     }
     std::vector<Ten*> skips;
@@ -714,10 +729,10 @@ int run_step(DmnTrainer* tr, const float* params, float* grads, const StepIO& io
     // loss and its gradient
     float* loss_dev = dry ? nullptr : io.loss;
     int acc;
-    float* dout = r.G(out, &acc);
+    void* dout = r.G(out, &acc);
     if (!dry) DMN_HIP_CHECK(hipMemsetAsync(loss_dev, 0, 4, s));
-    RUN(r, launch_loss(out->p, tgt->p, (long long)r.numel(out), tr->loss_kind, loss_dev, dout, s));
-    if (io.model_out) RUN(r, launch_nhwc_to_nchw(out->p, io.model_out, B, c.out_dim, H * W, s));
+    RUN(r, launch_loss(out->p, (const float*)tgt->p, out->adt, (long long)r.numel(out), tr->loss_kind, loss_dev, dout, s));
+    if (io.model_out) RUN(r, launch_nhwc_to_nchw(out->p, out->adt, io.model_out, B, c.out_dim, H * W, s));
 
     for (size_t i = r.tape.size(); i-- > 0;) r.tape[i]();
     RUN(r, launch_unpack_grads(tr->descs_dev, (int)tr->descs.size(), tr->max_numel, r.dwf, grads, s));
@@ -743,6 +758,7 @@ extern "C" int dmn_train_create(const DmnUnetCfg* cfg, int loss_kind, DmnTrainer
     DMN_REQUIRE(cfg->groups >= 1 && cfg->groups <= 64 && cfg->dim % cfg->groups == 0 && (cfg->dim / cfg->groups) % 4 == 0,
                 DMN_ERR_INVALID, "groups=%d", cfg->groups);
     DMN_REQUIRE(loss_kind >= 0 && loss_kind <= 2, DMN_ERR_INVALID, "loss_kind=%d", loss_kind);
+    DMN_REQUIRE(cfg->dtype >= 0 && cfg->dtype <= 2, DMN_ERR_INVALID, "dtype=%d", cfg->dtype);
     int maxc = cfg->dim;
     for (int i = 0; i < cfg->n_mults; ++i) {
         DMN_REQUIRE(cfg->dim_mults[i] >= 1, DMN_ERR_INVALID, "dim_mults[%d]", i);

@@ -9,20 +9,23 @@
 // tmode 0 gathers like a convolution (iy = oy*stride - pad + ky), tmode 1 like a transposed convolution
 // (iy = (oy + pad - ky) / stride where divisible). The first serves Conv2d forward and ConvTranspose2d input
 // gradients, the second ConvTranspose2d forward and Conv2d input gradients; linear layers are 1x1 on 1x1 images.
+// Activation tensors (and their gradients) are float32 (adt 0) or bfloat16 (adt 1: bf16 storage implies bf16 matrix-core
+// operands); parameters, parameter gradients, statistics and the time path's small tensors may differ per call.
 struct PGemmArgs {
-    const float* in;
+    const void* in;
     int ldin, Cin;          // floats per input pixel row; channels consumed (from the row's start)
     int B, Hi, Wi, Ho, Wo;
     int kh, kw, stride, pad, tmode;
     const float* w;         // [kh*kw*Cin][ldw]
     int ldw;
     const float* bias;      // [N] or null
-    float* out;
+    void* out;
     int ldout, N;
     int accumulate;
     int bf16;               // 1: operands rounded to bf16 for the matrix cores (fp32 accumulate)
     float* stats;           // optional [B][statsG][2], zeroed: += {sum, sum of squares} of the output per GroupNorm group
     int statsG;
+    int adt;                // type of in / out
 };
 int launch_pgemm(const PGemmArgs& a, hipStream_t s);
 // whether launch_pgemm can produce `stats` for these shapes (64-pixel tiles must not straddle images)
@@ -30,38 +33,37 @@ int pgemm_stats_supported(const PGemmArgs& a);
 
 // Weight gradient: dw[(tap*Cin + c)][n] += sum_m gather(x, m, tap)[c] * dy[m][n]   (atomic over pixel splits)
 struct WGemmArgs {
-    const float* x;
+    const void* x;
     int ldx, Cin;
     int B, Hi, Wi, Ho, Wo;
     int kh, kw, stride, pad, tmode;
-    const float* dy;
+    const void* dy;
     int lddy, N;
     float* dw;
     int lddw;
     int bf16;
     float* dbias;           // optional [N]: += column sums of dy (the bias gradient), taken from the staged tiles
+    int adt;                // type of x / dy
 };
 int launch_wgemm(const WGemmArgs& a, hipStream_t s);
 
-// out[c] += sum over rows of in[row][c]   (atomic)
-int launch_colsum(const float* in, int ld, long long rows, int C, float* out, hipStream_t s);
-
 // GroupNorm over NHWC: stats[b][g] = {sum, sum of squares} (atomic into zeroed memory)
-int launch_gn_stats(const float* x, int B, int HW, int C, int G, float* stats, hipStream_t s);
-// y = act(gn(x) * gamma + beta) + tb[b][c]   (act: 0 none, 1 SiLU; tb optional with row stride tb_ld)
+int launch_gn_stats(const void* x, int adt, int B, int HW, int C, int G, float* stats, hipStream_t s);
+// y = act(gn(x) * gamma + beta) + tb[b][c] + res   (act: 0 none, 1 SiLU; tb optional with row stride tb_ld)
 struct GnArgs {
-    const float* x;
+    const void* x;
     const float* stats;
     const float *gamma, *beta;
     const float* tb;
     int tb_ld;
-    const float* res;       // optional residual added after the activation (same shape as y)
-    float* y;
+    const void* res;        // optional residual added after the activation (same shape as y)
+    void* y;
     float* ystats;          // optional [B][2], zeroed: += {sum, sum of squares} of y per image (a following GroupNorm(1))
     int B, HW, C, G, act;
+    int adt;                // type of x, res, y, dy, dx
     // backward
-    const float* dy;
-    float* dx;
+    const void* dy;
+    void* dx;
     int accumulate;
     float* sums;            // [B][C][3] zeroed: sum dz*xhat, sum dz, sum dy
     float *dgamma, *dbeta;  // [C] accumulated atomically
@@ -71,45 +73,46 @@ struct GnArgs {
 int launch_gn_apply(const GnArgs& a, hipStream_t s);
 int launch_gn_bwd(const GnArgs& a, hipStream_t s);
 
-// elementwise helpers
-int launch_axpby(float* dst, const float* src, long long n, int accumulate, hipStream_t s);      // dst (+)= src
-int launch_add(float* out, const float* a, const float* b, long long n, hipStream_t s);         // out = a + b
+// elementwise helpers (element counts and widths are multiples of 4)
+int launch_axpby(void* dst, const void* src, int adt, long long n, int accumulate, hipStream_t s);      // dst (+)= src
+int launch_add(void* out, const void* a, const void* b, int adt, long long n, hipStream_t s);          // out = a + b
 // dst[row][doff + c] (+)= src[row][soff + c], c < C
-int launch_copy_slice(float* dst, int ldd, int doff, const float* src, int lds, int soff, int C, long long rows,
+int launch_copy_slice(void* dst, int ldd, int doff, const void* src, int lds, int soff, int C, long long rows, int adt,
                       int accumulate, hipStream_t s);
 // act: 0 SiLU, 1 exact GELU. Forward y = act(x); backward dx (+)= dy * act'(x).
-int launch_act_fwd(const float* x, float* y, long long n, int act, hipStream_t s);
-int launch_act_bwd(const float* x, const float* dy, float* dx, long long n, int act, int accumulate, hipStream_t s);
+int launch_act_fwd(const void* x, void* y, int adt, long long n, int act, hipStream_t s);
+int launch_act_bwd(const void* x, const void* dy, void* dx, int adt, long long n, int act, int accumulate, hipStream_t s);
 // Class conditioning (modules/unet.py:134-141): x[b][p][c] += table[label_b][c] in place (labels null: every image takes
 // row `pad`, the "no class" row); backward: dtable[label_b][c] += sum_p dy[b][p][c] except for row `pad`
 // (nn.Embedding's padding_idx keeps that row's gradient at zero).
-int launch_class_bias_fwd(float* x, const float* table, const long long* labels, int pad, int B, int HW, int C, hipStream_t s);
-int launch_class_bias_bwd(const float* dy, const long long* labels, int pad, float* dtable, int B, int HW, int C, hipStream_t s);
+int launch_class_bias_fwd(void* x, int adt, const float* table, const long long* labels, int pad, int B, int HW, int C, hipStream_t s);
+int launch_class_bias_bwd(const void* dy, int adt, const long long* labels, int pad, float* dtable, int B, int HW, int C, hipStream_t s);
 // Sinusoidal embedding of integer or float labels: out[b][dim]
 int launch_sinus(const void* t, int t_is_float, int B, int dim, float* out, hipStream_t s);
 
-// x_t = a[t_b] x0 + b[t_b] eps (a, b null: x_t = x0) from NCHW to NHWC, and eps to NHWC as the target.
-int launch_train_ingest(const float* x0, const float* eps, const long long* t, const float* sa, const float* sb, float* xt,
+// x_t = a[t_b] x0 + b[t_b] eps (a, b null: x_t = x0) from NCHW float32 to NHWC in the activation type, and eps to NHWC
+// float32 as the target.
+int launch_train_ingest(const float* x0, const float* eps, const long long* t, const float* sa, const float* sb, void* xt, int adt,
                         float* tgt, int B, int C, int H, int W, hipStream_t s);
 // loss (+= into a zeroed scalar) of DiffusionLoss with reduction 'mean' (loss/simple_loss.py:37-45): kind 0 l1,
 // 1 l2, 2 huber (smooth_l1, beta 1); dout = d loss / d out. out, tgt, dout: [n] in the same (NHWC) order.
-int launch_loss(const float* out, const float* tgt, long long n, int kind, float* loss, float* dout, hipStream_t s);
-// NHWC [B][HW][C] -> NCHW [B][C][HW]
-int launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, hipStream_t s);
+int launch_loss(const void* out, const float* tgt, int adt, long long n, int kind, float* loss, void* dout, hipStream_t s);
+// NHWC [B][HW][C] -> NCHW float32 [B][C][HW]
+int launch_nhwc_to_nchw(const void* in, int adt, float* out, int B, int C, int HW, hipStream_t s);
 
 // LinearAttention core on qkv [B][n][3*heads*32] (parts/mha.py:48-56): out [B][n][heads*32]. The pixels of an image
 // are split over linattn_train_splits() workgroups. ctx [B][heads][32][32] (unnormalised k^T v) and kstat
 // [B][heads][2][32] (max, sum of exp) must be ZEROED by the caller and are kept for the backward; pmax
 // [B][heads][splits][32] is scratch; dctx [B][heads][32][32] must be zeroed.
-int linattn_train_splits(int B, int n, int heads);
 // bf16: the per-pixel 32x32 products take bfloat16 operands (fp32 accumulate) instead of exact fp32.
-int launch_linattn_train_fwd(const float* qkv, float* out, float* ctx, float* kstat, float* pmax, int B, int n, int heads,
+int linattn_train_splits(int B, int n, int heads);
+int launch_linattn_train_fwd(const void* qkv, void* out, int adt, float* ctx, float* kstat, float* pmax, int B, int n, int heads,
                              int bf16, hipStream_t s);
-int launch_linattn_train_bwd(const float* qkv, const float* dout, const float* ctx, const float* kstat, float* dctx, float* dqkv,
+int launch_linattn_train_bwd(const void* qkv, const void* dout, int adt, const float* ctx, const float* kstat, float* dctx, void* dqkv,
                              int B, int n, int heads, int bf16, hipStream_t s);
-// Attention core (parts/mha.py:20-29): out [B][n][heads*32]; lse [B][heads][n] saved for the backward.
-int launch_attn_train_fwd(const float* qkv, float* out, float* lse, int B, int n, int heads, hipStream_t s);
-int launch_attn_train_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int B, int n,
+// Attention core (parts/mha.py:20-29): out [B][n][heads*32]; lse [B][heads][2][n] (log-sum-exp, then scratch).
+int launch_attn_train_fwd(const void* qkv, void* out, int adt, float* lse, int B, int n, int heads, hipStream_t s);
+int launch_attn_train_bwd(const void* qkv, const void* out, const void* dout, int adt, const float* lse, void* dqkv, int B, int n,
                           int heads, hipStream_t s);
 
 // Layout changes between the reference's parameter layout and the GEMM layout, for all tensors in one launch.

@@ -7,6 +7,7 @@
 
 #include "dmn_common.h"
 #include "dmn_train.h"
+#include "dmn_train_io.h"
 
 namespace {
 
@@ -99,8 +100,10 @@ __device__ __forceinline__ void tile_stats(const float (&s1)[BN / 16], const flo
     }
 }
 
-template <int BN, bool SLOW, bool BF>
+template <typename T, int BN, bool SLOW, bool BF>
 __global__ __launch_bounds__(256) void pgemm_kernel(const PGemmArgs a, const int M, const int pm) {
+    const T* in = reinterpret_cast<const T*>(a.in);
+    T* out = reinterpret_cast<T*>(a.out);
     constexpr int LDB = BN + 4, NJ = BN / 16, TPR = BN / 4, RPP = 256 / TPR, NB = 32 / RPP;
     __shared__ float Bs[32 * LDB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
@@ -138,9 +141,9 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const PGemmArgs a, const int
             const bool okx = src_coord(pox, kx, a.stride, a.pad, a.tmode, a.Wi, ix);
             an0 = an1 = f32x4{0.f, 0.f, 0.f, 0.f};
             if (mvalid & oky & okx) {
-                const float* p = a.in + ((size_t)(pb * a.Hi + iy) * a.Wi + ix) * a.ldin + cc * 32 + 4 * q;
-                an0 = *reinterpret_cast<const f32x4*>(p);
-                an1 = *reinterpret_cast<const f32x4*>(p + 16);
+                const T* p = in + ((size_t)(pb * a.Hi + iy) * a.Wi + ix) * a.ldin + cc * 32 + 4 * q;
+                an0 = Io<T>::ld4(p);
+                an1 = Io<T>::ld4(p + 16);
             }
             krow0 = (ky * a.kw + kx) * a.Cin + cc * 32;
         } else {
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const PGemmArgs a, const int
                         int iy = 0, ix = 0;
                         if (src_coord(poy, ky, a.stride, a.pad, a.tmode, a.Hi, iy) &&
                             src_coord(pox, kx, a.stride, a.pad, a.tmode, a.Wi, ix))
-                            v = a.in[((size_t)(pb * a.Hi + iy) * a.Wi + ix) * a.ldin + ci];
+                            v = Io<T>::ld(in + ((size_t)(pb * a.Hi + iy) * a.Wi + ix) * a.ldin + ci);
                     }
                     if (c == 0) an0[s] = v; else an1[s] = v;
                 }
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const PGemmArgs a, const int
             decode_m(m, a.Ho, a.Wo, pm, b, oy, ox);
             pl = (size_t)(b * a.Ho + oy) * a.Wo + ox;
         }
-        float* o = a.out + pl * a.ldout;
+        T* o = out + pl * a.ldout;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int n = n0 + 16 * j + r;
@@ -236,8 +239,8 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const PGemmArgs a, const int
                 if (a.bias) v += a.bias[n];
                 s1[j] += v;
                 s2[j] += v * v;
-                if (a.accumulate) v += o[n];
-                o[n] = v;
+                if (a.accumulate) v += Io<T>::ld(o + n);
+                Io<T>::st(o + n, v);
             }
         }
     }
@@ -247,10 +250,14 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const PGemmArgs a, const int
 // 3x3, stride 1, pad 1 (forward of the ResnetBlock convolutions and, with the taps mirrored, their input gradient):
 // one workgroup = 8x8 output pixels. For every 32-channel chunk the 10x10 halo of the tile is staged in LDS once and
 // all nine taps read their A operand from it (1.56 x the input instead of 9 x through L2); weights as in pgemm_kernel.
-template <int BN, bool BF>
+template <typename T, int BN, bool BF>
 __global__ __launch_bounds__(256) void pgemm_halo_kernel(const PGemmArgs a) {
+    const T* in = reinterpret_cast<const T*>(a.in);
+    T* out = reinterpret_cast<T*>(a.out);
     constexpr int LDB = BN + 4, NJ = BN / 16, TPR = BN / 4, RPP = 256 / TPR, NB = 32 / RPP, LDH = 36;
-    __shared__ float Bs[32 * LDB];
+    // one stage = the three taps of a kernel row for 32 channels: three weight tiles in flight per round trip, a third of
+    // the barriers, and the next chunk's halo rides along with the last row of the current one
+    __shared__ float Bs[3 * 32 * LDB];
     __shared__ float Hs[100 * LDH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
     const int tw = a.Wo >> 3, th = a.Ho >> 3;
@@ -258,81 +265,98 @@ __global__ __launch_bounds__(256) void pgemm_halo_kernel(const PGemmArgs a) {
     const int oy0 = (trem / tw) * 8, ox0 = (trem % tw) * 8;
     const int n0 = blockIdx.y * BN;
     const int pA = 16 * wave + r, py = pA >> 3, px = pA & 7;
-    const int nch = a.Cin >> 5, nstage = nch * 9;
+    const int nch = a.Cin >> 5, nstage = nch * 3;
     const bool wvec = ((reinterpret_cast<uintptr_t>(a.w) & 15) == 0) && ((a.ldw & 3) == 0);
 
     f32x4 acc[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 bn[NB];
+    f32x4 bn[3 * NB], hr[4];
 
     auto load_b = [&](int it) {
-        const int cc = it / 9, tap = it - cc * 9;
-        const int krow0 = tap * a.Cin + cc * 32;
+        const int cc = it / 3, ky = it - cc * 3;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int row = tid / TPR + i * RPP, n = n0 + (tid % TPR) * 4;
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            const float* p = a.w + (size_t)(krow0 + row) * a.ldw + n;
-            if (wvec && n + 3 < a.N) {
-                v = *reinterpret_cast<const f32x4*>(p);
-            } else {
+        for (int kx = 0; kx < 3; ++kx) {
+            const int krow0 = (ky * 3 + kx) * a.Cin + cc * 32;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (n + e < a.N) v[e] = p[e];
+            for (int i = 0; i < NB; ++i) {
+                const int row = tid / TPR + i * RPP, n = n0 + (tid % TPR) * 4;
+                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                const float* p = a.w + (size_t)(krow0 + row) * a.ldw + n;
+                if (wvec && n + 3 < a.N) {
+                    v = *reinterpret_cast<const f32x4*>(p);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < a.N) v[e] = p[e];
+                }
+                bn[kx * NB + i] = v;
             }
-            bn[i] = v;
         }
     };
     auto load_halo = [&](int cc) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = tid + 256 * i;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
             if (idx < 800) {
                 const int pix = idx >> 3, c4 = (idx & 7) * 4;
                 const int hy = pix / 10, hx = pix - hy * 10;
                 const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi)
-                    v = *reinterpret_cast<const f32x4*>(a.in + ((size_t)(b * a.Hi + iy) * a.Wi + ix) * a.ldin + cc * 32 + c4);
-                *reinterpret_cast<f32x4*>(&Hs[pix * LDH + c4]) = v;
+                    v = Io<T>::ld4(in + ((size_t)(b * a.Hi + iy) * a.Wi + ix) * a.ldin + cc * 32 + c4);
             }
+            hr[i] = v;
         }
     };
 
+    load_halo(0);
     load_b(0);
     for (int it = 0; it < nstage; ++it) {
-        const int cc = it / 9, tap = it - cc * 9;
-        if (tap == 0) load_halo(cc);   // the previous chunk's last reads ended at the barrier that closed its stage
+        const int cc = it / 3, ky = it - cc * 3;
+        if (ky == 0) {   // the previous chunk's last reads ended at the barrier that closed its stage
 #pragma unroll
-        for (int i = 0; i < NB; ++i)
-            *reinterpret_cast<f32x4*>(&Bs[(tid / TPR + i * RPP) * LDB + (tid % TPR) * 4]) = bn[i];
+            for (int i = 0; i < 4; ++i) {
+                const int idx = tid + 256 * i;
+                if (idx < 800) *reinterpret_cast<f32x4*>(&Hs[(idx >> 3) * LDH + (idx & 7) * 4]) = hr[i];
+            }
+        }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+                *reinterpret_cast<f32x4*>(&Bs[kx * 32 * LDB + (tid / TPR + i * RPP) * LDB + (tid % TPR) * 4]) = bn[kx * NB + i];
         __syncthreads();
         if (it + 1 < nstage) load_b(it + 1);
-        const int ky = tap / 3, kx = tap - ky * 3;
-        const int hy = py + (a.tmode ? 2 - ky : ky), hx = px + (a.tmode ? 2 - kx : kx);
-        const float* hp = &Hs[(hy * 10 + hx) * LDH + 4 * q];
-        const f32x4 ac0 = *reinterpret_cast<const f32x4*>(hp), ac1 = *reinterpret_cast<const f32x4*>(hp + 16);
-        if constexpr (BF) {
-            const float af[8] = {ac0[0], ac0[1], ac0[2], ac0[3], ac1[0], ac1[1], ac1[2], ac1[3]};
-            const bf16x8 a8 = pack_bf16(af);
+        if (ky == 2 && cc + 1 < nch) load_halo(cc + 1);
+        const int hy = py + (a.tmode ? 2 - ky : ky);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                float bf[8];
+        for (int kx = 0; kx < 3; ++kx) {
+            const int hx = px + (a.tmode ? 2 - kx : kx);
+            const float* hp = &Hs[(hy * 10 + hx) * LDH + 4 * q];
+            const f32x4 ac0 = *reinterpret_cast<const f32x4*>(hp), ac1 = *reinterpret_cast<const f32x4*>(hp + 16);
+            const float* Bt = &Bs[kx * 32 * LDB];
+            if constexpr (BF) {
+                const float af[8] = {ac0[0], ac0[1], ac0[2], ac0[3], ac1[0], ac1[1], ac1[2], ac1[3]};
+                const bf16x8 a8 = pack_bf16(af);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) bf[i] = Bs[(16 * (i >> 2) + 4 * q + (i & 3)) * LDB + r + 16 * j];
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, pack_bf16(bf), acc[j], 0, 0, 0);
-            }
-        } else {
+                for (int j = 0; j < NJ; ++j) {
+                    float bf[8];
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const float av = c == 0 ? ac0[s] : ac1[s];
-                    const float* brow = &Bs[(16 * c + 4 * q + s) * LDB + r];
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, brow[16 * j], acc[j], 0, 0, 0);
+                    for (int i = 0; i < 8; ++i) bf[i] = Bt[(16 * (i >> 2) + 4 * q + (i & 3)) * LDB + r + 16 * j];
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, pack_bf16(bf), acc[j], 0, 0, 0);
                 }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const float av = c == 0 ? ac0[s] : ac1[s];
+                        const float* brow = &Bt[(16 * c + 4 * q + s) * LDB + r];
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, brow[16 * j], acc[j], 0, 0, 0);
+                    }
+            }
         }
         __syncthreads();
     }
@@ -342,7 +366,7 @@ __global__ __launch_bounds__(256) void pgemm_halo_kernel(const PGemmArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int pO = 16 * wave + 4 * q + i;
-        float* o = a.out + ((size_t)(b * a.Ho + oy0 + (pO >> 3)) * a.Wo + ox0 + (pO & 7)) * a.ldout;
+        T* o = out + ((size_t)(b * a.Ho + oy0 + (pO >> 3)) * a.Wo + ox0 + (pO & 7)) * a.ldout;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int n = n0 + 16 * j + r;
@@ -351,8 +375,8 @@ __global__ __launch_bounds__(256) void pgemm_halo_kernel(const PGemmArgs a) {
                 if (a.bias) v += a.bias[n];
                 s1[j] += v;
                 s2[j] += v * v;
-                if (a.accumulate) v += o[n];
-                o[n] = v;
+                if (a.accumulate) v += Io<T>::ld(o + n);
+                Io<T>::st(o + n, v);
             }
         }
     }
@@ -362,8 +386,10 @@ __global__ __launch_bounds__(256) void pgemm_halo_kernel(const PGemmArgs a) {
 // Weight gradient tile TM (weight rows = (tap, cin)) x TN (cout) per workgroup, reduced over a contiguous range of
 // output pixels; 32 pixels per stage staged through LDS pixel-major for both operands (the MFMA's k index is the
 // pixel). Partial sums of the pixel splits meet in dw through hardware float atomics.
-template <int TM, int TN, bool SLOW, bool BF>
+template <typename T, int TM, int TN, bool SLOW, bool BF>
 __global__ __launch_bounds__(256) void wgemm_kernel(const WGemmArgs a, const int M, const int chunk) {
+    const T* x = reinterpret_cast<const T*>(a.x);
+    const T* dy = reinterpret_cast<const T*>(a.dy);
     constexpr int LDX = TM + 16, LDY = TN + 16, NI = TM / 32, NJ = TN / 32;
     constexpr int TPX = TM / 4, PPX = 256 / TPX, NX = 32 / PPX;   // threads per pixel row, pixels per pass, passes
     constexpr int TPY = TN / 4, PPY = 256 / TPY, NY = 32 / PPY;
@@ -403,7 +429,7 @@ __global__ __launch_bounds__(256) void wgemm_kernel(const WGemmArgs a, const int
                 if constexpr (!SLOW) {
                     int iy = 0, ix = 0;
                     if (src_coord(oy, tky, a.stride, a.pad, a.tmode, a.Hi, iy) && src_coord(ox, tkx, a.stride, a.pad, a.tmode, a.Wi, ix))
-                        v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(b * a.Hi + iy) * a.Wi + ix) * a.ldx + ci0 + c4);
+                        v = Io<T>::ld4(x + ((size_t)(b * a.Hi + iy) * a.Wi + ix) * a.ldx + ci0 + c4);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -413,7 +439,7 @@ __global__ __launch_bounds__(256) void wgemm_kernel(const WGemmArgs a, const int
                             const int ky = tap / a.kw, kx = tap - ky * a.kw;
                             int iy = 0, ix = 0;
                             if (src_coord(oy, ky, a.stride, a.pad, a.tmode, a.Hi, iy) && src_coord(ox, kx, a.stride, a.pad, a.tmode, a.Wi, ix))
-                                v[e] = a.x[((size_t)(b * a.Hi + iy) * a.Wi + ix) * a.ldx + ci];
+                                v[e] = Io<T>::ld(x + ((size_t)(b * a.Hi + iy) * a.Wi + ix) * a.ldx + ci);
                         }
                     }
                 }
@@ -425,13 +451,13 @@ __global__ __launch_bounds__(256) void wgemm_kernel(const WGemmArgs a, const int
             const int m = mb + tid / TPY + i * PPY, n = n0 + (tid % TPY) * 4;
             f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
             if (m < me) {
-                const float* p = a.dy + (size_t)m * a.lddy + n;
+                const T* p = dy + (size_t)m * a.lddy + n;
                 if (yvec && n + 3 < a.N) {
-                    v = *reinterpret_cast<const f32x4*>(p);
+                    v = Io<T>::ld4(p);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (n + e < a.N) v[e] = p[e];
+                        if (n + e < a.N) v[e] = Io<T>::ld(p + e);
                 }
             }
             yn[i] = v;
@@ -507,8 +533,10 @@ __global__ __launch_bounds__(256) void wgemm_kernel(const WGemmArgs a, const int
 // per 8x8 pixel tile the 10x10 halo of x and the tile of dy are staged once and every tap takes its A operand from the
 // halo at its own offset (the per-tap kernel above reads both tensors nine times). Wave w owns the 16x16 block
 // (w >> 1, w & 1) of every tap: nine accumulators.
-template <bool BF>
+template <typename T, bool BF>
 __global__ __launch_bounds__(256) void wgemm_halo_kernel(const WGemmArgs a, const int tiles, const int per) {
+    const T* x = reinterpret_cast<const T*>(a.x);
+    const T* dy = reinterpret_cast<const T*>(a.dy);
     constexpr int LDX = 48, LDY = 48;
     __shared__ float Xs[100 * LDX], Ys[64 * LDY];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
@@ -535,7 +563,7 @@ __global__ __launch_bounds__(256) void wgemm_halo_kernel(const WGemmArgs a, cons
                 const int hy = pix / 10, hx = pix - hy * 10;
                 const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
                 if (iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi)
-                    v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(b * a.Hi + iy) * a.Wi + ix) * a.ldx + ci0 + c4);
+                    v = Io<T>::ld4(x + ((size_t)(b * a.Hi + iy) * a.Wi + ix) * a.ldx + ci0 + c4);
             }
             xr[i] = v;
         }
@@ -544,13 +572,13 @@ __global__ __launch_bounds__(256) void wgemm_halo_kernel(const WGemmArgs a, cons
             const int idx = tid + 256 * i, pix = idx >> 3, c4 = (idx & 7) * 4;
             const int n = n0 + c4;
             f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            const float* p = a.dy + ((size_t)(b * a.Ho + oy0 + (pix >> 3)) * a.Wo + ox0 + (pix & 7)) * a.lddy + n;
+            const T* p = dy + ((size_t)(b * a.Ho + oy0 + (pix >> 3)) * a.Wo + ox0 + (pix & 7)) * a.lddy + n;
             if (n + 3 < a.N) {
-                v = *reinterpret_cast<const f32x4*>(p);
+                v = Io<T>::ld4(p);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (n + e < a.N) v[e] = p[e];
+                    if (n + e < a.N) v[e] = Io<T>::ld(p + e);
             }
             yr[i] = v;
         }
@@ -630,14 +658,18 @@ __global__ __launch_bounds__(256) void wgemm_halo_kernel(const WGemmArgs a, cons
         }                                                                         \
     } while (0)
 
-template <bool BF> static void pgemm_dispatch(const PGemmArgs& a, int M, int pm, bool slow, int bn, dim3 grid, hipStream_t s) {
+template <typename T, bool BF> static void pgemm_dispatch(const PGemmArgs& a, int M, int pm, bool slow, int bn, dim3 grid, hipStream_t s) {
     if (bn == 64) {
-        if (slow) pgemm_kernel<64, true, BF><<<grid, 256, 0, s>>>(a, M, pm);
-        else pgemm_kernel<64, false, BF><<<grid, 256, 0, s>>>(a, M, pm);
+        if (slow) pgemm_kernel<T, 64, true, BF><<<grid, 256, 0, s>>>(a, M, pm);
+        else pgemm_kernel<T, 64, false, BF><<<grid, 256, 0, s>>>(a, M, pm);
     } else {
-        if (slow) pgemm_kernel<32, true, BF><<<grid, 256, 0, s>>>(a, M, pm);
-        else pgemm_kernel<32, false, BF><<<grid, 256, 0, s>>>(a, M, pm);
+        if (slow) pgemm_kernel<T, 32, true, BF><<<grid, 256, 0, s>>>(a, M, pm);
+        else pgemm_kernel<T, 32, false, BF><<<grid, 256, 0, s>>>(a, M, pm);
     }
+}
+template <typename T, bool BF> static void pgemm_halo_dispatch(const PGemmArgs& a, int bn, dim3 grid, hipStream_t s) {
+    if (bn == 64) pgemm_halo_kernel<T, 64, BF><<<grid, 256, 0, s>>>(a);
+    else pgemm_halo_kernel<T, 32, BF><<<grid, 256, 0, s>>>(a);
 }
 
 int pgemm_stats_supported(const PGemmArgs& a) {
@@ -659,33 +691,30 @@ int launch_pgemm(const PGemmArgs& a, hipStream_t s) {
     if (!slow && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && (a.Ho & 7) == 0 && (a.Wo & 7) == 0 && a.Hi == a.Ho &&
         a.Wi == a.Wo) {
         dim3 hgrid(a.B * (a.Ho >> 3) * (a.Wo >> 3), (a.N + bn - 1) / bn);
-        if (bn == 64) {
-            if (a.bf16) pgemm_halo_kernel<64, true><<<hgrid, 256, 0, s>>>(a);
-            else pgemm_halo_kernel<64, false><<<hgrid, 256, 0, s>>>(a);
-        } else {
-            if (a.bf16) pgemm_halo_kernel<32, true><<<hgrid, 256, 0, s>>>(a);
-            else pgemm_halo_kernel<32, false><<<hgrid, 256, 0, s>>>(a);
-        }
+        if (a.adt == 1) pgemm_halo_dispatch<__bf16, true>(a, bn, hgrid, s);
+        else if (a.bf16) pgemm_halo_dispatch<float, true>(a, bn, hgrid, s);
+        else pgemm_halo_dispatch<float, false>(a, bn, hgrid, s);
         DMN_LAUNCH_CHECK();
         return DMN_OK;
     }
     dim3 grid((M + 63) / 64, (a.N + bn - 1) / bn);
-    if (a.bf16) pgemm_dispatch<true>(a, M, pm, slow, bn, grid, s);
-    else pgemm_dispatch<false>(a, M, pm, slow, bn, grid, s);
+    if (a.adt == 1) pgemm_dispatch<__bf16, true>(a, M, pm, slow, bn, grid, s);
+    else if (a.bf16) pgemm_dispatch<float, true>(a, M, pm, slow, bn, grid, s);
+    else pgemm_dispatch<float, false>(a, M, pm, slow, bn, grid, s);
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }
 
-template <bool BF> static void wgemm_dispatch(const WGemmArgs& a, int M, int chunk, bool slow, int tm, int tn, dim3 grid, hipStream_t s) {
+template <typename T, bool BF> static void wgemm_dispatch(const WGemmArgs& a, int M, int chunk, bool slow, int tm, int tn, dim3 grid, hipStream_t s) {
     if (slow) {
-        if (tn == 64) wgemm_kernel<32, 64, true, BF><<<grid, 256, 0, s>>>(a, M, chunk);
-        else wgemm_kernel<32, 32, true, BF><<<grid, 256, 0, s>>>(a, M, chunk);
+        if (tn == 64) wgemm_kernel<T, 32, 64, true, BF><<<grid, 256, 0, s>>>(a, M, chunk);
+        else wgemm_kernel<T, 32, 32, true, BF><<<grid, 256, 0, s>>>(a, M, chunk);
     } else if (tm == 64) {
-        if (tn == 64) wgemm_kernel<64, 64, false, BF><<<grid, 256, 0, s>>>(a, M, chunk);
-        else wgemm_kernel<64, 32, false, BF><<<grid, 256, 0, s>>>(a, M, chunk);
+        if (tn == 64) wgemm_kernel<T, 64, 64, false, BF><<<grid, 256, 0, s>>>(a, M, chunk);
+        else wgemm_kernel<T, 64, 32, false, BF><<<grid, 256, 0, s>>>(a, M, chunk);
     } else {
-        if (tn == 64) wgemm_kernel<32, 64, false, BF><<<grid, 256, 0, s>>>(a, M, chunk);
-        else wgemm_kernel<32, 32, false, BF><<<grid, 256, 0, s>>>(a, M, chunk);
+        if (tn == 64) wgemm_kernel<T, 32, 64, false, BF><<<grid, 256, 0, s>>>(a, M, chunk);
+        else wgemm_kernel<T, 32, 32, false, BF><<<grid, 256, 0, s>>>(a, M, chunk);
     }
 }
 
@@ -718,8 +747,9 @@ int launch_wgemm(const WGemmArgs& a, hipStream_t s) {
         const int per = (tiles + ns - 1) / ns;
         ns = (tiles + per - 1) / per;
         DMN_REQUIRE(cit <= 65535 && cot <= 65535, DMN_ERR_LIMIT, "wgemm: grid %d x %d", cit, cot);
-        if (a.bf16) wgemm_halo_kernel<true><<<dim3(ns, cit, cot), 256, 0, s>>>(a, tiles, per);
-        else wgemm_halo_kernel<false><<<dim3(ns, cit, cot), 256, 0, s>>>(a, tiles, per);
+        if (a.adt == 1) wgemm_halo_kernel<__bf16, true><<<dim3(ns, cit, cot), 256, 0, s>>>(a, tiles, per);
+        else if (a.bf16) wgemm_halo_kernel<float, true><<<dim3(ns, cit, cot), 256, 0, s>>>(a, tiles, per);
+        else wgemm_halo_kernel<float, false><<<dim3(ns, cit, cot), 256, 0, s>>>(a, tiles, per);
         DMN_LAUNCH_CHECK();
         return DMN_OK;
     }
@@ -734,8 +764,9 @@ int launch_wgemm(const WGemmArgs& a, hipStream_t s) {
     nsplit = (M + chunk - 1) / chunk;
     dim3 grid(nsplit, rt, ct);
     DMN_REQUIRE(rt <= 65535 && ct <= 65535, DMN_ERR_LIMIT, "wgemm: grid %d x %d", rt, ct);
-    if (a.bf16) wgemm_dispatch<true>(a, M, chunk, slow, tm, tn, grid, s);
-    else wgemm_dispatch<false>(a, M, chunk, slow, tm, tn, grid, s);
+    if (a.adt == 1) wgemm_dispatch<__bf16, true>(a, M, chunk, slow, tm, tn, grid, s);
+    else if (a.bf16) wgemm_dispatch<float, true>(a, M, chunk, slow, tm, tn, grid, s);
+    else wgemm_dispatch<float, false>(a, M, chunk, slow, tm, tn, grid, s);
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }

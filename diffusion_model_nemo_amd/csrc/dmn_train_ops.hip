@@ -5,6 +5,7 @@
 // q_sample (modules/gaussian_diffusion.py:104-116).
 #include "dmn_common.h"
 #include "dmn_train.h"
+#include "dmn_train_io.h"
 
 #define DMN_LAUNCH_CHECK()                                                        \
     do {                                                                          \
@@ -38,37 +39,19 @@ __device__ __forceinline__ float gelu_grad(float x) {
     return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
 }
 
-// ---- column sums --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int ld, long long rows, int C, int cw,
-                                                     float* __restrict__ out) {
-    __shared__ float sh[256];
-    const int tid = threadIdx.x, nrl = 256 / cw;
-    const int cl = tid % cw, rl = tid / cw;
-    const int col = blockIdx.y * 256 + cl;
-    float acc = 0.f;
-    if (rl < nrl && col < C)
-        for (long long row = (long long)blockIdx.x * nrl + rl; row < rows; row += (long long)gridDim.x * nrl) acc += in[row * ld + col];
-    sh[tid] = acc;
-    __syncthreads();
-    if (rl == 0 && col < C) {
-        float t = 0.f;
-        for (int i = 0; i < nrl; ++i) t += sh[i * cw + cl];
-        unsafeAtomicAdd(out + col, t);
-    }
-}
-
 // ---- GroupNorm ----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, int HW, int C, int G, float* __restrict__ stats) {
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, int HW, int C, int G, float* __restrict__ stats) {
     __shared__ float sh[4];
     const int bg = blockIdx.x, b = bg / G, g = bg - b * G;
     const int cg4 = (C / G) >> 2;
     const long long total = (long long)HW * cg4;
-    const float* base = x + (size_t)b * HW * C + g * (C / G);
+    const T* base = x + (size_t)b * HW * C + g * (C / G);
     float s = 0.f, ss = 0.f;
     for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < total; i += (long long)gridDim.y * 256) {
         const long long p = i / cg4;
         const int c4 = (int)(i - p * cg4);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(base + p * C + 4 * c4);
+        const f32x4 v = Io<T>::ld4(base + p * C + 4 * c4);
         s += (v[0] + v[1]) + (v[2] + v[3]);
         ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
     }
@@ -88,7 +71,10 @@ __device__ __forceinline__ void gn_mean_rstd(const float* stats, int bg, float i
 }
 
 // grid (blocks, B): a workgroup stays inside one image, so the statistics of its output need one atomic pair
-__global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
+template <typename T> __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
+    const T* x = reinterpret_cast<const T*>(a.x);
+    const T* res = reinterpret_cast<const T*>(a.res);
+    T* y = reinterpret_cast<T*>(a.y);
     __shared__ float sh[4];
     const int c4n = a.C >> 2, b = blockIdx.y;
     const long long total = (long long)a.HW * c4n;
@@ -102,7 +88,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
         float mean, rstd;
         gn_mean_rstd(a.stats, b * a.G + c / Cg, inv_cnt, mean, rstd);
         const size_t off = img + pix * a.C + c;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + off);
+        const f32x4 v = Io<T>::ld4(x + off);
         const f32x4 ga = *reinterpret_cast<const f32x4*>(a.gamma + c), be = *reinterpret_cast<const f32x4*>(a.beta + c);
         f32x4 o;
 #pragma unroll
@@ -112,12 +98,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
             if (a.tb) z += a.tb[(size_t)b * a.tb_ld + c + e];
             o[e] = z;
         }
-        if (a.res) {
-            const f32x4 rv = *reinterpret_cast<const f32x4*>(a.res + off);
+        if (res) {
+            const f32x4 rv = Io<T>::ld4(res + off);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] += rv[e];
         }
-        *reinterpret_cast<f32x4*>(a.y + off) = o;
+        Io<T>::st4(y + off, o);
         s1 += (o[0] + o[1]) + (o[2] + o[3]);
         s2 += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
     }
@@ -132,7 +118,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
 }
 
 // per (image, channel): sum dz * xhat, sum dz, sum dy. grid (splits, B); thread = fixed 4 channels, strided pixels.
-__global__ __launch_bounds__(256) void gn_bwd_sums_kernel(const GnArgs a) {
+template <typename T> __global__ __launch_bounds__(256) void gn_bwd_sums_kernel(const GnArgs a) {
+    const T* x = reinterpret_cast<const T*>(a.x);
+    const T* dy = reinterpret_cast<const T*>(a.dy);
     __shared__ float sh[256 * 12];
     const int b = blockIdx.y, c4n = a.C >> 2, tid = threadIdx.x;
     const int c = 4 * (tid % c4n), pl = tid / c4n, npl = 256 / c4n;
@@ -144,8 +132,8 @@ __global__ __launch_bounds__(256) void gn_bwd_sums_kernel(const GnArgs a) {
     float s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     const size_t img = (size_t)b * a.HW * a.C;
     for (int p = blockIdx.x * npl + pl; p < a.HW; p += gridDim.x * npl) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + img + (size_t)p * a.C + c);
-        const f32x4 d = *reinterpret_cast<const f32x4*>(a.dy + img + (size_t)p * a.C + c);
+        const f32x4 v = Io<T>::ld4(x + img + (size_t)p * a.C + c);
+        const f32x4 d = Io<T>::ld4(dy + img + (size_t)p * a.C + c);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float xh = (v[e] - mean) * rstd;
@@ -173,7 +161,10 @@ __global__ __launch_bounds__(256) void gn_bwd_sums_kernel(const GnArgs a) {
     }
 }
 
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GnArgs a) {
+template <typename T> __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GnArgs a) {
+    const T* x = reinterpret_cast<const T*>(a.x);
+    const T* dy = reinterpret_cast<const T*>(a.dy);
+    T* dx = reinterpret_cast<T*>(a.dx);
     __shared__ float S1[64], S2[64];
     const int b = blockIdx.y, tid = threadIdx.x, Cg = a.C / a.G, c4n = a.C >> 2;
     if (tid < a.G) {
@@ -205,10 +196,10 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GnArgs a) {
         gn_mean_rstd(a.stats, b * a.G + g, inv_cnt, mean, rstd);
         const float m1 = S1[g] * inv_cnt, m2 = S2[g] * inv_cnt;
         const size_t off = img + (size_t)p * a.C + c;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + off), d = *reinterpret_cast<const f32x4*>(a.dy + off);
+        const f32x4 v = Io<T>::ld4(x + off), d = Io<T>::ld4(dy + off);
         const f32x4 ga = *reinterpret_cast<const f32x4*>(a.gamma + c), be = *reinterpret_cast<const f32x4*>(a.beta + c);
         f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (a.accumulate) o = *reinterpret_cast<const f32x4*>(a.dx + off);
+        if (a.accumulate) o = Io<T>::ld4(dx + off);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float xh = (v[e] - mean) * rstd;
@@ -216,54 +207,77 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GnArgs a) {
             if (a.act) dz *= silu_grad(xh * ga[e] + be[e]);
             o[e] += rstd * (dz * ga[e] - m1 - xh * m2);
         }
-        *reinterpret_cast<f32x4*>(a.dx + off) = o;
+        Io<T>::st4(dx + off, o);
     }
 }
 
 // ---- elementwise --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void axpby_kernel(float* __restrict__ dst, const float* __restrict__ src, long long n, int acc) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
-        dst[i] = acc ? dst[i] + src[i] : src[i];
+// n is a multiple of 4 (channel counts are); four elements per thread and trip
+template <typename T>
+__global__ __launch_bounds__(256) void axpby_kernel(T* __restrict__ dst, const T* __restrict__ src, long long n4, int acc) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        f32x4 v = Io<T>::ld4(src + 4 * i);
+        if (acc) {
+            const f32x4 d = Io<T>::ld4(dst + 4 * i);
+            v = f32x4{v[0] + d[0], v[1] + d[1], v[2] + d[2], v[3] + d[3]};
+        }
+        Io<T>::st4(dst + 4 * i, v);
+    }
 }
-__global__ __launch_bounds__(256) void add_kernel(float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ b, long long n) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = a[i] + b[i];
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(T* __restrict__ out, const T* __restrict__ a, const T* __restrict__ b, long long n4) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const f32x4 x = Io<T>::ld4(a + 4 * i), y = Io<T>::ld4(b + 4 * i);
+        Io<T>::st4(out + 4 * i, f32x4{x[0] + y[0], x[1] + y[1], x[2] + y[2], x[3] + y[3]});
+    }
 }
-__global__ __launch_bounds__(256) void copy_slice_kernel(float* __restrict__ dst, int ldd, int doff, const float* __restrict__ src, int lds,
+template <typename T>
+__global__ __launch_bounds__(256) void copy_slice_kernel(T* __restrict__ dst, int ldd, int doff, const T* __restrict__ src, int lds,
                                                          int soff, int C, long long rows, int acc) {
-    const long long total = rows * C;
+    const int c4n = C >> 2;
+    const long long total = rows * c4n;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const long long row = i / C;
-        const int c = (int)(i - row * C);
-        const float v = src[row * lds + soff + c];
-        float* d = dst + row * ldd + doff + c;
-        *d = acc ? *d + v : v;
+        const long long row = i / c4n;
+        const int c = 4 * (int)(i - row * c4n);
+        f32x4 v = Io<T>::ld4(src + row * lds + soff + c);
+        T* d = dst + row * ldd + doff + c;
+        if (acc) {
+            const f32x4 o = Io<T>::ld4(d);
+            v = f32x4{v[0] + o[0], v[1] + o[1], v[2] + o[2], v[3] + o[3]};
+        }
+        Io<T>::st4(d, v);
     }
 }
-__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long n, int act) {
+template <typename T>
+__global__ __launch_bounds__(256) void act_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long long n, int act) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const float v = x[i];
-        y[i] = act == 0 ? v * sigmoid_f(v) : gelu_f(v);
+        const float v = Io<T>::ld(x + i);
+        Io<T>::st(y + i, act == 0 ? v * sigmoid_f(v) : gelu_f(v));
     }
 }
-__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
                                                       long long n, int act, int acc) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const float v = x[i];
-        const float g = dy[i] * (act == 0 ? silu_grad(v) : gelu_grad(v));
-        dx[i] = acc ? dx[i] + g : g;
+        const float v = Io<T>::ld(x + i);
+        const float g = Io<T>::ld(dy + i) * (act == 0 ? silu_grad(v) : gelu_grad(v));
+        Io<T>::st(dx + i, acc ? Io<T>::ld(dx + i) + g : g);
     }
 }
-__global__ __launch_bounds__(256) void class_bias_fwd_kernel(float* __restrict__ x, const float* __restrict__ table,
+template <typename T>
+__global__ __launch_bounds__(256) void class_bias_fwd_kernel(T* __restrict__ x, const float* __restrict__ table,
                                                              const long long* __restrict__ labels, int pad, int HW, int C) {
     const int b = blockIdx.y;
     const long long row = labels ? labels[b] : pad;
     const float* e = table + row * C;
-    float* xb = x + (size_t)b * HW * C;
+    T* xb = x + (size_t)b * HW * C;
     const long long total = (long long)HW * C;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) xb[i] += e[i % C];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256)
+        Io<T>::st(xb + i, Io<T>::ld(xb + i) + e[i % C]);
 }
 // grid (splits, B); thread = channel (c = tid % C) x pixel lane
-__global__ __launch_bounds__(256) void class_bias_bwd_kernel(const float* __restrict__ dy, const long long* __restrict__ labels, int pad,
+template <typename T>
+__global__ __launch_bounds__(256) void class_bias_bwd_kernel(const T* __restrict__ dy, const long long* __restrict__ labels, int pad,
                                                              float* __restrict__ dtable, int HW, int C) {
     __shared__ float sh[256];
     const int b = blockIdx.y, tid = threadIdx.x;
@@ -272,7 +286,7 @@ __global__ __launch_bounds__(256) void class_bias_bwd_kernel(const float* __rest
     const int c = tid % C, pl = tid / C, npl = 256 / C;
     float acc = 0.f;
     if (pl < npl)
-        for (int p = blockIdx.x * npl + pl; p < HW; p += gridDim.x * npl) acc += dy[((size_t)b * HW + p) * C + c];
+        for (int p = blockIdx.x * npl + pl; p < HW; p += gridDim.x * npl) acc += Io<T>::ld(dy + ((size_t)b * HW + p) * C + c);
     sh[tid] = acc;
     __syncthreads();
     if (pl == 0) {
@@ -294,9 +308,10 @@ __global__ void sinus_kernel(const void* t, int t_is_float, int B, int dim, floa
     out[i] = j < half ? sinf(arg) : cosf(arg);
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void train_ingest_kernel(const float* __restrict__ x0, const float* __restrict__ eps,
                                                            const long long* __restrict__ t, const float* __restrict__ sa,
-                                                           const float* __restrict__ sb, float* __restrict__ xt, float* __restrict__ tgt,
+                                                           const float* __restrict__ sb, T* __restrict__ xt, float* __restrict__ tgt,
                                                            int B, int C, int HW) {
     const long long total = (long long)B * C * HW;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -311,18 +326,20 @@ __global__ __launch_bounds__(256) void train_ingest_kernel(const float* __restri
             const long long tb = t[b];
             v = sa[tb] * v + sb[tb] * e;
         }
-        xt[i] = v;
+        Io<T>::st(xt + i, v);
         if (tgt) tgt[i] = e;
     }
 }
 
-__global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ out, const float* __restrict__ tgt, long long n, int kind,
-                                                   float* __restrict__ loss, float* __restrict__ dout) {
+// out / dout in the activation type; the target stays float32 (it is the caller's noise, only reordered)
+template <typename T>
+__global__ __launch_bounds__(256) void loss_kernel(const T* __restrict__ out, const float* __restrict__ tgt, long long n, int kind,
+                                                   float* __restrict__ loss, T* __restrict__ dout) {
     __shared__ float sh[4];
     const float inv = 1.0f / (float)n;
     float acc = 0.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const float d = out[i] - tgt[i];
+        const float d = Io<T>::ld(out + i) - tgt[i];
         float l, g;
         if (kind == 1) {
             l = d * d;
@@ -336,19 +353,20 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ out
             g = ad < 1.f ? d : (d > 0.f ? 1.f : -1.f);
         }
         acc += l;
-        dout[i] = g * inv;
+        Io<T>::st(dout + i, g * inv);
     }
     acc = block_sum(acc, sh);
     if (threadIdx.x == 0) unsafeAtomicAdd(loss, acc * inv);
 }
 
-__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, int HW) {
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ in, float* __restrict__ out, int B, int C, int HW) {
     const long long total = (long long)B * C * HW;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int p = (int)(i % HW);
         const long long bc = i / HW;
         const int c = (int)(bc % C), b = (int)(bc / C);
-        out[i] = in[((size_t)b * HW + p) * C + c];
+        out[i] = Io<T>::ld(in + ((size_t)b * HW + p) * C + c);
     }
 }
 
@@ -381,11 +399,12 @@ __device__ __forceinline__ void softmax_q_rows(float* Qs, int tid) {
 }
 
 // loads a [64 pixels][32] slice (channel offset coff of the row) into LDS rows of 33 floats; pixels >= n become `fill`
-__device__ __forceinline__ void load_tile(float* S, const float* base, int ld, int coff, int p0, int n, int tid, float fill) {
+template <typename T>
+__device__ __forceinline__ void load_tile(float* S, const T* base, int ld, int coff, int p0, int n, int tid, float fill) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int idx = tid + 256 * i, p = idx >> 5, d = idx & 31;
-        S[p * 33 + d] = (p0 + p < n) ? base[(size_t)(p0 + p) * ld + coff + d] : fill;
+        S[p * 33 + d] = (p0 + p < n) ? Io<T>::ld(base + (size_t)(p0 + p) * ld + coff + d) : fill;
     }
 }
 
@@ -398,16 +417,17 @@ __device__ __forceinline__ void split_range(int n, int& p_begin, int& p_end) {
 }
 
 // partial max over the split's pixels of every k channel: pmax[bh][split][32]
-__global__ __launch_bounds__(256) void linattn_kmax_kernel(const float* __restrict__ qkv, float* __restrict__ pmax, int n, int heads) {
+template <typename T>
+__global__ __launch_bounds__(256) void linattn_kmax_kernel(const T* __restrict__ qkv, float* __restrict__ pmax, int n, int heads) {
     __shared__ float red[8 * 32];
     const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads, tid = threadIdx.x;
     const int hid = heads * kD, ld = 3 * hid;
-    const float* base = qkv + (size_t)b * n * ld;
+    const T* base = qkv + (size_t)b * n * ld;
     int pb, pe;
     split_range(n, pb, pe);
     const int d = tid & 31, pl = tid >> 5;
     float mx = -INFINITY;
-    for (int p = pb + pl; p < pe; p += 8) mx = fmaxf(mx, base[(size_t)p * ld + hid + h * kD + d]);
+    for (int p = pb + pl; p < pe; p += 8) mx = fmaxf(mx, Io<T>::ld(base + (size_t)p * ld + hid + h * kD + d));
     red[pl * 32 + d] = mx;
     __syncthreads();
     if (tid < 32) {
@@ -418,12 +438,13 @@ __global__ __launch_bounds__(256) void linattn_kmax_kernel(const float* __restri
 }
 
 // ctx_un[d][e] += sum_n exp(k[n][d] - max[d]) v[n][e];  kstat[bh] = {max[32], sum of exp[32]}
-__global__ __launch_bounds__(256) void linattn_ctx_kernel(const float* __restrict__ qkv, const float* __restrict__ pmax,
+template <typename T>
+__global__ __launch_bounds__(256) void linattn_ctx_kernel(const T* __restrict__ qkv, const float* __restrict__ pmax,
                                                           float* __restrict__ ctx_un, float* __restrict__ kstat, int n, int heads) {
     __shared__ float Ks[64 * 33], Vs[64 * 33], kmx[32];
     const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads, tid = threadIdx.x;
     const int hid = heads * kD, ld = 3 * hid;
-    const float* base = qkv + (size_t)b * n * ld;
+    const T* base = qkv + (size_t)b * n * ld;
     int pb, pe;
     split_range(n, pb, pe);
     if (tid < 32) {
@@ -440,9 +461,9 @@ __global__ __launch_bounds__(256) void linattn_ctx_kernel(const float* __restric
         for (int i = 0; i < 8; ++i) {
             const int idx = tid + 256 * i, p = idx >> 5, dd = idx & 31;
             const bool ok = p0 + p < pe;
-            const float* row = base + (size_t)(p0 + p) * ld;
-            Ks[p * 33 + dd] = ok ? expf(row[hid + h * kD + dd] - kmx[dd]) : 0.f;
-            Vs[p * 33 + dd] = ok ? row[2 * hid + h * kD + dd] : 0.f;
+            const T* row = base + (size_t)(p0 + p) * ld;
+            Ks[p * 33 + dd] = ok ? expf(Io<T>::ld(row + hid + h * kD + dd) - kmx[dd]) : 0.f;
+            Vs[p * 33 + dd] = ok ? Io<T>::ld(row + 2 * hid + h * kD + dd) : 0.f;
         }
         __syncthreads();
 #pragma unroll 8
@@ -507,11 +528,11 @@ __device__ __forceinline__ float qmax(float v) {
     v = fmaxf(v, __shfl_xor(v, 32, 64));
     return v;
 }
-__device__ __forceinline__ void load8(const float* row, int q, bool ok, float* x) {
+template <typename T> __device__ __forceinline__ void load8(const T* row, int q, bool ok, float* x) {
     f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, b = a;
     if (ok) {
-        a = *reinterpret_cast<const f32x4*>(row + 4 * q);
-        b = *reinterpret_cast<const f32x4*>(row + 16 + 4 * q);
+        a = Io<T>::ld4(row + 4 * q);
+        b = Io<T>::ld4(row + 16 + 4 * q);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -519,9 +540,9 @@ __device__ __forceinline__ void load8(const float* row, int q, bool ok, float* x
         x[4 + i] = b[i];
     }
 }
-__device__ __forceinline__ void store8(float* row, int q, const float* x) {
-    *reinterpret_cast<f32x4*>(row + 4 * q) = f32x4{x[0], x[1], x[2], x[3]};
-    *reinterpret_cast<f32x4*>(row + 16 + 4 * q) = f32x4{x[4], x[5], x[6], x[7]};
+template <typename T> __device__ __forceinline__ void store8(T* row, int q, const float* x) {
+    Io<T>::st4(row + 4 * q, f32x4{x[0], x[1], x[2], x[3]});
+    Io<T>::st4(row + 16 + 4 * q, f32x4{x[4], x[5], x[6], x[7]});
 }
 // unscaled softmax over the 32 channels of the lane's pixel
 __device__ __forceinline__ void softmax8(const float* x, float* sm) {
@@ -541,14 +562,14 @@ __device__ __forceinline__ void softmax8(const float* x, float* sm) {
 }
 
 // out[n][e] = scale * sum_d ctx[d][e] * softmax_d(q[n])[d],  ctx = ctx_un / sum of exp
-template <bool BF>
-__global__ __launch_bounds__(256) void linattn_out_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx_un,
-                                                          const float* __restrict__ kstat, float* __restrict__ out, int n, int heads) {
+template <typename T, bool BF>
+__global__ __launch_bounds__(256) void linattn_out_kernel(const T* __restrict__ qkv, const float* __restrict__ ctx_un,
+                                                          const float* __restrict__ kstat, T* __restrict__ out, int n, int heads) {
     __shared__ float CxT[32 * 33];
     const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
     const int hid = heads * kD, ld = 3 * hid;
-    const float* base = qkv + (size_t)b * n * ld;
+    const T* base = qkv + (size_t)b * n * ld;
     int pb, pe;
     split_range(n, pb, pe);
     for (int i = tid; i < 1024; i += 256) {
@@ -570,13 +591,14 @@ __global__ __launch_bounds__(256) void linattn_out_kernel(const float* __restric
 }
 
 // dctx[d][e] += scale * sum_n softmax(q[n])[d] * dout[n][e]
-__global__ __launch_bounds__(256) void linattn_dctx_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+template <typename T>
+__global__ __launch_bounds__(256) void linattn_dctx_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
                                                            float* __restrict__ dctx, int n, int heads) {
     __shared__ float As[64 * 33], Bs[64 * 33];
     const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads, tid = threadIdx.x;
     const int hid = heads * kD, ld = 3 * hid;
-    const float* base = qkv + (size_t)b * n * ld;
-    const float* dob = dout + (size_t)b * n * hid;
+    const T* base = qkv + (size_t)b * n * ld;
+    const T* dob = dout + (size_t)b * n * hid;
     int pb, pe;
     split_range(n, pb, pe);
     const int d = tid >> 3, e4 = (tid & 7) * 4;
@@ -602,17 +624,17 @@ __global__ __launch_bounds__(256) void linattn_dctx_kernel(const float* __restri
 }
 
 // per pixel dq, dk, dv on the matrix cores (layout: see mat32_apply)
-template <bool BF>
-__global__ __launch_bounds__(256) void linattn_bwd_pix_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+template <typename T, bool BF>
+__global__ __launch_bounds__(256) void linattn_bwd_pix_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
                                                               const float* __restrict__ ctx_un, const float* __restrict__ kstat,
-                                                              const float* __restrict__ dctx, float* __restrict__ dqkv, int n, int heads) {
+                                                              const float* __restrict__ dctx, T* __restrict__ dqkv, int n, int heads) {
     __shared__ float Cx[32 * 33], Dc[32 * 33], DcT[32 * 33], sv[32];
     const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
     const int hid = heads * kD, ld = 3 * hid;
-    const float* base = qkv + (size_t)b * n * ld;
-    const float* dob = dout + (size_t)b * n * hid;
-    float* dqb = dqkv + (size_t)b * n * ld;
+    const T* base = qkv + (size_t)b * n * ld;
+    const T* dob = dout + (size_t)b * n * hid;
+    T* dqb = dqkv + (size_t)b * n * ld;
     int pb, pe;
     split_range(n, pb, pe);
     for (int i = tid; i < 1024; i += 256) {
@@ -640,7 +662,7 @@ __global__ __launch_bounds__(256) void linattn_bwd_pix_kernel(const float* __res
     for (int p0 = pb + 16 * wave; p0 < pe; p0 += 64) {
         const int pix = p0 + r;
         const bool ok = pix < pe;
-        const float* row = base + (size_t)pix * ld + h * kD;
+        const T* row = base + (size_t)pix * ld + h * kD;
         float qv[8], kv[8], vv[8], dov[8], qs[8], y[8], res[8];
         load8(row, q, ok, qv);
         load8(row + hid, q, ok, kv);
@@ -655,7 +677,7 @@ __global__ __launch_bounds__(256) void linattn_bwd_pix_kernel(const float* __res
         dot = qsum(dot);
 #pragma unroll
         for (int i = 0; i < 8; ++i) res[i] = kScale * qs[i] * (y[i] - dot);
-        float* orow = dqb + (size_t)pix * ld + h * kD;
+        T* orow = dqb + (size_t)pix * ld + h * kD;
         if (ok) store8(orow, q, res);
         // dkhat[d] = sum_e dctx[d][e] v[e]; dk = khat[d] * (dkhat[d] - sv[d])
         mat32_apply<BF>(Dc, vv, y, r, q);
@@ -674,19 +696,20 @@ __global__ __launch_bounds__(256) void linattn_bwd_pix_kernel(const float* __res
 
 // ---- softmax attention core (bottleneck) ------------------------------------------------------------------------
 // One workgroup per (image, head); thread = query row (rows beyond 256 in further rounds); keys in LDS tiles of 64.
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, float* __restrict__ lse,
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, float* __restrict__ lse,
                                                        int n, int heads) {
     __shared__ float Ks[64 * 33], Vs[64 * 33];
     const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads, tid = threadIdx.x;
     const int hid = heads * kD, ld = 3 * hid;
-    const float* base = qkv + (size_t)b * n * ld;
+    const T* base = qkv + (size_t)b * n * ld;
     for (int i0 = 0; i0 < n; i0 += 256) {
         const int i = i0 + tid;
         const bool ok = i < n;
         float qv[32], acc[32], m = -INFINITY, l = 0.f;
 #pragma unroll
         for (int d = 0; d < 32; ++d) {
-            qv[d] = ok ? base[(size_t)i * ld + h * kD + d] * kScale : 0.f;
+            qv[d] = ok ? Io<T>::ld(base + (size_t)i * ld + h * kD + d) * kScale : 0.f;
             acc[d] = 0.f;
         }
         for (int j0 = 0; j0 < n; j0 += 64) {
@@ -709,9 +732,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
         }
         if (ok) {
             const float inv = 1.0f / l;
-            float* orow = out + ((size_t)b * n + i) * hid + h * kD;
+            T* orow = out + ((size_t)b * n + i) * hid + h * kD;
 #pragma unroll
-            for (int d = 0; d < 32; ++d) orow[d] = acc[d] * inv;
+            for (int d = 0; d < 32; ++d) Io<T>::st(orow + d, acc[d] * inv);
             lse[(size_t)bh * n + i] = m + logf(l);
         }
     }
@@ -719,16 +742,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 
 // dq (thread = query) then dk, dv (thread = key). Dsh: per-query sum_e dout*out kept in global scratch `dsum`
 // ([B*heads][n], the tail of the lse allocation is not used for this: the caller passes a separate buffer).
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
-                                                       const float* __restrict__ dout, const float* __restrict__ lse,
-                                                       float* __restrict__ dqkv, float* __restrict__ dsum, int n, int heads) {
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
+                                                       const T* __restrict__ dout, const float* __restrict__ lse,
+                                                       T* __restrict__ dqkv, float* __restrict__ dsum, int n, int heads) {
     __shared__ float As[64 * 33], Bs[64 * 33], Ls[64], Ds[64];
     const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads, tid = threadIdx.x;
     const int hid = heads * kD, ld = 3 * hid;
-    const float* base = qkv + (size_t)b * n * ld;
-    const float* ob = out + (size_t)b * n * hid;
-    const float* dob = dout + (size_t)b * n * hid;
-    float* dqb = dqkv + (size_t)b * n * ld;
+    const T* base = qkv + (size_t)b * n * ld;
+    const T* ob = out + (size_t)b * n * hid;
+    const T* dob = dout + (size_t)b * n * hid;
+    T* dqb = dqkv + (size_t)b * n * ld;
     // phase 1: dq
     for (int i0 = 0; i0 < n; i0 += 256) {
         const int i = i0 + tid;
@@ -737,9 +761,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         const float li = ok ? lse[(size_t)bh * n + i] : 0.f;
 #pragma unroll
         for (int d = 0; d < 32; ++d) {
-            qv[d] = ok ? base[(size_t)i * ld + h * kD + d] * kScale : 0.f;
-            dov[d] = ok ? dob[(size_t)i * hid + h * kD + d] : 0.f;
-            Di += dov[d] * (ok ? ob[(size_t)i * hid + h * kD + d] : 0.f);
+            qv[d] = ok ? Io<T>::ld(base + (size_t)i * ld + h * kD + d) * kScale : 0.f;
+            dov[d] = ok ? Io<T>::ld(dob + (size_t)i * hid + h * kD + d) : 0.f;
+            Di += dov[d] * (ok ? Io<T>::ld(ob + (size_t)i * hid + h * kD + d) : 0.f);
             dq[d] = 0.f;
         }
         if (ok) dsum[(size_t)bh * n + i] = Di;
@@ -762,9 +786,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
             }
         }
         if (ok) {
-            float* row = dqb + (size_t)i * ld + h * kD;
+            T* row = dqb + (size_t)i * ld + h * kD;
 #pragma unroll
-            for (int d = 0; d < 32; ++d) row[d] = dq[d] * kScale;
+            for (int d = 0; d < 32; ++d) Io<T>::st(row + d, dq[d] * kScale);
         }
     }
     __threadfence_block();
@@ -775,8 +799,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         float kv[32], vv[32], dk[32], dv[32];
 #pragma unroll
         for (int d = 0; d < 32; ++d) {
-            kv[d] = ok ? base[(size_t)j * ld + hid + h * kD + d] : 0.f;
-            vv[d] = ok ? base[(size_t)j * ld + 2 * hid + h * kD + d] : 0.f;
+            kv[d] = ok ? Io<T>::ld(base + (size_t)j * ld + hid + h * kD + d) : 0.f;
+            vv[d] = ok ? Io<T>::ld(base + (size_t)j * ld + 2 * hid + h * kD + d) : 0.f;
             dk[d] = dv[d] = 0.f;
         }
         for (int i0 = 0; i0 < n; i0 += 64) {
@@ -807,11 +831,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
             }
         }
         if (ok) {
-            float* row = dqb + (size_t)j * ld + hid + h * kD;
+            T* row = dqb + (size_t)j * ld + hid + h * kD;
 #pragma unroll
             for (int d = 0; d < 32; ++d) {
-                row[d] = dk[d];
-                row[hid + d] = dv[d];
+                Io<T>::st(row + d, dk[d]);
+                Io<T>::st(row + hid + d, dv[d]);
             }
         }
     }
@@ -888,25 +912,14 @@ inline int grid_for(long long n, int per_block = 256, int cap = 8192) {
 
 }   // namespace
 
-int launch_colsum(const float* in, int ld, long long rows, int C, float* out, hipStream_t s) {
-    const int cw = C < 256 ? C : 256;
-    const int nrl = 256 / cw;
-    long long gx = (rows + nrl * 8 - 1) / (nrl * 8);
-    if (gx > 512) gx = 512;
-    if (gx < 1) gx = 1;
-    colsum_kernel<<<dim3((int)gx, (C + 255) / 256), 256, 0, s>>>(in, ld, rows, C, cw, out);
-    DMN_LAUNCH_CHECK();
-    return DMN_OK;
-}
-
-int launch_gn_stats(const float* x, int B, int HW, int C, int G, float* stats, hipStream_t s) {
+int launch_gn_stats(const void* x, int adt, int B, int HW, int C, int G, float* stats, hipStream_t s) {
     DMN_REQUIRE(C % G == 0 && (C / G) % 4 == 0, DMN_ERR_INVALID, "gn: C=%d G=%d", C, G);
     const long long per = (long long)HW * (C / G) / 4;
     int split = (int)((per + 2047) / 2048);
     const int cap = 2048 / (B * G) > 1 ? 2048 / (B * G) : 1;
     if (split > cap) split = cap;
     if (split < 1) split = 1;
-    gn_stats_kernel<<<dim3(B * G, split), 256, 0, s>>>(x, HW, C, G, stats);
+    DMN_DISPATCH_T(adt, gn_stats_kernel<T><<<dim3(B * G, split), 256, 0, s>>>((const T*)x, HW, C, G, stats));
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }
@@ -914,7 +927,8 @@ int launch_gn_stats(const float* x, int B, int HW, int C, int G, float* stats, h
 int launch_gn_apply(const GnArgs& a, hipStream_t s) {
     DMN_REQUIRE(a.C % 4 == 0 && a.C % a.G == 0 && (a.C / a.G) % 4 == 0, DMN_ERR_INVALID, "gn: C=%d G=%d", a.C, a.G);
     const int cap = 4096 / a.B > 1 ? 4096 / a.B : 1;
-    gn_apply_kernel<<<dim3(grid_for((long long)a.HW * a.C / 4, 256 * 2, cap), a.B), 256, 0, s>>>(a);
+    const dim3 grid(grid_for((long long)a.HW * a.C / 4, 256 * 2, cap), a.B);
+    DMN_DISPATCH_T(a.adt, gn_apply_kernel<T><<<grid, 256, 0, s>>>(a));
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }
@@ -922,57 +936,62 @@ int launch_gn_apply(const GnArgs& a, hipStream_t s) {
 int launch_gn_bwd(const GnArgs& a, hipStream_t s) {
     const int c4n = a.C / 4;
     DMN_REQUIRE(a.C % 4 == 0 && c4n <= 256 && 256 % c4n == 0 && a.G <= 64, DMN_ERR_INVALID, "gn backward: C=%d G=%d", a.C, a.G);
+    DMN_REQUIRE(a.dx && a.dgamma && a.dbeta, DMN_ERR_INVALID, "gn backward: null output");
     const int npl = 256 / c4n;
     int split = (a.HW + npl * 8 - 1) / (npl * 8);
     const int cap = 2048 / a.B > 1 ? 2048 / a.B : 1;
     if (split > cap) split = cap;
     if (split < 1) split = 1;
-    gn_bwd_sums_kernel<<<dim3(split, a.B), 256, 0, s>>>(a);
+    DMN_DISPATCH_T(a.adt, gn_bwd_sums_kernel<T><<<dim3(split, a.B), 256, 0, s>>>(a));
     DMN_LAUNCH_CHECK();
-    DMN_REQUIRE(a.dx && a.dgamma && a.dbeta, DMN_ERR_INVALID, "gn backward: null output");
-    int nb = grid_for((long long)a.HW * c4n, 256 * 4, cap);
-    gn_bwd_apply_kernel<<<dim3(nb, a.B), 256, 0, s>>>(a);
+    const int nb = grid_for((long long)a.HW * c4n, 256 * 4, cap);
+    DMN_DISPATCH_T(a.adt, gn_bwd_apply_kernel<T><<<dim3(nb, a.B), 256, 0, s>>>(a));
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }
 
-int launch_axpby(float* dst, const float* src, long long n, int accumulate, hipStream_t s) {
-    axpby_kernel<<<grid_for(n, 1024), 256, 0, s>>>(dst, src, n, accumulate);
+int launch_axpby(void* dst, const void* src, int adt, long long n, int accumulate, hipStream_t s) {
+    DMN_REQUIRE((n & 3) == 0, DMN_ERR_INVALID, "axpby: %lld elements", n);
+    DMN_DISPATCH_T(adt, axpby_kernel<T><<<grid_for(n / 4, 512), 256, 0, s>>>((T*)dst, (const T*)src, n / 4, accumulate));
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }
-int launch_add(float* out, const float* a, const float* b, long long n, hipStream_t s) {
-    add_kernel<<<grid_for(n, 1024), 256, 0, s>>>(out, a, b, n);
+int launch_add(void* out, const void* a, const void* b, int adt, long long n, hipStream_t s) {
+    DMN_REQUIRE((n & 3) == 0, DMN_ERR_INVALID, "add: %lld elements", n);
+    DMN_DISPATCH_T(adt, add_kernel<T><<<grid_for(n / 4, 512), 256, 0, s>>>((T*)out, (const T*)a, (const T*)b, n / 4));
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }
-int launch_copy_slice(float* dst, int ldd, int doff, const float* src, int lds, int soff, int C, long long rows, int accumulate,
-                      hipStream_t s) {
-    copy_slice_kernel<<<grid_for(rows * C, 1024), 256, 0, s>>>(dst, ldd, doff, src, lds, soff, C, rows, accumulate);
+int launch_copy_slice(void* dst, int ldd, int doff, const void* src, int lds, int soff, int C, long long rows, int adt,
+                      int accumulate, hipStream_t s) {
+    DMN_REQUIRE(((C | ldd | doff | lds | soff) & 3) == 0, DMN_ERR_INVALID, "copy_slice: widths must be multiples of 4");
+    DMN_DISPATCH_T(adt, copy_slice_kernel<T><<<grid_for(rows * C / 4, 512), 256, 0, s>>>((T*)dst, ldd, doff, (const T*)src, lds, soff, C,
+                                                                                          rows, accumulate));
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }
-int launch_act_fwd(const float* x, float* y, long long n, int act, hipStream_t s) {
-    act_fwd_kernel<<<grid_for(n, 1024), 256, 0, s>>>(x, y, n, act);
+int launch_act_fwd(const void* x, void* y, int adt, long long n, int act, hipStream_t s) {
+    DMN_DISPATCH_T(adt, act_fwd_kernel<T><<<grid_for(n, 1024), 256, 0, s>>>((const T*)x, (T*)y, n, act));
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }
-int launch_act_bwd(const float* x, const float* dy, float* dx, long long n, int act, int accumulate, hipStream_t s) {
-    act_bwd_kernel<<<grid_for(n, 1024), 256, 0, s>>>(x, dy, dx, n, act, accumulate);
+int launch_act_bwd(const void* x, const void* dy, void* dx, int adt, long long n, int act, int accumulate, hipStream_t s) {
+    DMN_DISPATCH_T(adt, act_bwd_kernel<T><<<grid_for(n, 1024), 256, 0, s>>>((const T*)x, (const T*)dy, (T*)dx, n, act, accumulate));
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }
-int launch_class_bias_fwd(float* x, const float* table, const long long* labels, int pad, int B, int HW, int C, hipStream_t s) {
-    class_bias_fwd_kernel<<<dim3(grid_for((long long)HW * C, 1024, 256), B), 256, 0, s>>>(x, table, labels, pad, HW, C);
+int launch_class_bias_fwd(void* x, int adt, const float* table, const long long* labels, int pad, int B, int HW, int C, hipStream_t s) {
+    const dim3 grid(grid_for((long long)HW * C, 1024, 256), B);
+    DMN_DISPATCH_T(adt, class_bias_fwd_kernel<T><<<grid, 256, 0, s>>>((T*)x, table, labels, pad, HW, C));
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }
-int launch_class_bias_bwd(const float* dy, const long long* labels, int pad, float* dtable, int B, int HW, int C, hipStream_t s) {
+int launch_class_bias_bwd(const void* dy, int adt, const long long* labels, int pad, float* dtable, int B, int HW, int C, hipStream_t s) {
     DMN_REQUIRE(C <= 256, DMN_ERR_LIMIT, "class embedding width %d", C);
     const int npl = 256 / C;
     int split = (HW + npl * 16 - 1) / (npl * 16);
     if (split > 64) split = 64;
-    class_bias_bwd_kernel<<<dim3(split, B), 256, 0, s>>>(dy, labels, pad, dtable, HW, C);
+    DMN_DISPATCH_T(adt, class_bias_bwd_kernel<T><<<dim3(split, B), 256, 0, s>>>((const T*)dy, labels, pad, dtable, HW, C));
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }
@@ -981,19 +1000,20 @@ int launch_sinus(const void* t, int t_is_float, int B, int dim, float* out, hipS
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }
-int launch_train_ingest(const float* x0, const float* eps, const long long* t, const float* sa, const float* sb, float* xt,
+int launch_train_ingest(const float* x0, const float* eps, const long long* t, const float* sa, const float* sb, void* xt, int adt,
                         float* tgt, int B, int C, int H, int W, hipStream_t s) {
-    train_ingest_kernel<<<grid_for((long long)B * C * H * W, 1024), 256, 0, s>>>(x0, eps, t, sa, sb, xt, tgt, B, C, H * W);
+    DMN_DISPATCH_T(adt, train_ingest_kernel<T><<<grid_for((long long)B * C * H * W, 1024), 256, 0, s>>>(x0, eps, t, sa, sb, (T*)xt, tgt, B,
+                                                                                                         C, H * W));
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }
-int launch_loss(const float* out, const float* tgt, long long n, int kind, float* loss, float* dout, hipStream_t s) {
-    loss_kernel<<<grid_for(n, 1024, 1024), 256, 0, s>>>(out, tgt, n, kind, loss, dout);
+int launch_loss(const void* out, const float* tgt, int adt, long long n, int kind, float* loss, void* dout, hipStream_t s) {
+    DMN_DISPATCH_T(adt, loss_kernel<T><<<grid_for(n, 1024, 1024), 256, 0, s>>>((const T*)out, tgt, n, kind, loss, (T*)dout));
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }
-int launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, hipStream_t s) {
-    nhwc_to_nchw_kernel<<<grid_for((long long)B * C * HW, 1024), 256, 0, s>>>(in, out, B, C, HW);
+int launch_nhwc_to_nchw(const void* in, int adt, float* out, int B, int C, int HW, hipStream_t s) {
+    DMN_DISPATCH_T(adt, nhwc_to_nchw_kernel<T><<<grid_for((long long)B * C * HW, 1024), 256, 0, s>>>((const T*)in, out, B, C, HW));
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }
@@ -1005,37 +1025,44 @@ int linattn_train_splits(int B, int n, int heads) {
     if (splits > 256) splits = 256;
     return splits;
 }
-int launch_linattn_train_fwd(const float* qkv, float* out, float* ctx, float* kstat, float* pmax, int B, int n, int heads,
+int launch_linattn_train_fwd(const void* qkv, void* out, int adt, float* ctx, float* kstat, float* pmax, int B, int n, int heads,
                              int bf16, hipStream_t s) {
     const dim3 grid(B * heads, linattn_train_splits(B, n, heads));
-    linattn_kmax_kernel<<<grid, 256, 0, s>>>(qkv, pmax, n, heads);
+    DMN_DISPATCH_T(adt, linattn_kmax_kernel<T><<<grid, 256, 0, s>>>((const T*)qkv, pmax, n, heads));
     DMN_LAUNCH_CHECK();
-    linattn_ctx_kernel<<<grid, 256, 0, s>>>(qkv, pmax, ctx, kstat, n, heads);
+    DMN_DISPATCH_T(adt, linattn_ctx_kernel<T><<<grid, 256, 0, s>>>((const T*)qkv, pmax, ctx, kstat, n, heads));
     DMN_LAUNCH_CHECK();
-    if (bf16) linattn_out_kernel<true><<<grid, 256, 0, s>>>(qkv, ctx, kstat, out, n, heads);
-    else linattn_out_kernel<false><<<grid, 256, 0, s>>>(qkv, ctx, kstat, out, n, heads);
+    if (adt == 1) linattn_out_kernel<__bf16, true><<<grid, 256, 0, s>>>((const __bf16*)qkv, ctx, kstat, (__bf16*)out, n, heads);
+    else if (bf16) linattn_out_kernel<float, true><<<grid, 256, 0, s>>>((const float*)qkv, ctx, kstat, (float*)out, n, heads);
+    else linattn_out_kernel<float, false><<<grid, 256, 0, s>>>((const float*)qkv, ctx, kstat, (float*)out, n, heads);
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }
-int launch_linattn_train_bwd(const float* qkv, const float* dout, const float* ctx, const float* kstat, float* dctx, float* dqkv,
+int launch_linattn_train_bwd(const void* qkv, const void* dout, int adt, const float* ctx, const float* kstat, float* dctx, void* dqkv,
                              int B, int n, int heads, int bf16, hipStream_t s) {
     const dim3 grid(B * heads, linattn_train_splits(B, n, heads));
-    linattn_dctx_kernel<<<grid, 256, 0, s>>>(qkv, dout, dctx, n, heads);
+    DMN_DISPATCH_T(adt, linattn_dctx_kernel<T><<<grid, 256, 0, s>>>((const T*)qkv, (const T*)dout, dctx, n, heads));
     DMN_LAUNCH_CHECK();
-    if (bf16) linattn_bwd_pix_kernel<true><<<grid, 256, 0, s>>>(qkv, dout, ctx, kstat, dctx, dqkv, n, heads);
-    else linattn_bwd_pix_kernel<false><<<grid, 256, 0, s>>>(qkv, dout, ctx, kstat, dctx, dqkv, n, heads);
+    if (adt == 1)
+        linattn_bwd_pix_kernel<__bf16, true><<<grid, 256, 0, s>>>((const __bf16*)qkv, (const __bf16*)dout, ctx, kstat, dctx, (__bf16*)dqkv, n,
+                                                                  heads);
+    else if (bf16)
+        linattn_bwd_pix_kernel<float, true><<<grid, 256, 0, s>>>((const float*)qkv, (const float*)dout, ctx, kstat, dctx, (float*)dqkv, n, heads);
+    else
+        linattn_bwd_pix_kernel<float, false><<<grid, 256, 0, s>>>((const float*)qkv, (const float*)dout, ctx, kstat, dctx, (float*)dqkv, n, heads);
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }
-int launch_attn_train_fwd(const float* qkv, float* out, float* lse, int B, int n, int heads, hipStream_t s) {
-    attn_fwd_kernel<<<B * heads, 256, 0, s>>>(qkv, out, lse, n, heads);
+int launch_attn_train_fwd(const void* qkv, void* out, int adt, float* lse, int B, int n, int heads, hipStream_t s) {
+    DMN_DISPATCH_T(adt, attn_fwd_kernel<T><<<B * heads, 256, 0, s>>>((const T*)qkv, (T*)out, lse, n, heads));
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }
-int launch_attn_train_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int B, int n,
+int launch_attn_train_bwd(const void* qkv, const void* out, const void* dout, int adt, const float* lse, void* dqkv, int B, int n,
                           int heads, hipStream_t s) {
     // lse: [B*heads][2][n] -- the second half is this kernel's per-query scratch
-    attn_bwd_kernel<<<B * heads, 256, 0, s>>>(qkv, out, dout, lse, dqkv, const_cast<float*>(lse) + (size_t)B * heads * n, n, heads);
+    float* dsum = const_cast<float*>(lse) + (size_t)B * heads * n;
+    DMN_DISPATCH_T(adt, attn_bwd_kernel<T><<<B * heads, 256, 0, s>>>((const T*)qkv, (const T*)out, (const T*)dout, lse, (T*)dqkv, dsum, n, heads));
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }

@@ -37,14 +37,26 @@ def flat_layout(unet_cfg: "N.DmnUnetCfg", loss_kind: int = 1):
 
 
 class UnetTrainer:
-    def __init__(self, unet, loss_type: str = "l2", device=None):
+    def __init__(self, unet, loss_type: str = "l2", device=None, activations: Optional[str] = None):
+        """`unet.compute_dtype` selects the matrix-core operand type ('fp32' exact, 'bf16' rounded operands with fp32
+        accumulation). `activations` selects how the saved activations and their gradients are stored: 'fp32', or
+        'bf16' (only with bf16 operands; halves the workspace and the step's memory traffic at a wider gradient error
+        band; parameters, their gradients, statistics and the optimiser stay fp32). Default 'fp32': the kernels are
+        latency- rather than bandwidth-bound today, so the narrower storage buys memory, not time."""
         if loss_type not in LOSS_KINDS:
             raise ValueError("loss_type must be 'l1', 'l2' or 'huber'")
+        if activations is None:
+            activations = "fp32"
+        if activations not in ("fp32", "bf16") or (activations == "bf16" and unet.compute_dtype != "bf16"):
+            raise ValueError("activations must be 'fp32', or 'bf16' together with compute_dtype='bf16'")
+        self.activations = activations
         self.unet = unet
         self.device = torch.device(device) if device is not None else next(unet.parameters()).device
         lib = N.lib()
         h = C.c_void_p()
         cfg = unet._cfg()
+        if activations == "bf16":
+            cfg.dtype = 2
         N.check(lib.dmn_train_create(C.byref(cfg), LOSS_KINDS[loss_type], C.byref(h)))
         self._handle = h
         self.layout: Dict[str, tuple] = {}

@@ -141,8 +141,10 @@ int dmn_bench_dominant_kernel(DmnUnet* u, int B, int H, int W, int iters, void* 
  * Networks with out_dim == channels only. */
 typedef struct DmnTrainer DmnTrainer;
 /* loss_kind: 0 'l1', 1 'l2', 2 'huber' with reduction 'mean' (loss/simple_loss.py:37-45).
- * cfg->dtype selects the matrix-core operand type of the convolutions / linears: 0 exact float32, 1 operands rounded to
- * bfloat16 (float32 accumulate); activations, gradients, norms, attention and the optimiser stay float32 either way. */
+ * cfg->dtype: 0 exact float32 matrix cores and float32 activations (parity mode); 1 matrix-core operands rounded to
+ * bfloat16 (float32 accumulate), activations float32; 2 as 1 with the saved activations and their gradients STORED as
+ * bfloat16 (half the memory traffic). Parameters, parameter gradients, statistics, softmax and the optimiser are
+ * float32 in every mode. */
 int dmn_train_create(const DmnUnetCfg* cfg, int loss_kind, DmnTrainer** out);
 void dmn_train_destroy(DmnTrainer* tr);
 /* Class labels of the next steps (unet.py:134-141; ConditionalDDPM.get_diffusion_model, models/conditional_ddpm.py:51-67,

@@ -17,7 +17,7 @@ from oracle import ref_cpu as R  # noqa: E402
 from oracle.weights import make_state_dict, unet_param_shapes  # noqa: E402
 
 
-def build(dim=32, mults=(1, 2, 4, 8), groups=8, order="bn_act_conv", loss="l2", dtype="fp32"):
+def build(dim=32, mults=(1, 2, 4, 8), groups=8, order="bn_act_conv", loss="l2", dtype="fp32", activations=None):
     from diffusion_model_nemo_amd.modules import Unet
     from diffusion_model_nemo_amd.training import UnetTrainer
     u = Unet(input_dim=32, dim=dim, dim_mults=list(mults), channels=3, resnet_block_groups=groups, use_convnext=False,
@@ -25,7 +25,7 @@ def build(dim=32, mults=(1, 2, 4, 8), groups=8, order="bn_act_conv", loss="l2", 
     sd = make_state_dict(unet_param_shapes(dim=dim, dim_mults=mults, resnet_block_order=order))
     u.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     u = u.cuda()
-    return u, UnetTrainer(u, loss_type=loss), sd
+    return u, UnetTrainer(u, loss_type=loss, activations=activations), sd
 
 
 def oracle_grads(sd, x0, t, noise, dim=32, groups=8, loss="l2"):
@@ -131,11 +131,13 @@ def test_clip_and_adamw_match_torch_and_sampling_sees_the_update():
     assert float((got.cpu() - want).abs().max()) <= 5e-4
 
 
-def test_bf16_operand_mode_stays_close_to_fp32_gradients():
-    """bf16 matrix-core operands (fp32 accumulate, everything else fp32): loss within 2e-3 relative of the oracle and
-    every gradient tensor within 4e-2 of its largest entry with cosine similarity >= 0.995 (report-only band in the
-    spirit of the reference's own bf16-autocast deviation; the fp32 mode above is the parity mode)."""
-    u, tr, sd = build(dtype="bf16")
+@pytest.mark.parametrize("activations,rel_tol,cos_tol", [("fp32", 4e-2, 0.995), ("bf16", 1.5e-1, 0.97)])
+def test_bf16_modes_stay_close_to_fp32_gradients(activations, rel_tol, cos_tol):
+    """bf16 matrix-core operands (fp32 accumulate), with fp32 or bf16 STORAGE of the saved activations: loss within
+    2e-3 / 1e-2 relative of the oracle and every gradient tensor within rel_tol of its largest entry with cosine
+    similarity >= cos_tol (report-only bands in the spirit of the reference's own bf16-autocast deviation; the fp32
+    mode above is the parity mode)."""
+    u, tr, sd = build(dtype="bf16", activations=activations)
     gen = torch.Generator().manual_seed(9)
     x0 = torch.tanh(torch.randn(2, 3, 32, 32, generator=gen))
     noise = torch.randn(2, 3, 32, 32, generator=gen)
@@ -143,15 +145,15 @@ def test_bf16_operand_mode_stays_close_to_fp32_gradients():
     c = R.ddpm_constants(1000, "cosine")
     val, ref = oracle_grads(sd, x0, t, noise)
     got = tr.loss_and_grads(x0.cuda(), t.cuda(), noise.cuda(), c["sqrt_alphas_cumprod"], c["sqrt_one_minus_alphas_cumprod"])
-    assert abs(float(got) - val) <= 2e-3 * abs(val), (float(got), val)
+    assert abs(float(got) - val) <= (2e-3 if activations == "fp32" else 1e-2) * abs(val), (float(got), val)
     worst_rel, worst_cos = 0.0, 1.0
     for name, g in ref.items():
         mine = tr.grad_of(name).cpu()
         rel = float((mine - g).abs().max()) / (float(g.abs().max()) + 1e-30)
         cos = float((mine * g).sum() / (mine.norm() * g.norm() + 1e-30))
         worst_rel, worst_cos = max(worst_rel, rel), min(worst_cos, cos)
-        assert rel <= 4e-2 and cos >= 0.995, (name, rel, cos)
-    print("bf16 operands: worst relative error", worst_rel, "worst cosine", worst_cos)
+        assert rel <= rel_tol and cos >= cos_tol, (name, rel, cos)
+    print("bf16 operands,", activations, "activations: worst relative error", worst_rel, "worst cosine", worst_cos)
 
 
 def test_class_conditional_gradients_match_oracle_and_null_row_stays_frozen():

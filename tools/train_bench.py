@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"], help="matrix-core operand type")
+    ap.add_argument("--activations", default=None, choices=["bf16", "fp32"], help="storage of saved activations")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -33,7 +34,7 @@ def main():
     torch.manual_seed(1234)
     u = Unet(input_dim=a.size, dim=32, dim_mults=[1, 2, 4, 8], channels=3, resnet_block_groups=8, use_convnext=False,
              dropout=0.0, compute_dtype=a.dtype).cuda()
-    tr = UnetTrainer(u, "l2")
+    tr = UnetTrainer(u, "l2", activations=a.activations)
     gd = GaussianDiffusion(timesteps=1000, schedule_name="cosine")
     sa = gd.sqrt_alphas_cumprod.cuda()
     sb = gd.sqrt_one_minus_alphas_cumprod.cuda()
@@ -65,7 +66,7 @@ def main():
     if int(os.environ.get("RANK", "0")) == 0:
         print(json.dumps({"metric": "images/sec, DDPM training step", "value": a.batch * world / dt, "unit": "images/sec",
                           "n_gpus": world, "ms_per_step": dt * 1e3, "batch_per_gpu": a.batch, "size": a.size,
-                          "tflops_per_gpu": a.batch * flop_img / dt / 1e12, "dtype": "bf16 operands, f32 accumulate/activations" if a.dtype == "bf16" else "f32", "loss": float(loss)}))
+                          "tflops_per_gpu": a.batch * flop_img / dt / 1e12, "dtype": {"fp32": "f32", "bf16": "bf16 operands, f32 accumulate, %s activations" % tr.activations}[a.dtype], "loss": float(loss)}))
     if world > 1:
         dist.destroy_process_group()
 
