@@ -56,7 +56,7 @@ SIGNATURES = {
     "dmn_train_flat_size": (_i64, [_vp]),
     "dmn_train_tensor_info": (_i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(_i64), C.POINTER(_i), C.POINTER(_i64 * 4)]),
     "dmn_train_workspace_bytes": (_i, [_vp, _i, _i, _i, C.POINTER(_sz)]),
-    "dmn_train_loss_and_grads": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "dmn_train_loss_and_grads": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "dmn_adamw_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _f, _vp, _vp]),
     "dmn_fill_normal": (_i, [_vp, _i, _i, _u64, C.c_uint32, _i64, _f, _vp]),
     "dmn_test_set_conv_debug": (_i, [_vp]),

@@ -612,6 +612,7 @@ struct StepIO {
     const float *x0, *noise;
     const long long* t;
     const float *sa, *sb;
+    int n_timesteps;
     float* loss;
     float* model_out;
 };
@@ -678,7 +679,7 @@ int run_step(DmnTrainer* tr, const float* params, float* grads, const StepIO& io
     // inputs
     Ten* xt = r.nt(c.channels, H, W, r.img_adt);
     Ten* tgt = r.nt(c.channels, H, W, 0);
-    RUN(r, launch_train_ingest(io.x0, io.noise, io.t, io.sa, io.sb, xt->p, xt->adt, (float*)tgt->p, B, c.channels, H, W, s));
+    RUN(r, launch_train_ingest(io.x0, io.noise, io.t, io.sa, io.sb, io.n_timesteps, xt->p, xt->adt, (float*)tgt->p, B, c.channels, H, W, s));
     // time path (modules/unet.py:61-66, parts/convnext.py:68-72,81-83)
     Ten* emb = r.nt(c.dim, 1, 1, 0);
     RUN(r, launch_sinus(io.t, 0, B, c.dim, (float*)emb->p, s));
@@ -817,17 +818,19 @@ extern "C" int dmn_train_workspace_bytes(DmnTrainer* tr, int B, int H, int W, si
 }
 
 extern "C" int dmn_train_loss_and_grads(DmnTrainer* tr, const float* params, float* grads, const float* x0, const float* noise,
-                                        const int64_t* t, const float* sqrt_acp, const float* sqrt_1m_acp, int B, int H, int W,
-                                        float* loss, float* model_out, void* workspace, size_t workspace_bytes, void* stream) {
+                                        const int64_t* t, const float* sqrt_acp, const float* sqrt_1m_acp, int n_timesteps, int B,
+                                        int H, int W, float* loss, float* model_out, void* workspace, size_t workspace_bytes, void* stream) {
     DMN_REQUIRE(tr && params && grads && x0 && noise && t && loss && workspace, DMN_ERR_INVALID,
                 "dmn_train_loss_and_grads: null argument");
     DMN_REQUIRE((sqrt_acp == nullptr) == (sqrt_1m_acp == nullptr), DMN_ERR_INVALID, "schedule tables: both or neither");
+    DMN_REQUIRE(sqrt_acp == nullptr || n_timesteps >= 1, DMN_ERR_INVALID, "n_timesteps=%d", n_timesteps);
     StepIO io;
     io.x0 = x0;
     io.noise = noise;
     io.t = reinterpret_cast<const long long*>(t);
     io.sa = sqrt_acp;
     io.sb = sqrt_1m_acp;
+    io.n_timesteps = n_timesteps;
     io.loss = loss;
     io.model_out = model_out;
     return run_step(tr, params, grads, io, B, H, W, workspace, workspace_bytes, (hipStream_t)stream, false, nullptr);

@@ -92,8 +92,9 @@ int launch_sinus(const void* t, int t_is_float, int B, int dim, float* out, hipS
 
 // x_t = a[t_b] x0 + b[t_b] eps (a, b null: x_t = x0) from NCHW float32 to NHWC in the activation type, and eps to NHWC
 // float32 as the target.
-int launch_train_ingest(const float* x0, const float* eps, const long long* t, const float* sa, const float* sb, void* xt, int adt,
-                        float* tgt, int B, int C, int H, int W, hipStream_t s);
+// Labels are clamped to [0, n_timesteps).
+int launch_train_ingest(const float* x0, const float* eps, const long long* t, const float* sa, const float* sb, int n_timesteps,
+                        void* xt, int adt, float* tgt, int B, int C, int H, int W, hipStream_t s);
 // loss (+= into a zeroed scalar) of DiffusionLoss with reduction 'mean' (loss/simple_loss.py:37-45): kind 0 l1,
 // 1 l2, 2 huber (smooth_l1, beta 1); dout = d loss / d out. out, tgt, dout: [n] in the same (NHWC) order.
 int launch_loss(const void* out, const float* tgt, int adt, long long n, int kind, float* loss, void* dout, hipStream_t s);

@@ -268,7 +268,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void class_bias_fwd_kernel(T* __restrict__ x, const float* __restrict__ table,
                                                              const long long* __restrict__ labels, int pad, int HW, int C) {
     const int b = blockIdx.y;
-    const long long row = labels ? labels[b] : pad;
+    const long long row = labels ? min(max(labels[b], 0ll), (long long)pad) : pad;
     const float* e = table + row * C;
     T* xb = x + (size_t)b * HW * C;
     const long long total = (long long)HW * C;
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void class_bias_bwd_kernel(const T* __restrict
                                                              float* __restrict__ dtable, int HW, int C) {
     __shared__ float sh[256];
     const int b = blockIdx.y, tid = threadIdx.x;
-    const long long row = labels ? labels[b] : pad;
+    const long long row = labels ? min(max(labels[b], 0ll), (long long)pad) : pad;
     if (row == pad) return;
     const int c = tid % C, pl = tid / C, npl = 256 / C;
     float acc = 0.f;
@@ -312,7 +312,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void train_ingest_kernel(const float* __restrict__ x0, const float* __restrict__ eps,
                                                            const long long* __restrict__ t, const float* __restrict__ sa,
                                                            const float* __restrict__ sb, T* __restrict__ xt, float* __restrict__ tgt,
-                                                           int B, int C, int HW) {
+                                                           int B, int C, int HW, int nT) {
     const long long total = (long long)B * C * HW;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         // i indexes NHWC
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void train_ingest_kernel(const float* __restri
         const float e = eps ? eps[src] : 0.f;
         float v = x0[src];
         if (sa) {
-            const long long tb = t[b];
+            const long long tb = min(max(t[b], 0ll), (long long)nT - 1);   // an out-of-range label must not read outside the tables
             v = sa[tb] * v + sb[tb] * e;
         }
         Io<T>::st(xt + i, v);
@@ -1000,10 +1000,10 @@ int launch_sinus(const void* t, int t_is_float, int B, int dim, float* out, hipS
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }
-int launch_train_ingest(const float* x0, const float* eps, const long long* t, const float* sa, const float* sb, void* xt, int adt,
-                        float* tgt, int B, int C, int H, int W, hipStream_t s) {
+int launch_train_ingest(const float* x0, const float* eps, const long long* t, const float* sa, const float* sb, int n_timesteps,
+                        void* xt, int adt, float* tgt, int B, int C, int H, int W, hipStream_t s) {
     DMN_DISPATCH_T(adt, train_ingest_kernel<T><<<grid_for((long long)B * C * H * W, 1024), 256, 0, s>>>(x0, eps, t, sa, sb, (T*)xt, tgt, B,
-                                                                                                         C, H * W));
+                                                                                                         C, H * W, n_timesteps));
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }

@@ -158,11 +158,12 @@ int dmn_train_tensor_info(const DmnTrainer* tr, int idx, const char** name, int6
 int dmn_train_workspace_bytes(DmnTrainer* tr, int B, int H, int W, size_t* bytes);
 /* x_t = sqrt_acp[t] x0 + sqrt_1m_acp[t] noise (gaussian_diffusion.py:104-116; both tables NULL: x_t = x0),
  * out = Unet(x_t, t), *loss = DiffusionLoss(out, noise), grads = d loss / d params (overwritten, not accumulated).
- * x0, noise: device [B][C][H][W]; t: device int64 [B]; tables: device float32 [T]; loss: device scalar;
+ * x0, noise: device [B][C][H][W]; t: device int64 [B] (clamped to [0, n_timesteps) for the table look-up; the network
+ * sees it as given); tables: device float32 [n_timesteps]; loss: device scalar;
  * model_out: optional device [B][C][H][W]. workspace: 256-byte aligned, >= dmn_train_workspace_bytes. */
 int dmn_train_loss_and_grads(DmnTrainer* tr, const float* params, float* grads, const float* x0, const float* noise,
-                             const int64_t* t, const float* sqrt_acp, const float* sqrt_1m_acp, int B, int H, int W,
-                             float* loss, float* model_out, void* workspace, size_t workspace_bytes, void* stream);
+                             const int64_t* t, const float* sqrt_acp, const float* sqrt_1m_acp, int n_timesteps, int B, int H,
+                             int W, float* loss, float* model_out, void* workspace, size_t workspace_bytes, void* stream);
 /* torch.nn.utils.clip_grad_norm_(max_norm) (max_norm <= 0: off) followed by one torch.optim.AdamW step on flat
  * buffers, all on the device (no host read of the norm). grads are multiplied by grad_scale first (1/world_size after
  * a summing all-reduce). step counts from 1. scratch: device, >= 4 bytes. */
