@@ -100,12 +100,62 @@ __device__ __forceinline__ void tile_stats(const float (&s1)[BN / 16], const flo
     }
 }
 
+// Output tile of a pixel GEMM, 64 pixels x BN channels: the accumulators (+ bias) go through LDS so that every thread
+// writes (and, when accumulating, first reads) ONE 16-byte piece of a pixel's channel row -- whole cache lines per
+// pixel instead of a 4- or 2-byte element per lane. Es: 64 * (BN + 4) floats that nothing else uses any more.
+// rowptr(p): output row of tile pixel p, or null. Also returns the per-lane statistics sums of the biased values.
+template <typename T, int BN, typename RowPtr>
+__device__ __forceinline__ void store_tile(float* Es, const f32x4 (&acc)[BN / 16], const float* bias, int accumulate, int n0, int N,
+                                           RowPtr rowptr, float (&s1)[BN / 16], float (&s2)[BN / 16]) {
+    constexpr int LDE = BN + 4, V = Io<T>::VEC, PER_ROW = BN / V;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < BN / 16; ++j) {
+        const int n = n0 + 16 * j + r;
+        const float bv = (bias && n < N) ? bias[n] : 0.f;
+        s1[j] = s2[j] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float v = acc[j][i] + bv;
+            Es[(16 * wave + 4 * q + i) * LDE + 16 * j + r] = v;
+            if (n < N) {
+                s1[j] += v;
+                s2[j] += v * v;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < (64 * PER_ROW + 255) / 256; ++k) {
+        const int idx = tid + 256 * k;
+        if (idx >= 64 * PER_ROW) break;
+        const int p = idx / PER_ROW, cv = (idx - p * PER_ROW) * V;
+        T* o = rowptr(p);
+        if (!o || n0 + cv >= N) continue;
+        float v[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) v[e] = Es[p * LDE + cv + e];
+        if (accumulate) {
+            float old[V];
+            Io<T>::ldv(o + n0 + cv, old);
+#pragma unroll
+            for (int e = 0; e < V; ++e) v[e] += old[e];
+        }
+        Io<T>::stv(o + n0 + cv, v);
+    }
+    __syncthreads();
+}
+// whether the vector epilogue applies: channel rows made of whole 16-byte pieces
+template <typename T> __device__ __forceinline__ bool tile_store_ok(const PGemmArgs& a) {
+    return (a.N % Io<T>::VEC) == 0 && (a.ldout % Io<T>::VEC) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
+}
+
 template <typename T, int BN, bool SLOW, bool BF>
 __global__ __launch_bounds__(256) void pgemm_kernel(const PGemmArgs a, const int M, const int pm) {
     const T* in = reinterpret_cast<const T*>(a.in);
     T* out = reinterpret_cast<T*>(a.out);
     constexpr int LDB = BN + 4, NJ = BN / 16, TPR = BN / 4, RPP = 256 / TPR, NB = 32 / RPP;
-    __shared__ float Bs[32 * LDB];
+    __shared__ float Bs[64 * LDB];   // weight tile (32 rows) during the loop, the output tile (64 rows) afterwards
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
     const int m0 = blockIdx.x * 64, n0 = blockIdx.y * BN;
     const int mA = m0 + 16 * wave + r;
@@ -218,6 +268,21 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const PGemmArgs a, const int
 
     // D[4q + i][r]: output pixel 16*wave + 4q + i of the tile, output channel 16j + r
     float s1[NJ], s2[NJ];
+    if (tile_store_ok<T>(a)) {
+        store_tile<T, BN>(Bs, acc, a.bias, a.accumulate, n0, a.N, [&](int p) -> T* {
+            const int m = m0 + p;
+            if (m >= M) return nullptr;
+            size_t pl = (size_t)m;
+            if (pm) {
+                int b, oy, ox;
+                decode_m(m, a.Ho, a.Wo, pm, b, oy, ox);
+                pl = (size_t)(b * a.Ho + oy) * a.Wo + ox;
+            }
+            return out + pl * a.ldout;
+        }, s1, s2);
+        if (a.stats) tile_stats<BN>(s1, s2, Bs, n0, a.N, a.N / a.statsG, a.stats + (size_t)(m0 / (a.Ho * a.Wo)) * a.statsG * 2);
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) s1[j] = s2[j] = 0.f;
 #pragma unroll
@@ -257,7 +322,7 @@ __global__ __launch_bounds__(256) void pgemm_halo_kernel(const PGemmArgs a) {
     constexpr int LDB = BN + 4, NJ = BN / 16, TPR = BN / 4, RPP = 256 / TPR, NB = 32 / RPP, LDH = 36;
     // one stage = the three taps of a kernel row for 32 channels: three weight tiles in flight per round trip, a third of
     // the barriers, and the next chunk's halo rides along with the last row of the current one
-    __shared__ float Bs[3 * 32 * LDB];
+    __shared__ float Bs[3 * 32 * LDB];   // >= 64 * LDB: doubles as the output tile of the epilogue
     __shared__ float Hs[100 * LDH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
     const int tw = a.Wo >> 3, th = a.Ho >> 3;
@@ -361,6 +426,13 @@ __global__ __launch_bounds__(256) void pgemm_halo_kernel(const PGemmArgs a) {
         __syncthreads();
     }
     float s1[NJ], s2[NJ];
+    if (tile_store_ok<T>(a)) {
+        store_tile<T, BN>(Bs, acc, a.bias, a.accumulate, n0, a.N, [&](int p) -> T* {
+            return out + ((size_t)(b * a.Ho + oy0 + (p >> 3)) * a.Wo + ox0 + (p & 7)) * a.ldout;
+        }, s1, s2);
+        if (a.stats) tile_stats<BN>(s1, s2, Bs, n0, a.N, a.N / a.statsG, a.stats + (size_t)b * a.statsG * 2);
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) s1[j] = s2[j] = 0.f;
 #pragma unroll

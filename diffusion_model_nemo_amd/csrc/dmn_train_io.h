@@ -9,6 +9,13 @@ template <> struct Io<float> {
     static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
     static __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
     static __device__ __forceinline__ void st4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
+    // one 16-byte access: VEC elements
+    static constexpr int VEC = 4;
+    static __device__ __forceinline__ void ldv(const float* p, float* v) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+    }
+    static __device__ __forceinline__ void stv(float* p, const float* v) { *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]}; }
 };
 template <> struct Io<__bf16> {
     static __device__ __forceinline__ float ld(const __bf16* p) { return (float)*p; }
@@ -24,6 +31,18 @@ template <> struct Io<__bf16> {
         o[2] = (__bf16)v[2];
         o[3] = (__bf16)v[3];
         *reinterpret_cast<bf16x4*>(p) = o;
+    }
+    static constexpr int VEC = 8;
+    static __device__ __forceinline__ void ldv(const __bf16* p, float* v) {
+        const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
+    }
+    static __device__ __forceinline__ void stv(__bf16* p, const float* v) {
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (__bf16)v[i];
+        *reinterpret_cast<bf16x8*>(p) = o;
     }
 };
 
