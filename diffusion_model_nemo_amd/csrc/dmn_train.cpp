@@ -6,6 +6,7 @@
 // backward closures over the kernels of dmn_train.h. Parameters and gradients live in ONE flat float32 buffer each, in
 // the reference's per-tensor layouts (so state_dicts interchange and one RCCL all-reduce covers all gradients); the
 // GEMM-ordered copies the kernels consume are rebuilt from it at the start of every step.
+#include <stdlib.h>
 #include <string.h>
 
 #include <cmath>
@@ -76,6 +77,13 @@ struct DmnTrainer {
     const long long* labels = nullptr;    // borrowed device labels of the coming steps
     int tb_total = 0;
     long long tb_bias_off = 0;   // the per-block time-linear biases are consecutive in the flat buffer
+    // The weight-gradient kernels depend on nothing but their convolution's output gradient and feed nothing but the
+    // final layout change, so they run on a second stream beside the chain of input-gradient kernels: one event from
+    // the main stream per launch, one join at the end of the step.
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> events;
+    hipEvent_t join = nullptr;
+    int use_side = 1;
     // workspace region sizes of the last shape
     int sz_B = 0, sz_H = 0, sz_W = 0;
     size_t sz_zero = 0, sz_arena = 0, sz_total = 0;
@@ -311,6 +319,21 @@ struct Run {
     float *wf, *wb, *dwf;
     std::vector<std::function<void()>> tape;
     std::deque<Ten> tens;
+    size_t ev_next = 0;
+    bool side_used = false;
+    // stream for a weight-gradient launch whose inputs the main stream has produced by now
+    hipStream_t wgrad_stream() {
+        if (!tr->use_side || !tr->side || dry || rc != DMN_OK) return s;
+        if (ev_next >= tr->events.size()) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return s;
+            tr->events.push_back(e);
+        }
+        hipEvent_t e = tr->events[ev_next++];
+        if (hipEventRecord(e, s) != hipSuccess || hipStreamWaitEvent(tr->side, e, 0) != hipSuccess) return s;
+        side_used = true;
+        return tr->side;
+    }
 
     void fail_ws() {
         if (rc == DMN_OK) {
@@ -427,7 +450,7 @@ Ten* conv(Run& r, Ten* x, const ConvP& w, bool need_dx = true, const float* bias
         g.bf16 = r.bf16;
         g.adt = x->adt;
         g.dbias = dbias;
-        RUN(r, launch_wgemm(g, r.s));
+        RUN(r, launch_wgemm(g, r.wgrad_stream()));
         if (need_dx) {
             PGemmArgs d;
             memset(&d, 0, sizeof(d));
@@ -654,6 +677,10 @@ int run_step(DmnTrainer* tr, const float* params, float* grads, const StepIO& io
         DMN_REQUIRE(ws_bytes >= tr->sz_total, DMN_ERR_WORKSPACE, "training workspace: %zu bytes given, %zu needed", ws_bytes,
                     tr->sz_total);
         DMN_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, DMN_ERR_INVALID, "training workspace must be 256-byte aligned");
+        if (!tr->side && tr->use_side) {
+            DMN_HIP_CHECK(hipStreamCreateWithFlags(&tr->side, hipStreamNonBlocking));
+            DMN_HIP_CHECK(hipEventCreateWithFlags(&tr->join, hipEventDisableTiming));
+        }
         if (!tr->descs_dev) {   // first step on the device: upload the layout table (creation itself needs no GPU)
             DMN_HIP_CHECK(hipMalloc((void**)&tr->descs_dev, tr->descs.size() * sizeof(RepackDesc)));
             DMN_HIP_CHECK(hipMemcpy(tr->descs_dev, tr->descs.data(), tr->descs.size() * sizeof(RepackDesc), hipMemcpyHostToDevice));
@@ -736,6 +763,10 @@ int run_step(DmnTrainer* tr, const float* params, float* grads, const StepIO& io
     if (io.model_out) RUN(r, launch_nhwc_to_nchw(out->p, out->adt, io.model_out, B, c.out_dim, H * W, s));
 
     for (size_t i = r.tape.size(); i-- > 0;) r.tape[i]();
+    if (r.side_used) {   // the layout change below reads what the side stream's kernels accumulated
+        DMN_HIP_CHECK(hipEventRecord(tr->join, tr->side));
+        DMN_HIP_CHECK(hipStreamWaitEvent(s, tr->join, 0));
+    }
     RUN(r, launch_unpack_grads(tr->descs_dev, (int)tr->descs.size(), tr->max_numel, r.dwf, grads, s));
 
     if (dry && sz) {
@@ -769,6 +800,7 @@ extern "C" int dmn_train_create(const DmnUnetCfg* cfg, int loss_kind, DmnTrainer
     DmnTrainer* tr = new DmnTrainer();
     tr->cfg = *cfg;
     tr->loss_kind = loss_kind;
+    if (const char* e = getenv("DMN_TRAIN_SIDE_STREAM")) tr->use_side = atoi(e) != 0;   // tuning aid: 0 keeps one stream
     int rc = build_structure(tr);
     if (rc) {
         delete tr;
@@ -782,6 +814,9 @@ extern "C" int dmn_train_create(const DmnUnetCfg* cfg, int loss_kind, DmnTrainer
 extern "C" void dmn_train_destroy(DmnTrainer* tr) {
     if (!tr) return;
     if (tr->descs_dev) (void)hipFree(tr->descs_dev);
+    for (hipEvent_t e : tr->events) (void)hipEventDestroy(e);
+    if (tr->join) (void)hipEventDestroy(tr->join);
+    if (tr->side) (void)hipStreamDestroy(tr->side);
     delete tr;
 }
 
