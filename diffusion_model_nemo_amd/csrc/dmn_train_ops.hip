@@ -740,102 +740,120 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     }
 }
 
-// dq (thread = query) then dk, dv (thread = key). Dsh: per-query sum_e dout*out kept in global scratch `dsum`
-// ([B*heads][n], the tail of the lse allocation is not used for this: the caller passes a separate buffer).
+// Backward of the softmax attention in two launches on a grid (image * head, blocks of 64 rows): thread (row = tid & 63,
+// part = tid >> 6) owns one query (first launch: dq and the per-query sum_e dout*out) or one key (second launch:
+// dk, dv) and a quarter (16 of every staged 64) of the other side; the four partial rows are added through LDS.
 template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
-                                                       const T* __restrict__ dout, const float* __restrict__ lse,
-                                                       T* __restrict__ dqkv, float* __restrict__ dsum, int n, int heads) {
-    __shared__ float As[64 * 33], Bs[64 * 33], Ls[64], Ds[64];
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ out, const T* __restrict__ dout,
+                                                          const float* __restrict__ lse, T* __restrict__ dqkv, float* __restrict__ dsum,
+                                                          int n, int heads) {
+    __shared__ float As[64 * 33], Bs[64 * 33], red[4 * 64 * 33];
     const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads, tid = threadIdx.x;
+    const int row = tid & 63, part = tid >> 6;
     const int hid = heads * kD, ld = 3 * hid;
     const T* base = qkv + (size_t)b * n * ld;
     const T* ob = out + (size_t)b * n * hid;
     const T* dob = dout + (size_t)b * n * hid;
-    T* dqb = dqkv + (size_t)b * n * ld;
-    // phase 1: dq
-    for (int i0 = 0; i0 < n; i0 += 256) {
-        const int i = i0 + tid;
-        const bool ok = i < n;
-        float qv[32], dov[32], dq[32], Di = 0.f;
-        const float li = ok ? lse[(size_t)bh * n + i] : 0.f;
+    const int i = blockIdx.y * 64 + row;
+    const bool ok = i < n;
+    float qv[32], dov[32], dq[32], Di = 0.f;
+    const float li = ok ? lse[(size_t)bh * n + i] : 0.f;
 #pragma unroll
-        for (int d = 0; d < 32; ++d) {
-            qv[d] = ok ? Io<T>::ld(base + (size_t)i * ld + h * kD + d) * kScale : 0.f;
-            dov[d] = ok ? Io<T>::ld(dob + (size_t)i * hid + h * kD + d) : 0.f;
-            Di += dov[d] * (ok ? Io<T>::ld(ob + (size_t)i * hid + h * kD + d) : 0.f);
-            dq[d] = 0.f;
-        }
-        if (ok) dsum[(size_t)bh * n + i] = Di;
-        for (int j0 = 0; j0 < n; j0 += 64) {
-            __syncthreads();
-            load_tile(As, base, ld, hid + h * kD, j0, n, tid, 0.f);
-            load_tile(Bs, base, ld, 2 * hid + h * kD, j0, n, tid, 0.f);
-            __syncthreads();
-            const int jn = min(64, n - j0);
-            for (int j = 0; j < jn; ++j) {
-                float sc = 0.f, dp = 0.f;
-#pragma unroll
-                for (int d = 0; d < 32; ++d) {
-                    sc += qv[d] * As[j * 33 + d];
-                    dp += dov[d] * Bs[j * 33 + d];
-                }
-                const float ds = expf(sc - li) * (dp - Di);
-#pragma unroll
-                for (int d = 0; d < 32; ++d) dq[d] += ds * As[j * 33 + d];
-            }
-        }
-        if (ok) {
-            T* row = dqb + (size_t)i * ld + h * kD;
-#pragma unroll
-            for (int d = 0; d < 32; ++d) Io<T>::st(row + d, dq[d] * kScale);
-        }
+    for (int d = 0; d < 32; ++d) {
+        qv[d] = ok ? Io<T>::ld(base + (size_t)i * ld + h * kD + d) * kScale : 0.f;
+        dov[d] = ok ? Io<T>::ld(dob + (size_t)i * hid + h * kD + d) : 0.f;
+        Di += dov[d] * (ok ? Io<T>::ld(ob + (size_t)i * hid + h * kD + d) : 0.f);
+        dq[d] = 0.f;
     }
-    __threadfence_block();
-    // phase 2: dk, dv
-    for (int j0 = 0; j0 < n; j0 += 256) {
-        const int j = j0 + tid;
-        const bool ok = j < n;
-        float kv[32], vv[32], dk[32], dv[32];
-#pragma unroll
-        for (int d = 0; d < 32; ++d) {
-            kv[d] = ok ? Io<T>::ld(base + (size_t)j * ld + hid + h * kD + d) : 0.f;
-            vv[d] = ok ? Io<T>::ld(base + (size_t)j * ld + 2 * hid + h * kD + d) : 0.f;
-            dk[d] = dv[d] = 0.f;
-        }
-        for (int i0 = 0; i0 < n; i0 += 64) {
-            __syncthreads();
-            load_tile(As, base, ld, h * kD, i0, n, tid, 0.f);     // q (unscaled)
-            load_tile(Bs, dob, hid, h * kD, i0, n, tid, 0.f);    // dout
-            if (tid < 64) {
-                const bool in = i0 + tid < n;
-                Ls[tid] = in ? lse[(size_t)bh * n + i0 + tid] : 0.f;
-                Ds[tid] = in ? dsum[(size_t)bh * n + i0 + tid] : 0.f;
-            }
-            __syncthreads();
-            const int in_ = min(64, n - i0);
-            for (int i = 0; i < in_; ++i) {
-                float sc = 0.f, dp = 0.f;
-#pragma unroll
-                for (int d = 0; d < 32; ++d) {
-                    sc += As[i * 33 + d] * kv[d];
-                    dp += Bs[i * 33 + d] * vv[d];
-                }
-                const float pij = expf(sc * kScale - Ls[i]);
-                const float ds = pij * (dp - Ds[i]) * kScale;
-#pragma unroll
-                for (int d = 0; d < 32; ++d) {
-                    dv[d] += pij * Bs[i * 33 + d];
-                    dk[d] += ds * As[i * 33 + d];
-                }
-            }
-        }
-        if (ok) {
-            T* row = dqb + (size_t)j * ld + hid + h * kD;
+    if (ok && part == 0) dsum[(size_t)bh * n + i] = Di;
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        __syncthreads();
+        load_tile(As, base, ld, hid + h * kD, j0, n, tid, 0.f);
+        load_tile(Bs, base, ld, 2 * hid + h * kD, j0, n, tid, 0.f);
+        __syncthreads();
+        const int jn = min(64, n - j0);
+        for (int j = 16 * part; j < min(jn, 16 * part + 16); ++j) {
+            float sc = 0.f, dp = 0.f;
 #pragma unroll
             for (int d = 0; d < 32; ++d) {
-                Io<T>::st(row + d, dk[d]);
-                Io<T>::st(row + hid + d, dv[d]);
+                sc += qv[d] * As[j * 33 + d];
+                dp += dov[d] * Bs[j * 33 + d];
+            }
+            const float ds = expf(sc - li) * (dp - Di);
+#pragma unroll
+            for (int d = 0; d < 32; ++d) dq[d] += ds * As[j * 33 + d];
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 32; ++d) red[(part * 64 + row) * 33 + d] = dq[d];
+    __syncthreads();
+    if (ok && part == 0) {
+        T* orow = dqkv + ((size_t)b * n + i) * ld + h * kD;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) {
+            const float v = (red[row * 33 + d] + red[(64 + row) * 33 + d]) + (red[(128 + row) * 33 + d] + red[(192 + row) * 33 + d]);
+            Io<T>::st(orow + d, v * kScale);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, const float* __restrict__ lse,
+                                                           const float* __restrict__ dsum, T* __restrict__ dqkv, int n, int heads) {
+    __shared__ float As[64 * 33], Bs[64 * 33], Ls[64], Ds[64], red[4 * 64 * 33];
+    const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads, tid = threadIdx.x;
+    const int row = tid & 63, part = tid >> 6;
+    const int hid = heads * kD, ld = 3 * hid;
+    const T* base = qkv + (size_t)b * n * ld;
+    const T* dob = dout + (size_t)b * n * hid;
+    const int j = blockIdx.y * 64 + row;
+    const bool ok = j < n;
+    float kv[32], vv[32], dk[32], dv[32];
+#pragma unroll
+    for (int d = 0; d < 32; ++d) {
+        kv[d] = ok ? Io<T>::ld(base + (size_t)j * ld + hid + h * kD + d) : 0.f;
+        vv[d] = ok ? Io<T>::ld(base + (size_t)j * ld + 2 * hid + h * kD + d) : 0.f;
+        dk[d] = dv[d] = 0.f;
+    }
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        __syncthreads();
+        load_tile(As, base, ld, h * kD, i0, n, tid, 0.f);     // q (unscaled)
+        load_tile(Bs, dob, hid, h * kD, i0, n, tid, 0.f);    // dout
+        if (tid < 64) {
+            const bool in = i0 + tid < n;
+            Ls[tid] = in ? lse[(size_t)bh * n + i0 + tid] : 0.f;
+            Ds[tid] = in ? dsum[(size_t)bh * n + i0 + tid] : 0.f;
+        }
+        __syncthreads();
+        const int in_ = min(64, n - i0);
+        for (int i = 16 * part; i < min(in_, 16 * part + 16); ++i) {
+            float sc = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) {
+                sc += As[i * 33 + d] * kv[d];
+                dp += Bs[i * 33 + d] * vv[d];
+            }
+            const float pij = expf(sc * kScale - Ls[i]);
+            const float ds = pij * (dp - Ds[i]) * kScale;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) {
+                dv[d] += pij * Bs[i * 33 + d];
+                dk[d] += ds * As[i * 33 + d];
+            }
+        }
+    }
+    T* orow = dqkv + ((size_t)b * n + j) * ld + hid + h * kD;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();
+#pragma unroll
+        for (int d = 0; d < 32; ++d) red[(part * 64 + row) * 33 + d] = pass == 0 ? dk[d] : dv[d];
+        __syncthreads();
+        if (ok && part == 0) {
+#pragma unroll
+            for (int d = 0; d < 32; ++d) {
+                const float v = (red[row * 33 + d] + red[(64 + row) * 33 + d]) + (red[(128 + row) * 33 + d] + red[(192 + row) * 33 + d]);
+                Io<T>::st(orow + pass * hid + d, v);
             }
         }
     }
@@ -1060,9 +1078,12 @@ int launch_attn_train_fwd(const void* qkv, void* out, int adt, float* lse, int B
 }
 int launch_attn_train_bwd(const void* qkv, const void* out, const void* dout, int adt, const float* lse, void* dqkv, int B, int n,
                           int heads, hipStream_t s) {
-    // lse: [B*heads][2][n] -- the second half is this kernel's per-query scratch
+    // lse: [B*heads][2][n] -- the second half holds the per-query sums between the two launches
     float* dsum = const_cast<float*>(lse) + (size_t)B * heads * n;
-    DMN_DISPATCH_T(adt, attn_bwd_kernel<T><<<B * heads, 256, 0, s>>>((const T*)qkv, (const T*)out, (const T*)dout, lse, (T*)dqkv, dsum, n, heads));
+    const dim3 grid(B * heads, (n + 63) / 64);
+    DMN_DISPATCH_T(adt, attn_bwd_dq_kernel<T><<<grid, 256, 0, s>>>((const T*)qkv, (const T*)out, (const T*)dout, lse, (T*)dqkv, dsum, n, heads));
+    DMN_LAUNCH_CHECK();
+    DMN_DISPATCH_T(adt, attn_bwd_dkv_kernel<T><<<grid, 256, 0, s>>>((const T*)qkv, (const T*)dout, lse, dsum, (T*)dqkv, n, heads));
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }
