@@ -377,9 +377,9 @@ constexpr float kScale = 0.17677669529663687f;   // 32^-0.5
 
 // softmax over the 32 channels of q for 64 pixels staged in LDS rows of 33 floats: thread (p = tid>>2, part = tid&3)
 // owns channels 8*part..+7; afterwards Qs holds the UNSCALED softmax.
-__device__ __forceinline__ void softmax_q_rows(float* Qs, int tid) {
+template <int LD = 33> __device__ __forceinline__ void softmax_q_rows(float* Qs, int tid) {
     const int p = tid >> 2, part = tid & 3;
-    float* row = Qs + p * 33 + 8 * part;
+    float* row = Qs + p * LD + 8 * part;
     float mx = row[0];
 #pragma unroll
     for (int i = 1; i < 8; ++i) mx = fmaxf(mx, row[i]);
@@ -399,12 +399,28 @@ __device__ __forceinline__ void softmax_q_rows(float* Qs, int tid) {
 }
 
 // loads a [64 pixels][32] slice (channel offset coff of the row) into LDS rows of 33 floats; pixels >= n become `fill`
-template <typename T>
+template <typename T, int LD = 33>
 __device__ __forceinline__ void load_tile(float* S, const T* base, int ld, int coff, int p0, int n, int tid, float fill) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int idx = tid + 256 * i, p = idx >> 5, d = idx & 31;
-        S[p * 33 + d] = (p0 + p < n) ? Io<T>::ld(base + (size_t)(p0 + p) * ld + coff + d) : fill;
+        S[p * LD + d] = (p0 + p < n) ? Io<T>::ld(base + (size_t)(p0 + p) * ld + coff + d) : fill;
+    }
+}
+
+// C[d][e] += sum over the 64 staged pixels of A[p][d] * B[p][e] on the matrix cores (exact fp32): wave w owns the
+// 16x16 block (w >> 1, w & 1); row pitch 48 floats keeps the operand reads of a half-wave on 32 different banks.
+// With SUM the waves of column block 0 also accumulate sum_p A[p][d] (every column of `sums` holds it).
+constexpr int kLdT = 48;
+template <bool SUM>
+__device__ __forceinline__ void tile_outer_acc(const float* As, const float* Bs, int lane, int wave, f32x4& acc, f32x4& sums) {
+    const int r = lane & 15, q = lane >> 4, di = wave >> 1, ej = wave & 1;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const float av = As[(4 * s + q) * kLdT + 16 * di + r];
+        const float bv = Bs[(4 * s + q) * kLdT + 16 * ej + r];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+        if (SUM && ej == 0) sums = __builtin_amdgcn_mfma_f32_16x16x4f32(av, 1.0f, sums, 0, 0, 0);
     }
 }
 
@@ -441,8 +457,9 @@ __global__ __launch_bounds__(256) void linattn_kmax_kernel(const T* __restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void linattn_ctx_kernel(const T* __restrict__ qkv, const float* __restrict__ pmax,
                                                           float* __restrict__ ctx_un, float* __restrict__ kstat, int n, int heads) {
-    __shared__ float Ks[64 * 33], Vs[64 * 33], kmx[32];
+    __shared__ float Ks[64 * kLdT], Vs[64 * kLdT], kmx[32];
     const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const int hid = heads * kD, ld = 3 * hid;
     const T* base = qkv + (size_t)b * n * ld;
     int pb, pe;
@@ -453,8 +470,7 @@ __global__ __launch_bounds__(256) void linattn_ctx_kernel(const T* __restrict__ 
         kmx[tid] = m;
         if (blockIdx.y == 0) kstat[(size_t)bh * 64 + tid] = m;
     }
-    const int d = tid >> 3, e4 = (tid & 7) * 4;
-    float acc[4] = {0, 0, 0, 0}, ks = 0.f;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, sums = acc;
     for (int p0 = pb; p0 < pe; p0 += 64) {
         __syncthreads();
 #pragma unroll
@@ -462,22 +478,20 @@ __global__ __launch_bounds__(256) void linattn_ctx_kernel(const T* __restrict__ 
             const int idx = tid + 256 * i, p = idx >> 5, dd = idx & 31;
             const bool ok = p0 + p < pe;
             const T* row = base + (size_t)(p0 + p) * ld;
-            Ks[p * 33 + dd] = ok ? expf(Io<T>::ld(row + hid + h * kD + dd) - kmx[dd]) : 0.f;
-            Vs[p * 33 + dd] = ok ? Io<T>::ld(row + 2 * hid + h * kD + dd) : 0.f;
+            Ks[p * kLdT + dd] = ok ? expf(Io<T>::ld(row + hid + h * kD + dd) - kmx[dd]) : 0.f;
+            Vs[p * kLdT + dd] = ok ? Io<T>::ld(row + 2 * hid + h * kD + dd) : 0.f;
         }
         __syncthreads();
-#pragma unroll 8
-        for (int p = 0; p < 64; ++p) {
-            const float kv = Ks[p * 33 + d];
-            ks += kv;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] += kv * Vs[p * 33 + e4 + e];
-        }
+        tile_outer_acc<true>(Ks, Vs, lane, wave, acc, sums);
     }
-    if (pb < pe) {
+    if (pb < pe) {   // D[4q + i][r]: row d = 16*(wave>>1) + 4q + i, column e = 16*(wave&1) + r
+        const int r = lane & 15, q = lane >> 4, di = wave >> 1, ej = wave & 1;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) unsafeAtomicAdd(ctx_un + (size_t)bh * 1024 + d * 32 + e4 + e, acc[e]);
-        if ((tid & 7) == 0) unsafeAtomicAdd(kstat + (size_t)bh * 64 + 32 + d, ks);
+        for (int i = 0; i < 4; ++i) {
+            const int d = 16 * di + 4 * q + i;
+            unsafeAtomicAdd(ctx_un + (size_t)bh * 1024 + d * 32 + 16 * ej + r, acc[i]);
+            if (ej == 0 && r == 0) unsafeAtomicAdd(kstat + (size_t)bh * 64 + 32 + d, sums[i]);
+        }
     }
 }
 
@@ -594,32 +608,29 @@ __global__ __launch_bounds__(256) void linattn_out_kernel(const T* __restrict__ 
 template <typename T>
 __global__ __launch_bounds__(256) void linattn_dctx_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
                                                            float* __restrict__ dctx, int n, int heads) {
-    __shared__ float As[64 * 33], Bs[64 * 33];
+    __shared__ float As[64 * kLdT], Bs[64 * kLdT];
     const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const int hid = heads * kD, ld = 3 * hid;
     const T* base = qkv + (size_t)b * n * ld;
     const T* dob = dout + (size_t)b * n * hid;
     int pb, pe;
     split_range(n, pb, pe);
-    const int d = tid >> 3, e4 = (tid & 7) * 4;
-    float acc[4] = {0, 0, 0, 0};
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, unused = acc;
     for (int p0 = pb; p0 < pe; p0 += 64) {
         __syncthreads();
-        load_tile(As, base, ld, h * kD, p0, pe, tid, 0.f);
-        load_tile(Bs, dob, hid, h * kD, p0, pe, tid, 0.f);   // rows beyond the range are zero: they add nothing
+        load_tile<T, kLdT>(As, base, ld, h * kD, p0, pe, tid, 0.f);
+        load_tile<T, kLdT>(Bs, dob, hid, h * kD, p0, pe, tid, 0.f);   // rows beyond the range are zero: they add nothing
         __syncthreads();
-        softmax_q_rows(As, tid);
+        softmax_q_rows<kLdT>(As, tid);
         __syncthreads();
-#pragma unroll 8
-        for (int p = 0; p < 64; ++p) {
-            const float qv = As[p * 33 + d];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] += qv * Bs[p * 33 + e4 + e];
-        }
+        tile_outer_acc<false>(As, Bs, lane, wave, acc, unused);
     }
     if (pb < pe) {
+        const int r = lane & 15, q = lane >> 4, di = wave >> 1, ej = wave & 1;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dctx + (size_t)bh * 1024 + d * 32 + e4 + e, acc[e] * kScale);
+        for (int i = 0; i < 4; ++i)
+            unsafeAtomicAdd(dctx + (size_t)bh * 1024 + (16 * di + 4 * q + i) * 32 + 16 * ej + r, acc[i] * kScale);
     }
 }
 
