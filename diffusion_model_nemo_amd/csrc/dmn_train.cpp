@@ -80,10 +80,12 @@ struct DmnTrainer {
     // The weight-gradient kernels depend on nothing but their convolution's output gradient and feed nothing but the
     // final layout change, so they run on a second stream beside the chain of input-gradient kernels: one event from
     // the main stream per launch, one join at the end of the step.
-    hipStream_t side = nullptr;
+    // A step of an even batch also runs as two half-batch chains, the second on `chain2` with its own side stream.
+    hipStream_t side[2] = {nullptr, nullptr}, chain2 = nullptr;
     std::vector<hipEvent_t> events;
-    hipEvent_t join = nullptr;
-    int use_side = 1;
+    size_t ev_next = 0;
+    hipEvent_t join = nullptr, fork = nullptr;
+    int use_side = 1, use_dual = 1;
     // workspace region sizes of the last shape
     int sz_B = 0, sz_H = 0, sz_W = 0;
     size_t sz_zero = 0, sz_arena = 0, sz_total = 0;
@@ -319,20 +321,21 @@ struct Run {
     float *wf, *wb, *dwf;
     std::vector<std::function<void()>> tape;
     std::deque<Ten> tens;
-    size_t ev_next = 0;
+    hipStream_t side = nullptr;
+    const long long* labels = nullptr;   // class labels of this chain's images
     bool side_used = false;
-    // stream for a weight-gradient launch whose inputs the main stream has produced by now
+    // stream for a weight-gradient launch whose inputs this chain's stream has produced by now
     hipStream_t wgrad_stream() {
-        if (!tr->use_side || !tr->side || dry || rc != DMN_OK) return s;
-        if (ev_next >= tr->events.size()) {
+        if (!tr->use_side || !side || dry || rc != DMN_OK) return s;
+        if (tr->ev_next >= tr->events.size()) {
             hipEvent_t e = nullptr;
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return s;
             tr->events.push_back(e);
         }
-        hipEvent_t e = tr->events[ev_next++];
-        if (hipEventRecord(e, s) != hipSuccess || hipStreamWaitEvent(tr->side, e, 0) != hipSuccess) return s;
+        hipEvent_t e = tr->events[tr->ev_next++];
+        if (hipEventRecord(e, s) != hipSuccess || hipStreamWaitEvent(side, e, 0) != hipSuccess) return s;
         side_used = true;
-        return tr->side;
+        return side;
     }
 
     void fail_ws() {
@@ -644,65 +647,14 @@ struct Sizes {
     size_t zero = 0, arena = 0, total = 0;
 };
 
-int run_step(DmnTrainer* tr, const float* params, float* grads, const StepIO& io, int B, int H, int W, void* ws, size_t ws_bytes,
-             hipStream_t s, bool dry, Sizes* sz) {
+// Forward, loss and backward of `r.B` images on stream r.s: everything between the shared prologue (zero fill, weight
+// layout change) and the shared epilogue (gradient layout change). n_mean: element count the mean loss runs over (the
+// whole batch, also when this chain holds a part of it).
+int run_chain(Run& r, const StepIO& io, int H, int W, long long n_mean) {
+    DmnTrainer* tr = r.tr;
     const DmnUnetCfg& c = tr->cfg;
-    const int nlev = c.n_mults, div = 1 << (nlev - 1);
-    DMN_REQUIRE(B >= 1 && H % div == 0 && W % div == 0 && H >= div && W >= div, DMN_ERR_INVALID,
-                "training: image %dx%d must be a multiple of %d", H, W, div);
-    Run r;
-    r.tr = tr;
-    r.s = s;
-    r.dry = dry;
-    r.B = B;
-    r.bf16 = c.dtype >= 1 ? 1 : 0;
-    r.img_adt = c.dtype == 2 ? 1 : 0;
-    r.params = params;
-    r.grads = grads;
-    // workspace: [wf | wb | zero region: dwf + zero arena | arena]
-    const size_t gemm_bytes = ((size_t)tr->gemm_numel * 4 + 255) & ~(size_t)255;
-    if (!dry) {
-        // region sizes come from a dry pass of the same code, cached per shape
-        if (tr->sz_B != B || tr->sz_H != H || tr->sz_W != W) {
-            Sizes q;
-            int rc = run_step(tr, params, grads, io, B, H, W, nullptr, 0, s, true, &q);
-            if (rc) return rc;
-            tr->sz_B = B;
-            tr->sz_H = H;
-            tr->sz_W = W;
-            tr->sz_zero = q.zero;
-            tr->sz_arena = q.arena;
-            tr->sz_total = q.total;
-        }
-        DMN_REQUIRE(ws_bytes >= tr->sz_total, DMN_ERR_WORKSPACE, "training workspace: %zu bytes given, %zu needed", ws_bytes,
-                    tr->sz_total);
-        DMN_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, DMN_ERR_INVALID, "training workspace must be 256-byte aligned");
-        if (!tr->side && tr->use_side) {
-            DMN_HIP_CHECK(hipStreamCreateWithFlags(&tr->side, hipStreamNonBlocking));
-            DMN_HIP_CHECK(hipEventCreateWithFlags(&tr->join, hipEventDisableTiming));
-        }
-        if (!tr->descs_dev) {   // first step on the device: upload the layout table (creation itself needs no GPU)
-            DMN_HIP_CHECK(hipMalloc((void**)&tr->descs_dev, tr->descs.size() * sizeof(RepackDesc)));
-            DMN_HIP_CHECK(hipMemcpy(tr->descs_dev, tr->descs.data(), tr->descs.size() * sizeof(RepackDesc), hipMemcpyHostToDevice));
-        }
-    }
-    char* base = (char*)ws;
-    r.wf = (float*)base;
-    r.wb = (float*)(base + gemm_bytes);
-    r.dwf = (float*)(base + 2 * gemm_bytes);
-    if (dry) {
-        r.z.dry = r.a.dry = true;
-    } else {
-        r.z.base = base + 3 * gemm_bytes;
-        r.z.cap = tr->sz_zero;
-        r.a.base = base + 3 * gemm_bytes + tr->sz_zero;
-        r.a.cap = tr->sz_arena;
-        DMN_HIP_CHECK(hipMemsetAsync(r.dwf, 0, gemm_bytes + tr->sz_zero, s));
-        DMN_HIP_CHECK(hipMemsetAsync(grads, 0, (size_t)tr->n_flat * 4, s));
-        RUN(r, launch_repack(tr->descs_dev, (int)tr->descs.size(), tr->max_numel, params, r.wf, r.wb, s));
-    }
-
-    const int td = 4 * c.dim;
+    const int nlev = c.n_mults, B = r.B;
+    hipStream_t s = r.s;
     // inputs
     Ten* xt = r.nt(c.channels, H, W, r.img_adt);
     Ten* tgt = r.nt(c.channels, H, W, 0);
@@ -714,18 +666,18 @@ int run_step(DmnTrainer* tr, const float* params, float* grads, const StepIO& io
     Ten* h2 = activation(r, h1, 1);
     Ten* temb = conv(r, h2, tr->t2);
     Ten* st = activation(r, temb, 0);
-    Ten* tb = conv(r, st, tr->tball, true, params + tr->tb_bias_off, grads + tr->tb_bias_off);
+    Ten* tb = conv(r, st, tr->tball, true, r.params + tr->tb_bias_off, r.grads + tr->tb_bias_off);
     tb->g = r.zalloc((size_t)B * tr->tb_total);   // every block adds its share
     tb->gset = true;
-    (void)td;
 
     Ten* cur = conv(r, xt, tr->init, false);
     if (tr->class_embed >= 0) {   // x = init_conv(x) + class_embed(classes)[:, :, None, None]  (unet.py:134-141), in place
-        RUN(r, launch_class_bias_fwd(cur->p, cur->adt, r.P(tr->class_embed), tr->labels, c.num_classes, B, H * W, c.dim, s));
+        const long long* labels = r.labels;
+        RUN(r, launch_class_bias_fwd(cur->p, cur->adt, r.P(tr->class_embed), labels, c.num_classes, B, H * W, c.dim, s));
         Run* rp = &r;
-        r.tape.push_back([rp, cur, tr, H, W]() {
+        r.tape.push_back([rp, cur, tr, labels, H, W]() {
             Run& r = *rp;
-            RUN(r, launch_class_bias_bwd(cur->g, cur->adt, tr->labels, tr->cfg.num_classes, r.GP(tr->class_embed), r.B, H * W, tr->cfg.dim,
+            RUN(r, launch_class_bias_bwd(cur->g, cur->adt, labels, tr->cfg.num_classes, r.GP(tr->class_embed), r.B, H * W, tr->cfg.dim,
                                          r.s));
         });
     }
@@ -754,27 +706,134 @@ int run_step(DmnTrainer* tr, const float* params, float* grads, const StepIO& io
     Ten* out = conv(r, cur, tr->tail);
     DMN_REQUIRE(out->H == H && out->W == W, DMN_ERR_INVALID, "internal: output %dx%d", out->H, out->W);
 
-    // loss and its gradient
-    float* loss_dev = dry ? nullptr : io.loss;
+    // loss and its gradient (the scalar was zeroed in the prologue)
     int acc;
     void* dout = r.G(out, &acc);
-    if (!dry) DMN_HIP_CHECK(hipMemsetAsync(loss_dev, 0, 4, s));
-    RUN(r, launch_loss(out->p, (const float*)tgt->p, out->adt, (long long)r.numel(out), tr->loss_kind, loss_dev, dout, s));
+    RUN(r, launch_loss(out->p, (const float*)tgt->p, out->adt, (long long)r.numel(out), n_mean, tr->loss_kind, r.dry ? nullptr : io.loss,
+                       dout, s));
     if (io.model_out) RUN(r, launch_nhwc_to_nchw(out->p, out->adt, io.model_out, B, c.out_dim, H * W, s));
 
     for (size_t i = r.tape.size(); i-- > 0;) r.tape[i]();
-    if (r.side_used) {   // the layout change below reads what the side stream's kernels accumulated
-        DMN_HIP_CHECK(hipEventRecord(tr->join, tr->side));
-        DMN_HIP_CHECK(hipStreamWaitEvent(s, tr->join, 0));
-    }
-    RUN(r, launch_unpack_grads(tr->descs_dev, (int)tr->descs.size(), tr->max_numel, r.dwf, grads, s));
-
-    if (dry && sz) {
-        sz->zero = (r.z.used + 255) & ~(size_t)255;
-        sz->arena = (r.a.used + 255) & ~(size_t)255;
-        sz->total = 3 * gemm_bytes + sz->zero + sz->arena;
-    }
     return r.rc;
+}
+
+// chains a step of B images is cut into: two half-batch chains on two streams keep more of the chip busy through the
+// low-resolution levels, whose launches have fewer workgroups than there are CUs
+int chains_for(const DmnTrainer* tr, int B) { return (tr->use_dual && B >= 4 && B % 2 == 0) ? 2 : 1; }
+
+int run_step(DmnTrainer* tr, const float* params, float* grads, const StepIO& io, int B, int H, int W, void* ws, size_t ws_bytes,
+             hipStream_t s, bool dry, Sizes* sz) {
+    const DmnUnetCfg& c = tr->cfg;
+    const int nlev = c.n_mults, div = 1 << (nlev - 1);
+    DMN_REQUIRE(B >= 1 && H % div == 0 && W % div == 0 && H >= div && W >= div, DMN_ERR_INVALID,
+                "training: image %dx%d must be a multiple of %d", H, W, div);
+    const int nchain = chains_for(tr, B), Bc = B / nchain;
+    // workspace: [wf | wb | zero region: dwf + one zero arena per chain | one arena per chain]
+    const size_t gemm_bytes = ((size_t)tr->gemm_numel * 4 + 255) & ~(size_t)255;
+    if (!dry) {
+        // region sizes come from a dry pass of the same code, cached per shape
+        if (tr->sz_B != B || tr->sz_H != H || tr->sz_W != W) {
+            Sizes q;
+            int rc = run_step(tr, params, grads, io, B, H, W, nullptr, 0, s, true, &q);
+            if (rc) return rc;
+            tr->sz_B = B;
+            tr->sz_H = H;
+            tr->sz_W = W;
+            tr->sz_zero = q.zero;
+            tr->sz_arena = q.arena;
+            tr->sz_total = q.total;
+        }
+        DMN_REQUIRE(ws_bytes >= tr->sz_total, DMN_ERR_WORKSPACE, "training workspace: %zu bytes given, %zu needed", ws_bytes,
+                    tr->sz_total);
+        DMN_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, DMN_ERR_INVALID, "training workspace must be 256-byte aligned");
+        if (!tr->join) {
+            for (int k = 0; k < 2; ++k) DMN_HIP_CHECK(hipStreamCreateWithFlags(&tr->side[k], hipStreamNonBlocking));
+            DMN_HIP_CHECK(hipStreamCreateWithFlags(&tr->chain2, hipStreamNonBlocking));
+            DMN_HIP_CHECK(hipEventCreateWithFlags(&tr->fork, hipEventDisableTiming));
+            DMN_HIP_CHECK(hipEventCreateWithFlags(&tr->join, hipEventDisableTiming));
+        }
+        if (!tr->descs_dev) {   // first step on the device: upload the layout table (creation itself needs no GPU)
+            DMN_HIP_CHECK(hipMalloc((void**)&tr->descs_dev, tr->descs.size() * sizeof(RepackDesc)));
+            DMN_HIP_CHECK(hipMemcpy(tr->descs_dev, tr->descs.data(), tr->descs.size() * sizeof(RepackDesc), hipMemcpyHostToDevice));
+        }
+    }
+    char* base = (char*)ws;
+    float* wf = (float*)base;
+    float* wb = (float*)(base + gemm_bytes);
+    float* dwf = (float*)(base + 2 * gemm_bytes);
+    if (!dry) {
+        DMN_HIP_CHECK(hipMemsetAsync(dwf, 0, gemm_bytes + nchain * tr->sz_zero, s));
+        DMN_HIP_CHECK(hipMemsetAsync(grads, 0, (size_t)tr->n_flat * 4, s));
+        DMN_HIP_CHECK(hipMemsetAsync(io.loss, 0, 4, s));
+        int rc = launch_repack(tr->descs_dev, (int)tr->descs.size(), tr->max_numel, params, wf, wb, s);
+        if (rc) return rc;
+        if (nchain > 1) {
+            DMN_HIP_CHECK(hipEventRecord(tr->fork, s));
+            DMN_HIP_CHECK(hipStreamWaitEvent(tr->chain2, tr->fork, 0));
+        }
+        tr->ev_next = 0;
+    }
+    const long long n_mean = (long long)B * H * W * c.out_dim;
+    const size_t img = (size_t)c.channels * H * W;
+    int rc = DMN_OK;
+    bool side_used[2] = {false, false};
+    Sizes one;
+    for (int k = 0; k < (dry ? 1 : nchain) && rc == DMN_OK; ++k) {
+        Run r;
+        r.tr = tr;
+        r.s = k == 0 ? s : tr->chain2;
+        r.side = tr->side[k];
+        r.dry = dry;
+        r.B = Bc;
+        r.bf16 = c.dtype >= 1 ? 1 : 0;
+        r.img_adt = c.dtype == 2 ? 1 : 0;
+        r.params = params;
+        r.grads = grads;
+        r.wf = wf;
+        r.wb = wb;
+        r.dwf = dwf;
+        r.labels = tr->labels ? tr->labels + (size_t)k * Bc : nullptr;
+        if (dry) {
+            r.z.dry = r.a.dry = true;
+        } else {
+            r.z.base = base + 3 * gemm_bytes + k * tr->sz_zero;
+            r.z.cap = tr->sz_zero;
+            r.a.base = base + 3 * gemm_bytes + nchain * tr->sz_zero + k * tr->sz_arena;
+            r.a.cap = tr->sz_arena;
+        }
+        StepIO ck = io;
+        if (!dry) {
+            ck.x0 = io.x0 + (size_t)k * Bc * img;
+            ck.noise = io.noise + (size_t)k * Bc * img;
+            ck.t = io.t + (size_t)k * Bc;
+            if (io.model_out) ck.model_out = io.model_out + (size_t)k * Bc * c.out_dim * H * W;
+        }
+        rc = run_chain(r, ck, H, W, n_mean);
+        side_used[k] = r.side_used;
+        if (dry) {
+            one.zero = (r.z.used + 255) & ~(size_t)255;
+            one.arena = (r.a.used + 255) & ~(size_t)255;
+        }
+    }
+    if (rc) return rc;
+    if (!dry) {
+        // the layout change below reads what every stream accumulated
+        for (int k = 0; k < nchain; ++k)
+            if (side_used[k]) {
+                DMN_HIP_CHECK(hipEventRecord(tr->join, tr->side[k]));
+                DMN_HIP_CHECK(hipStreamWaitEvent(s, tr->join, 0));
+            }
+        if (nchain > 1) {
+            DMN_HIP_CHECK(hipEventRecord(tr->join, tr->chain2));
+            DMN_HIP_CHECK(hipStreamWaitEvent(s, tr->join, 0));
+        }
+        rc = launch_unpack_grads(tr->descs_dev, (int)tr->descs.size(), tr->max_numel, dwf, grads, s);
+    } else if (sz) {
+        sz->zero = one.zero;
+        sz->arena = one.arena;
+        sz->total = 3 * gemm_bytes + nchain * (one.zero + one.arena);
+    }
+    return rc;
 }
 
 }   // namespace
@@ -800,7 +859,8 @@ extern "C" int dmn_train_create(const DmnUnetCfg* cfg, int loss_kind, DmnTrainer
     DmnTrainer* tr = new DmnTrainer();
     tr->cfg = *cfg;
     tr->loss_kind = loss_kind;
-    if (const char* e = getenv("DMN_TRAIN_SIDE_STREAM")) tr->use_side = atoi(e) != 0;   // tuning aid: 0 keeps one stream
+    if (const char* e = getenv("DMN_TRAIN_SIDE_STREAM")) tr->use_side = atoi(e) != 0;   // tuning aids: 0 keeps one stream,
+    if (const char* e = getenv("DMN_TRAIN_DUAL_CHAIN")) tr->use_dual = atoi(e) != 0;    // 0 keeps one chain
     int rc = build_structure(tr);
     if (rc) {
         delete tr;
@@ -816,7 +876,10 @@ extern "C" void dmn_train_destroy(DmnTrainer* tr) {
     if (tr->descs_dev) (void)hipFree(tr->descs_dev);
     for (hipEvent_t e : tr->events) (void)hipEventDestroy(e);
     if (tr->join) (void)hipEventDestroy(tr->join);
-    if (tr->side) (void)hipStreamDestroy(tr->side);
+    if (tr->fork) (void)hipEventDestroy(tr->fork);
+    for (int k = 0; k < 2; ++k)
+        if (tr->side[k]) (void)hipStreamDestroy(tr->side[k]);
+    if (tr->chain2) (void)hipStreamDestroy(tr->chain2);
     delete tr;
 }
 

@@ -96,8 +96,10 @@ int launch_sinus(const void* t, int t_is_float, int B, int dim, float* out, hipS
 int launch_train_ingest(const float* x0, const float* eps, const long long* t, const float* sa, const float* sb, int n_timesteps,
                         void* xt, int adt, float* tgt, int B, int C, int H, int W, hipStream_t s);
 // loss (+= into a zeroed scalar) of DiffusionLoss with reduction 'mean' (loss/simple_loss.py:37-45): kind 0 l1,
-// 1 l2, 2 huber (smooth_l1, beta 1); dout = d loss / d out. out, tgt, dout: [n] in the same (NHWC) order.
-int launch_loss(const void* out, const float* tgt, int adt, long long n, int kind, float* loss, void* dout, hipStream_t s);
+// 1 l2, 2 huber (smooth_l1, beta 1); dout = d loss / d out. out, tgt, dout: [n] in the same (NHWC) order. The mean runs
+// over n_mean elements (>= n: a launch may hold a part of the batch).
+int launch_loss(const void* out, const float* tgt, int adt, long long n, long long n_mean, int kind, float* loss, void* dout,
+                hipStream_t s);
 // NHWC [B][HW][C] -> NCHW float32 [B][C][HW]
 int launch_nhwc_to_nchw(const void* in, int adt, float* out, int B, int C, int HW, hipStream_t s);
 

@@ -333,10 +333,10 @@ __global__ __launch_bounds__(256) void train_ingest_kernel(const float* __restri
 
 // out / dout in the activation type; the target stays float32 (it is the caller's noise, only reordered)
 template <typename T>
-__global__ __launch_bounds__(256) void loss_kernel(const T* __restrict__ out, const float* __restrict__ tgt, long long n, int kind,
-                                                   float* __restrict__ loss, T* __restrict__ dout) {
+__global__ __launch_bounds__(256) void loss_kernel(const T* __restrict__ out, const float* __restrict__ tgt, long long n, long long n_mean,
+                                                   int kind, float* __restrict__ loss, T* __restrict__ dout) {
     __shared__ float sh[4];
-    const float inv = 1.0f / (float)n;
+    const float inv = 1.0f / (float)n_mean;
     float acc = 0.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const float d = Io<T>::ld(out + i) - tgt[i];
@@ -1036,8 +1036,9 @@ int launch_train_ingest(const float* x0, const float* eps, const long long* t, c
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }
-int launch_loss(const void* out, const float* tgt, int adt, long long n, int kind, float* loss, void* dout, hipStream_t s) {
-    DMN_DISPATCH_T(adt, loss_kernel<T><<<grid_for(n, 1024, 1024), 256, 0, s>>>((const T*)out, tgt, n, kind, loss, (T*)dout));
+int launch_loss(const void* out, const float* tgt, int adt, long long n, long long n_mean, int kind, float* loss, void* dout,
+                hipStream_t s) {
+    DMN_DISPATCH_T(adt, loss_kernel<T><<<grid_for(n, 1024, 1024), 256, 0, s>>>((const T*)out, tgt, n, n_mean, kind, loss, (T*)dout));
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }

@@ -72,7 +72,8 @@ def test_training_step_matches_reference_golden():
     assert float((out.cpu() - want).abs().max()) <= 2e-4
 
 
-@pytest.mark.parametrize("B,H,W,loss", [(2, 32, 32, "l2"), (3, 16, 24, "l1"), (1, 64, 64, "huber")])
+# B=4: an even batch of four or more runs as two concurrent half-batch chains inside the library
+@pytest.mark.parametrize("B,H,W,loss", [(2, 32, 32, "l2"), (3, 16, 24, "l1"), (1, 64, 64, "huber"), (4, 32, 32, "l2")])
 def test_every_gradient_matches_oracle_autograd(B, H, W, loss):
     u, tr, sd = build(loss=loss)
     gen = torch.Generator().manual_seed(7 + B)
