@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the extra training-step measurement")
     return ap.parse_args()
 
 
@@ -74,6 +75,68 @@ def cpu_baseline(image_size, timesteps, budget_s):
     return {"value": B / (sec_per_step * timesteps), "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": f"CPU oracle, B={B} {image_size}x{image_size}, {n} p_sample steps in {el:.1f}s "
                       f"({sec_per_step * 1e3:.1f} ms/step), extrapolated x{timesteps}"}
+
+
+def train_step_extra(dev, rank, world, dist):
+    """Extra, reported beside the headline: the DDPM training step of BASELINE configuration 5 (128x128, 32 images per
+    GPU: q_sample + forward + L_simple + backward, ONE all-reduce of the flat gradient buffer over RCCL when N > 1,
+    global-norm clip + AdamW), bf16 matrix-core operands, fp32 activations. Every rank first runs one step without any
+    collective and the ranks agree that all succeeded before the timed loop with the all-reduce starts, so a failure
+    here cannot hang the job; it only drops this entry."""
+    ok, tr, step = 1, None, None
+    try:
+        from diffusion_model_nemo_amd.modules import GaussianDiffusion, Unet
+        from diffusion_model_nemo_amd.training import UnetTrainer, cosine_annealing_lr
+        Bt, St = 32, 128
+        net = Unet(input_dim=St, dim=32, dim_mults=[1, 2, 4, 8], channels=3, resnet_block_groups=8, use_convnext=False,
+                   dropout=0.0, compute_dtype="bf16").to(dev)
+        tr = UnetTrainer(net, "l2")
+        gd = GaussianDiffusion(timesteps=1000, schedule_name="cosine")
+        sa, sb = gd.sqrt_alphas_cumprod.to(dev), gd.sqrt_one_minus_alphas_cumprod.to(dev)
+        gen = torch.Generator(device=dev).manual_seed(100 + rank)
+        x0 = torch.rand(Bt, 3, St, St, device=dev, generator=gen) * 2 - 1
+
+        def step(i, reduce):
+            t = torch.randint(0, 1000, (Bt,), device=dev, generator=gen)
+            eps = torch.randn(Bt, 3, St, St, device=dev, generator=gen)
+            loss = tr.loss_and_grads(x0, t, eps, sa, sb)
+            scale = tr.all_reduce_grads() if reduce else 1.0
+            tr.optimizer_step(lr=cosine_annealing_lr(i, 10000, 1e-3, 1e-4), betas=(0.9, 0.98), weight_decay=1e-3,
+                              max_grad_norm=1.0, grad_scale=scale)
+            return loss
+
+        first = float(step(0, False))
+        ok = 1 if first == first else 0   # NaN check
+    except Exception as e:   # noqa: BLE001 - the headline number must survive a failure of the extra
+        print(f"[bench] training-step extra skipped on rank {rank}: {e}", file=sys.stderr)
+        ok = 0
+    flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+    if dist is not None:
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        return None
+    warm, iters = 3, 10
+    for i in range(warm):
+        step(1 + i, True)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(iters):
+        loss = step(1 + warm + i, True)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    tt = torch.tensor([(time.perf_counter() - t0) / iters], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    return {"metric": "images/sec, DDPM training step (q_sample + fwd + L_simple + bwd + grad all-reduce + clip + AdamW)",
+            "value": 32 * world / dt, "unit": "images/sec", "ms_per_step": dt * 1e3, "n_gpus": world,
+            "config": {"workload": "128x128x3 DDPM U-Net (dim 32, mults 1-2-4-8), 32 images per GPU", "global_batch": 32 * world,
+                       "parallelism": f"dp{world}, one all-reduce of 32.3 MB fp32 gradients per step"},
+            "dtype": "bf16 matrix-core operands, fp32 accumulate / activations / optimiser", "scaling": "weak",
+            "tflops_per_gpu": 32 * 3 * 10.677e9 / dt / 1e12, "loss": float(loss)}
 
 
 def main():
@@ -143,6 +206,8 @@ def main():
         if tj.get("batch") == B and tj.get("image_size") == S and tj.get("dtype") == a.dtype:
             traffic = tj["hbm_bytes_per_launch"]
 
+    train = None if a.no_train else train_step_extra(dev, rank, world, dist)
+
     if rank == 0:
         imgs = world * B * a.steps
         sec_per_eval = (loop_ms / 1e3) / a.timesteps
@@ -167,6 +232,8 @@ def main():
                      "frac_of_hbm_peak": alg_bytes / sec_per_eval / 1e9 / HBM_PEAK_GBS,
                      "tflops": B * GFLOP_PER_IMG_EVAL / sec_per_eval / 1e3},
         }
+        if train is not None:
+            res["train_step"] = train
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(S, a.timesteps, a.cpu_seconds)
         print(json.dumps(res), flush=True)

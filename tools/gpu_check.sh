@@ -5,5 +5,5 @@ timeout -k 10 600 python -u -m pytest tests -x -q -m gpu --timeout 300 --timeout
 rc=$?; echo exit=$rc >> gpurun_out/test_$tag.log; tail -4 gpurun_out/test_$tag.log
 [ $rc -ne 0 ] && exit $rc
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python bench.py --steps 1 --warmup 1 --timesteps $ts --no-cpu-baseline > gpurun_out/prof_$tag.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python bench.py --steps 1 --warmup 1 --timesteps $ts --no-cpu-baseline --no-train > gpurun_out/prof_$tag.log 2>&1 || exit 1
 grep -v "^[WE]2026" gpurun_out/prof_$tag.log | tail -1 | cut -c 1-220
