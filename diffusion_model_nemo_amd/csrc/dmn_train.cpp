@@ -80,8 +80,11 @@ struct DmnTrainer {
     // The weight-gradient kernels depend on nothing but their convolution's output gradient and feed nothing but the
     // final layout change, so they run on a second stream beside the chain of input-gradient kernels: one event from
     // the main stream per launch, one join at the end of the step.
-    // A step of an even batch also runs as two half-batch chains, the second on `chain2` with its own side stream.
-    hipStream_t side[2] = {nullptr, nullptr}, chain2 = nullptr;
+    // A step also runs as up to kMaxChains part-batch chains: chain 0 on the caller's stream, the others on `chain[k]`,
+    // each with its own side stream.
+    static constexpr int kMaxChains = 4;
+    hipStream_t side[kMaxChains] = {}, chain[kMaxChains] = {};
+    int max_chains = 2;
     std::vector<hipEvent_t> events;
     size_t ev_next = 0;
     hipEvent_t join = nullptr, fork = nullptr;
@@ -719,7 +722,12 @@ int run_chain(Run& r, const StepIO& io, int H, int W, long long n_mean) {
 
 // chains a step of B images is cut into: two half-batch chains on two streams keep more of the chip busy through the
 // low-resolution levels, whose launches have fewer workgroups than there are CUs
-int chains_for(const DmnTrainer* tr, int B) { return (tr->use_dual && B >= 4 && B % 2 == 0) ? 2 : 1; }
+int chains_for(const DmnTrainer* tr, int B) {
+    if (!tr->use_dual) return 1;
+    for (int n = tr->max_chains; n > 1; n >>= 1)
+        if (B % n == 0 && B / n >= 2) return n;
+    return 1;
+}
 
 int run_step(DmnTrainer* tr, const float* params, float* grads, const StepIO& io, int B, int H, int W, void* ws, size_t ws_bytes,
              hipStream_t s, bool dry, Sizes* sz) {
@@ -747,8 +755,10 @@ int run_step(DmnTrainer* tr, const float* params, float* grads, const StepIO& io
                     tr->sz_total);
         DMN_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, DMN_ERR_INVALID, "training workspace must be 256-byte aligned");
         if (!tr->join) {
-            for (int k = 0; k < 2; ++k) DMN_HIP_CHECK(hipStreamCreateWithFlags(&tr->side[k], hipStreamNonBlocking));
-            DMN_HIP_CHECK(hipStreamCreateWithFlags(&tr->chain2, hipStreamNonBlocking));
+            for (int k = 0; k < DmnTrainer::kMaxChains; ++k) {
+                DMN_HIP_CHECK(hipStreamCreateWithFlags(&tr->side[k], hipStreamNonBlocking));
+                if (k) DMN_HIP_CHECK(hipStreamCreateWithFlags(&tr->chain[k], hipStreamNonBlocking));
+            }
             DMN_HIP_CHECK(hipEventCreateWithFlags(&tr->fork, hipEventDisableTiming));
             DMN_HIP_CHECK(hipEventCreateWithFlags(&tr->join, hipEventDisableTiming));
         }
@@ -769,19 +779,19 @@ int run_step(DmnTrainer* tr, const float* params, float* grads, const StepIO& io
         if (rc) return rc;
         if (nchain > 1) {
             DMN_HIP_CHECK(hipEventRecord(tr->fork, s));
-            DMN_HIP_CHECK(hipStreamWaitEvent(tr->chain2, tr->fork, 0));
+            for (int k = 1; k < nchain; ++k) DMN_HIP_CHECK(hipStreamWaitEvent(tr->chain[k], tr->fork, 0));
         }
         tr->ev_next = 0;
     }
     const long long n_mean = (long long)B * H * W * c.out_dim;
     const size_t img = (size_t)c.channels * H * W;
     int rc = DMN_OK;
-    bool side_used[2] = {false, false};
+    bool side_used[DmnTrainer::kMaxChains] = {};
     Sizes one;
     for (int k = 0; k < (dry ? 1 : nchain) && rc == DMN_OK; ++k) {
         Run r;
         r.tr = tr;
-        r.s = k == 0 ? s : tr->chain2;
+        r.s = k == 0 ? s : tr->chain[k];
         r.side = tr->side[k];
         r.dry = dry;
         r.B = Bc;
@@ -823,8 +833,8 @@ int run_step(DmnTrainer* tr, const float* params, float* grads, const StepIO& io
                 DMN_HIP_CHECK(hipEventRecord(tr->join, tr->side[k]));
                 DMN_HIP_CHECK(hipStreamWaitEvent(s, tr->join, 0));
             }
-        if (nchain > 1) {
-            DMN_HIP_CHECK(hipEventRecord(tr->join, tr->chain2));
+        for (int k = 1; k < nchain; ++k) {
+            DMN_HIP_CHECK(hipEventRecord(tr->join, tr->chain[k]));
             DMN_HIP_CHECK(hipStreamWaitEvent(s, tr->join, 0));
         }
         rc = launch_unpack_grads(tr->descs_dev, (int)tr->descs.size(), tr->max_numel, dwf, grads, s);
@@ -861,6 +871,10 @@ extern "C" int dmn_train_create(const DmnUnetCfg* cfg, int loss_kind, DmnTrainer
     tr->loss_kind = loss_kind;
     if (const char* e = getenv("DMN_TRAIN_SIDE_STREAM")) tr->use_side = atoi(e) != 0;   // tuning aids: 0 keeps one stream,
     if (const char* e = getenv("DMN_TRAIN_DUAL_CHAIN")) tr->use_dual = atoi(e) != 0;    // 0 keeps one chain
+    if (const char* e = getenv("DMN_TRAIN_CHAINS")) {
+        const int n = atoi(e);
+        tr->max_chains = n >= 4 ? 4 : (n >= 2 ? 2 : 1);
+    }
     int rc = build_structure(tr);
     if (rc) {
         delete tr;
@@ -877,9 +891,10 @@ extern "C" void dmn_train_destroy(DmnTrainer* tr) {
     for (hipEvent_t e : tr->events) (void)hipEventDestroy(e);
     if (tr->join) (void)hipEventDestroy(tr->join);
     if (tr->fork) (void)hipEventDestroy(tr->fork);
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < DmnTrainer::kMaxChains; ++k) {
         if (tr->side[k]) (void)hipStreamDestroy(tr->side[k]);
-    if (tr->chain2) (void)hipStreamDestroy(tr->chain2);
+        if (tr->chain[k]) (void)hipStreamDestroy(tr->chain[k]);
+    }
     delete tr;
 }
 
