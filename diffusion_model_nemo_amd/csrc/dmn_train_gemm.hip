@@ -336,9 +336,12 @@ __global__ __launch_bounds__(256) void pgemm_halo_kernel(const PGemmArgs a) {
     f32x4 acc[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 bn[3 * NB], hr[4];
+    // two stages of weight tiles in flight (register sets bn0 / bn1 alternate): at the low-resolution levels a launch
+    // has two workgroups per CU and a stage's three MFMAs per 16 channels hide nothing, so the round trip of the weight
+    // loads is what a stage costs; two in flight halve it
+    f32x4 bn0[3 * NB], bn1[3 * NB], hr[4];
 
-    auto load_b = [&](int it) {
+    auto load_b = [&](int it, f32x4 (&bn)[3 * NB]) {
         const int cc = it / 3, ky = it - cc * 3;
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
@@ -375,9 +378,7 @@ __global__ __launch_bounds__(256) void pgemm_halo_kernel(const PGemmArgs a) {
         }
     };
 
-    load_halo(0);
-    load_b(0);
-    for (int it = 0; it < nstage; ++it) {
+    auto stage = [&](int it, f32x4 (&bn)[3 * NB]) {
         const int cc = it / 3, ky = it - cc * 3;
         if (ky == 0) {   // the previous chunk's last reads ended at the barrier that closed its stage
 #pragma unroll
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(256) void pgemm_halo_kernel(const PGemmArgs a) {
             for (int i = 0; i < NB; ++i)
                 *reinterpret_cast<f32x4*>(&Bs[kx * 32 * LDB + (tid / TPR + i * RPP) * LDB + (tid % TPR) * 4]) = bn[kx * NB + i];
         __syncthreads();
-        if (it + 1 < nstage) load_b(it + 1);
+        if (it + 2 < nstage) load_b(it + 2, bn);
         if (ky == 2 && cc + 1 < nch) load_halo(cc + 1);
         const int hy = py + (a.tmode ? 2 - ky : ky);
 #pragma unroll
@@ -424,6 +425,13 @@ __global__ __launch_bounds__(256) void pgemm_halo_kernel(const PGemmArgs a) {
             }
         }
         __syncthreads();
+    };
+    load_halo(0);
+    load_b(0, bn0);
+    if (nstage > 1) load_b(1, bn1);
+    for (int it = 0; it < nstage; it += 2) {
+        stage(it, bn0);
+        if (it + 1 < nstage) stage(it + 1, bn1);
     }
     float s1[NJ], s2[NJ];
     if (tile_store_ok<T>(a)) {
