@@ -160,7 +160,8 @@ class DDPM(AbstractDiffusionModel):
 
     def training_loss(self, batch, t: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None):
         """Forward half of models/ddpm.py:43-57: t ~ U{0..T-1}, x_t = q_sample(x_0, t, eps), loss(net(x_t, t), eps).
-        The value is computed by the HIP forward and carries no autograd graph (backward kernels are not built)."""
+        The value comes from the sampling path's forward (any compute_dtype) and carries no autograd graph;
+        `training_step` / `train_batch` are the entry points that also compute the gradients."""
         samples = batch["pixel_values"]
         B = samples.shape[0]
         if t is None:
