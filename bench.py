@@ -206,6 +206,21 @@ def main():
         if tj.get("batch") == B and tj.get("image_size") == S and tj.get("dtype") == a.dtype:
             traffic = tj["hbm_bytes_per_launch"]
 
+    # what this device sustains, beside the nominal peaks the roofline is priced against (rank 0, single GPU only)
+    peaks = None
+    if rank == 0 and world == 1:
+        from diffusion_model_nemo_amd.peaks import measure as measure_peaks
+        pk = measure_peaks(dev)
+        big = max(e["bytes"] for e in pk["stream"])
+        small = min(e["bytes"] for e in pk["stream"])
+        rate = {(e["kind"], e["bytes"]): e["GBs"] for e in pk["stream"]}
+        peaks = {"hbm_copy_GBs": rate[("copy", big)], "hbm_read_GBs": rate[("read", big)],
+                 "copy_of_one_level0_activation_GBs": rate[("copy", small)],
+                 "mfma_bf16_TFLOPs": max(m["TFLOPs"] for m in pk["mfma"] if "bf16" in m["instruction"]),
+                 "mfma_f32_TFLOPs": max(m["TFLOPs"] for m in pk["mfma"] if "bf16" not in m["instruction"])}
+        del pk
+        torch.cuda.empty_cache()
+
     train = None if a.no_train else train_step_extra(dev, rank, world, dist)
 
     if rank == 0:
@@ -232,6 +247,9 @@ def main():
                      "frac_of_hbm_peak": alg_bytes / sec_per_eval / 1e9 / HBM_PEAK_GBS,
                      "tflops": B * GFLOP_PER_IMG_EVAL / sec_per_eval / 1e3},
         }
+        if peaks is not None:
+            res["measured_peaks"] = peaks
+            res["roofline"]["frac_of_measured_hbm_copy"] = res["roofline"]["achieved"] / peaks["hbm_copy_GBs"]
         if train is not None:
             res["train_step"] = train
         if world == 1 and not a.no_cpu_baseline:

@@ -49,6 +49,8 @@ SIGNATURES = {
     "dmn_sample_workspace_bytes": (_i, [_vp, _i, _i, _i, C.POINTER(_sz)]),
     "dmn_loop_last_ms": (_i, [_vp, C.POINTER(_f)]),
     "dmn_bench_dominant_kernel": (_i, [_vp, _i, _i, _i, _i, _vp, _sz, _vp, C.POINTER(_f), C.POINTER(C.c_double)]),
+    "dmn_bench_stream": (_i, [_i, _vp, _vp, _sz, _i, _vp, C.POINTER(_f)]),
+    "dmn_bench_mfma": (_i, [_i, _i, _i, _i, _vp, _vp, C.POINTER(_f), C.POINTER(C.c_double)]),
     "dmn_train_create": (_i, [C.POINTER(DmnUnetCfg), _i, C.POINTER(_vp)]),
     "dmn_train_destroy": (None, [_vp]),
     "dmn_train_set_class_labels": (_i, [_vp, _vp]),

@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libdmn_hip.so")
 SOURCES = ["dmn_conv.hip", "dmn_elem.hip", "dmn_attn.hip", "dmn_linattn.hip", "dmn_sampler.hip", "dmn_unet.cpp", "dmn_api.cpp",
-           "dmn_train_gemm.hip", "dmn_train_ops.hip", "dmn_train.cpp"]
+           "dmn_train_gemm.hip", "dmn_train_ops.hip", "dmn_train.cpp", "dmn_peaks.hip"]
 ARCH = "gfx950"
 
 

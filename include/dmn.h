@@ -132,6 +132,16 @@ int dmn_loop_last_ms(DmnUnet* u, float* ms);
 int dmn_bench_dominant_kernel(DmnUnet* u, int B, int H, int W, int iters, void* workspace, size_t workspace_bytes,
                               void* stream, float* avg_ms, double* alg_bytes);
 
+/* Measured ceilings of the device: `iters` back-to-back launches timed with HIP events on `stream`.
+ * dmn_bench_stream: mode 0 copies `bytes` from src to dst (HBM traffic 2 x bytes per launch), mode 1 only reads src
+ * (dst: any 4 writable bytes). Buffers 16-byte aligned, bytes a multiple of 16.
+ * dmn_bench_mfma: register-resident matrix-core loop, kind 0 v_mfma_f32_16x16x32_bf16, kind 1 v_mfma_f32_16x16x4_f32;
+ * 256 x wgs_per_cu workgroups of four waves, 32 x n_outer instructions per wave; sink: >= 65536 * wgs_per_cu floats;
+ * flops receives the operations of one launch.
+ * No counterpart in the reference: measurement hooks used by bench.py. */
+int dmn_bench_stream(int mode, void* dst, const void* src, size_t bytes, int iters, void* stream, float* avg_ms);
+int dmn_bench_mfma(int kind, int wgs_per_cu, int n_outer, int iters, float* sink, void* stream, float* avg_ms, double* flops);
+
 /* ---- training step ------------------------------------------------------------------------------------------------
  * DDPM.training_step (models/ddpm.py:43-57) and what its Lightning trainer does with the returned loss: backward
  * through Unet.forward (modules/unet.py:131-168), gradient clipping (trainer.gradient_clip_val) and AdamW

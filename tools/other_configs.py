@@ -1,4 +1,4 @@
-"""Timing of the other BASELINE configurations on one GPU (reported in DESIGN.md; bench.py measures configs[1]).
+"""Timing of the other baseline configurations on one GPU (bench.py measures only the headline configuration).
 
 C3 shape: improved DDPM (learned variance), 64x64, 64 images per GPU, T=1000.
 C4 shape: VE-SDE predictor-corrector, 32x32, B=64, N=1000: reverse_diffusion + langevin (2 NFE/step) and the YAML
