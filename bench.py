@@ -115,7 +115,7 @@ def train_step_extra(dev, rank, world, dist):
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if int(flag.item()) == 0:
         return None
-    warm, iters = 3, 10
+    warm, iters = 4, 20
     for i in range(warm):
         step(1 + i, True)
     if dist is not None:

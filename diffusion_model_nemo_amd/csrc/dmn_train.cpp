@@ -825,7 +825,18 @@ int run_step(DmnTrainer* tr, const float* params, float* grads, const StepIO& io
             one.arena = (r.a.used + 255) & ~(size_t)255;
         }
     }
-    if (rc) return rc;
+    if (rc) {
+        // kernels already queued on the internal streams still use the caller's buffers: drain them before the
+        // caller learns of the failure and may free the workspace
+        if (!dry) {
+            for (int k = 0; k < nchain; ++k) {
+                if (tr->side[k]) (void)hipStreamSynchronize(tr->side[k]);
+                if (k && tr->chain[k]) (void)hipStreamSynchronize(tr->chain[k]);
+            }
+            (void)hipStreamSynchronize(s);
+        }
+        return rc;
+    }
     if (!dry) {
         // the layout change below reads what every stream accumulated
         for (int k = 0; k < nchain; ++k)

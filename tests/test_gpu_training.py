@@ -281,3 +281,55 @@ def test_ddpm_model_training_step_feeds_autograd_and_train_batch_learns():
     for _ in range(20):
         last = float(m.train_batch({"pixel_values": x0.cuda()}, t=t.cuda(), noise=noise.cuda()))
     assert last < 0.9 * first, (first, last)
+
+
+def test_full_size_step_properties():
+    """Configuration-5 size (32 images of 128x128 per GPU), where the CPU oracle would take minutes: properties that
+    need no oracle. (1) the network output of the training forward equals the sampling path's forward -- a separate set
+    of kernels, itself pinned to the oracle at small sizes -- on the same x_t; (2) the loss equals the mean squared
+    error of that output computed by torch; (3) the mean-loss gradient of the batch is the average of its two
+    half-batch gradients (the halves run as different chain splits inside the library); (4) a repeated call gives the
+    same gradients up to the summation order of the float atomics. Tolerances: output 2e-4 absolute, loss 1e-5
+    relative, gradients 5e-5 of each tensor's largest entry (1e-5 for the repeat)."""
+    B, S = 32, 128
+    u, tr, sd = build()
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    x0 = torch.rand(B, 3, S, S, device="cuda", generator=gen) * 2 - 1
+    noise = torch.randn(B, 3, S, S, device="cuda", generator=gen)
+    t = torch.randint(0, 1000, (B,), device="cuda", generator=gen)
+    t[0], t[1] = 0, 999
+    c = R.ddpm_constants(1000, "cosine")
+    sa, sb = c["sqrt_alphas_cumprod"].cuda(), c["sqrt_one_minus_alphas_cumprod"].cuda()
+    out = torch.empty(B, 3, S, S, device="cuda")
+    loss = float(tr.loss_and_grads(x0, t, noise, sa, sb, model_out=out))
+    full = tr.grads.clone()
+    # (1), (2)
+    x_t = sa[t].view(B, 1, 1, 1) * x0 + sb[t].view(B, 1, 1, 1) * noise
+    with torch.no_grad():
+        want = u.eval()(x_t, t)
+    u.train()
+    assert float((out - want).abs().max()) <= 2e-4
+    mse = float(((out.double() - noise.double()) ** 2).mean())
+    assert abs(loss - mse) <= 1e-5 * mse, (loss, mse)
+    # (4)
+    tr.loss_and_grads(x0, t, noise, sa, sb)
+    names = [n for n, _ in u.named_parameters()]
+
+    def close(a_flat, b_flat, tol):
+        tr.grads.copy_(a_flat)
+        a = {n: tr.grad_of(n).clone() for n in names}
+        tr.grads.copy_(b_flat)
+        for n in names:
+            b = tr.grad_of(n)
+            scale = float(a[n].abs().max())
+            assert float((a[n] - b).abs().max()) <= tol * scale + 1e-7, n
+
+    close(full, tr.grads.clone(), 1e-5)
+    # (3)
+    h = B // 2
+    la = float(tr.loss_and_grads(x0[:h].contiguous(), t[:h].contiguous(), noise[:h].contiguous(), sa, sb))
+    ga = tr.grads.clone()
+    lb = float(tr.loss_and_grads(x0[h:].contiguous(), t[h:].contiguous(), noise[h:].contiguous(), sa, sb))
+    gb = tr.grads.clone()
+    assert abs(0.5 * (la + lb) - loss) <= 1e-5 * loss
+    close(full, 0.5 * (ga + gb), 5e-5)
