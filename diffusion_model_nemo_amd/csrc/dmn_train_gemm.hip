@@ -752,6 +752,15 @@ template <typename T, bool BF> static void pgemm_halo_dispatch(const PGemmArgs& 
     else pgemm_halo_kernel<T, 32, BF><<<grid, 256, 0, s>>>(a);
 }
 
+static int pgemm_small_below() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("DMN_PGEMM_SMALL");
+        v = e ? atoi(e) : 512;
+    }
+    return v;
+}
+
 int pgemm_stats_supported(const PGemmArgs& a) {
     const int hw = a.Ho * a.Wo;
     const bool halo = a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && (a.Ho & 7) == 0 && (a.Wo & 7) == 0;
@@ -767,7 +776,12 @@ int launch_pgemm(const PGemmArgs& a, hipStream_t s) {
     const bool slow = (a.Cin & 31) != 0 || (a.ldin & 3) != 0 || (reinterpret_cast<uintptr_t>(a.in) & 15) != 0;
     const int hw = a.Ho * a.Wo;
     const int pm = (!slow && a.tmode == 1 && a.stride == 2 && (a.Ho & 1) == 0 && (a.Wo & 1) == 0 && ((hw >> 2) % 64) == 0) ? 1 : 0;
-    const int bn = a.N > 32 ? 64 : 32;
+    // launches with few workgroups (the low-resolution levels) take the narrow channel tile: twice the workgroups, so
+    // that a CU holds two whose load latencies overlap
+    const bool is_halo = !slow && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && (a.Ho & 7) == 0 && (a.Wo & 7) == 0 &&
+                         a.Hi == a.Ho && a.Wi == a.Wo;
+    const long long wgs64 = (is_halo ? (long long)a.B * (a.Ho >> 3) * (a.Wo >> 3) : (long long)(M + 63) / 64) * ((a.N + 63) / 64);
+    const int bn = (a.N > 32 && !(a.N % 32 == 0 && wgs64 < pgemm_small_below())) ? 64 : 32;
     if (!slow && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && (a.Ho & 7) == 0 && (a.Wo & 7) == 0 && a.Hi == a.Ho &&
         a.Wi == a.Wo) {
         dim3 hgrid(a.B * (a.Ho >> 3) * (a.Wo >> 3), (a.N + bn - 1) / bn);
