@@ -117,7 +117,8 @@ template <typename T> __global__ __launch_bounds__(256) void gn_apply_kernel(con
     }
 }
 
-// per (image, channel): sum dz * xhat, sum dz, sum dy. grid (splits, B); thread = fixed 4 channels, strided pixels.
+// per (image, channel): sum dz * xhat, sum dz, sum dy. grid (splits, B); C/4 divides 256 (checked by the launcher): a thread keeps four
+// fixed channels and walks pixels with a stride, four pixels' loads issued before the first use.
 template <typename T> __global__ __launch_bounds__(256) void gn_bwd_sums_kernel(const GnArgs a) {
     const T* x = reinterpret_cast<const T*>(a.x);
     const T* dy = reinterpret_cast<const T*>(a.dy);
@@ -131,9 +132,9 @@ template <typename T> __global__ __launch_bounds__(256) void gn_bwd_sums_kernel(
     const f32x4 ga = *reinterpret_cast<const f32x4*>(a.gamma + c), be = *reinterpret_cast<const f32x4*>(a.beta + c);
     float s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     const size_t img = (size_t)b * a.HW * a.C;
-    for (int p = blockIdx.x * npl + pl; p < a.HW; p += gridDim.x * npl) {
-        const f32x4 v = Io<T>::ld4(x + img + (size_t)p * a.C + c);
-        const f32x4 d = Io<T>::ld4(dy + img + (size_t)p * a.C + c);
+    const T* xp = x + img + c;
+    const T* dp = dy + img + c;
+    auto one = [&](const f32x4& v, const f32x4& d) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float xh = (v[e] - mean) * rstd;
@@ -143,7 +144,20 @@ template <typename T> __global__ __launch_bounds__(256) void gn_bwd_sums_kernel(
             s1[e] += dz;
             s2[e] += d[e];
         }
+    };
+    int p = blockIdx.x * npl + pl;
+    const int st = gridDim.x * npl;
+    for (; p + 3 * st < a.HW; p += 4 * st) {
+        f32x4 v[4], d[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            v[u] = Io<T>::ld4(xp + (size_t)(p + u * st) * a.C);
+            d[u] = Io<T>::ld4(dp + (size_t)(p + u * st) * a.C);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) one(v[u], d[u]);
     }
+    for (; p < a.HW; p += st) one(Io<T>::ld4(xp + (size_t)p * a.C), Io<T>::ld4(dp + (size_t)p * a.C));
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         sh[tid * 12 + e] = s0[e];
