@@ -206,6 +206,8 @@ def main():
         if tj.get("batch") == B and tj.get("image_size") == S and tj.get("dtype") == a.dtype:
             traffic = tj["hbm_bytes_per_launch"]
 
+    train = None if a.no_train else train_step_extra(dev, rank, world, dist)
+
     # what this device sustains, beside the nominal peaks the roofline is priced against (rank 0, single GPU only)
     peaks = None
     if rank == 0 and world == 1:
@@ -220,8 +222,6 @@ def main():
                  "mfma_f32_TFLOPs": max(m["TFLOPs"] for m in pk["mfma"] if "bf16" not in m["instruction"])}
         del pk
         torch.cuda.empty_cache()
-
-    train = None if a.no_train else train_step_extra(dev, rank, world, dist)
 
     if rank == 0:
         imgs = world * B * a.steps

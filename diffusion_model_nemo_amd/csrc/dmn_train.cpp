@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <cmath>
 
 #include <deque>
@@ -84,6 +85,16 @@ struct DmnTrainer {
     // each with its own side stream.
     static constexpr int kMaxChains = 4;
     hipStream_t side[kMaxChains] = {}, chain[kMaxChains] = {};
+    // The device exposes few hardware queues (four by default) and the runtime maps every stream of the process onto
+    // one of them; two streams on one queue run their kernels in turn. A process that already holds other streams
+    // (a framework's side streams, a collective library's) would otherwise find a chain sharing a queue with its own
+    // weight-gradient stream or with the other chain (measured: 12.4 -> 13.8 or 16.7 ms per step). The trainer therefore
+    // creates candidate streams and keeps those that a timing probe shows on queues of their own.
+    std::vector<hipStream_t> pool;          // every stream created (kept until destroy, also the rejected ones:
+                                            // freeing one would hand its queue slot to the next candidate)
+    hipStream_t picked_for = nullptr;       // caller stream the roles were picked against
+    int picked = 0;                         // roles filled: chain[1], side[0], side[1], chain[2], side[2], ...
+    bool have_pick = false;
     int max_chains = 2;
     std::vector<hipEvent_t> events;
     size_t ev_next = 0;
@@ -729,6 +740,67 @@ int chains_for(const DmnTrainer* tr, int B) {
     return 1;
 }
 
+// true when kernels launched on a and b run one after the other (same hardware queue): two 300 us single-wave waits
+// take ~300 us on separate queues and ~600 us on a shared one. Best of two trials.
+bool streams_share_queue(hipStream_t a, hipStream_t b) {
+    double best = 1e30;
+    for (int trial = 0; trial < 2; ++trial) {
+        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return false;
+        const auto t0 = std::chrono::steady_clock::now();
+        if (launch_spin(300, a) != DMN_OK || launch_spin(300, b) != DMN_OK) return false;
+        (void)hipStreamSynchronize(a);
+        (void)hipStreamSynchronize(b);
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (us < best) best = us;
+    }
+    return best > 480.0;
+}
+
+// Fills chain[1..] and side[0..] for `nchain` chains against the caller's stream s. Roles are filled in the order of
+// what a shared queue would cost: the second chain, then the weight-gradient streams.
+int pick_streams(DmnTrainer* tr, hipStream_t s, int nchain) {
+    const int need = (nchain - 1) + (tr->use_side ? nchain : 0);
+    if (tr->have_pick && tr->picked_for == s && tr->picked >= need) return DMN_OK;
+    std::vector<hipStream_t> distinct, rest;
+    size_t next = 0;
+    const size_t max_pool = 12;
+    while ((int)distinct.size() < need) {
+        hipStream_t c = nullptr;
+        if (next < tr->pool.size()) {
+            c = tr->pool[next];
+        } else if (tr->pool.size() < max_pool) {
+            DMN_HIP_CHECK(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
+            tr->pool.push_back(c);
+            if (launch_spin(0, c) != DMN_OK) return DMN_ERR_HIP;   // first use: the runtime binds the stream to a queue
+        } else {
+            break;
+        }
+        ++next;
+        bool shared = streams_share_queue(c, s);
+        for (size_t i = 0; i < distinct.size() && !shared; ++i) shared = streams_share_queue(c, distinct[i]);
+        (shared ? rest : distinct).push_back(c);
+    }
+    // fewer separate queues than roles (more chains than queues, or a lower queue limit): the rest share
+    for (size_t i = 0; (int)distinct.size() < need; ++i) {
+        if (rest.empty()) return DMN_ERR_HIP;
+        distinct.push_back(rest[i % rest.size()]);
+    }
+    int k = 0;
+    auto take = [&]() { return distinct[k++]; };
+    for (int c = 0; c < DmnTrainer::kMaxChains; ++c) tr->side[c] = tr->chain[c] = nullptr;
+    if (nchain > 1) tr->chain[1] = take();
+    if (tr->use_side) tr->side[0] = take();
+    if (tr->use_side && nchain > 1) tr->side[1] = take();
+    for (int c = 2; c < nchain; ++c) {
+        tr->chain[c] = take();
+        if (tr->use_side) tr->side[c] = take();
+    }
+    tr->picked_for = s;
+    tr->picked = need;
+    tr->have_pick = true;
+    return DMN_OK;
+}
+
 int run_step(DmnTrainer* tr, const float* params, float* grads, const StepIO& io, int B, int H, int W, void* ws, size_t ws_bytes,
              hipStream_t s, bool dry, Sizes* sz) {
     const DmnUnetCfg& c = tr->cfg;
@@ -755,12 +827,12 @@ int run_step(DmnTrainer* tr, const float* params, float* grads, const StepIO& io
                     tr->sz_total);
         DMN_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, DMN_ERR_INVALID, "training workspace must be 256-byte aligned");
         if (!tr->join) {
-            for (int k = 0; k < DmnTrainer::kMaxChains; ++k) {
-                DMN_HIP_CHECK(hipStreamCreateWithFlags(&tr->side[k], hipStreamNonBlocking));
-                if (k) DMN_HIP_CHECK(hipStreamCreateWithFlags(&tr->chain[k], hipStreamNonBlocking));
-            }
             DMN_HIP_CHECK(hipEventCreateWithFlags(&tr->fork, hipEventDisableTiming));
             DMN_HIP_CHECK(hipEventCreateWithFlags(&tr->join, hipEventDisableTiming));
+        }
+        {
+            int rcp = pick_streams(tr, s, nchain);
+            if (rcp) return rcp;
         }
         if (!tr->descs_dev) {   // first step on the device: upload the layout table (creation itself needs no GPU)
             DMN_HIP_CHECK(hipMalloc((void**)&tr->descs_dev, tr->descs.size() * sizeof(RepackDesc)));
@@ -902,10 +974,7 @@ extern "C" void dmn_train_destroy(DmnTrainer* tr) {
     for (hipEvent_t e : tr->events) (void)hipEventDestroy(e);
     if (tr->join) (void)hipEventDestroy(tr->join);
     if (tr->fork) (void)hipEventDestroy(tr->fork);
-    for (int k = 0; k < DmnTrainer::kMaxChains; ++k) {
-        if (tr->side[k]) (void)hipStreamDestroy(tr->side[k]);
-        if (tr->chain[k]) (void)hipStreamDestroy(tr->chain[k]);
-    }
+    for (hipStream_t st : tr->pool) (void)hipStreamDestroy(st);
     delete tr;
 }
 

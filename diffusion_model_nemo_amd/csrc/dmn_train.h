@@ -148,3 +148,6 @@ struct AdamWArgs {
     float grad_scale;       // multiplies g before everything else (1/world_size after a summing all-reduce)
 };
 int launch_adamw(const AdamWArgs& a, hipStream_t s);
+// One wave that waits `us` microseconds of the constant 100 MHz counter and exits (bounded by an iteration count as
+// well): the probe with which the trainer finds out which of its streams share a hardware queue.
+int launch_spin(int us, hipStream_t s);

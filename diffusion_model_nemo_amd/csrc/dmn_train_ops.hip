@@ -1124,6 +1124,23 @@ int launch_unpack_grads(const RepackDesc* descs_dev, int n_desc, long long max_n
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }
+namespace {
+__global__ void spin_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < (1 << 18); ++i) {   // leaves after at most 2^18 polls whatever the counter does
+        if (__builtin_amdgcn_s_memrealtime() - t0 >= ticks) break;
+        __builtin_amdgcn_s_sleep(16);
+    }
+}
+}   // namespace
+
+int launch_spin(int us, hipStream_t s) {
+    DMN_REQUIRE(us >= 0 && us <= 5000, DMN_ERR_INVALID, "spin: %d us", us);
+    spin_kernel<<<1, 64, 0, s>>>((unsigned long long)us * 100ull);
+    DMN_LAUNCH_CHECK();
+    return DMN_OK;
+}
+
 int launch_sqnorm(const float* g, long long n, float* out_sq, hipStream_t s) {
     sqnorm_kernel<<<grid_for(n, 2048, 1024), 256, 0, s>>>(g, n, out_sq);
     DMN_LAUNCH_CHECK();

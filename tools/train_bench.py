@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"], help="matrix-core operand type")
     ap.add_argument("--activations", default=None, choices=["bf16", "fp32"], help="storage of saved activations")
+    ap.add_argument("--extra-streams", type=int, default=0, help="streams created and used before the trainer's own (queue-sharing study)")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -31,6 +32,11 @@ def main():
         dist.init_process_group("nccl")
     from diffusion_model_nemo_amd.modules import GaussianDiffusion, Unet
     from diffusion_model_nemo_amd.training import UnetTrainer, cosine_annealing_lr
+    extra = [torch.cuda.Stream() for _ in range(a.extra_streams)]
+    for st in extra:
+        with torch.cuda.stream(st):
+            torch.zeros(16, device="cuda").add_(1)
+    torch.cuda.synchronize()
     torch.manual_seed(1234)
     u = Unet(input_dim=a.size, dim=32, dim_mults=[1, 2, 4, 8], channels=3, resnet_block_groups=8, use_convnext=False,
              dropout=0.0, compute_dtype=a.dtype).cuda()
