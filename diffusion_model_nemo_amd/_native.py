@@ -50,6 +50,7 @@ SIGNATURES = {
     "dmn_loop_last_ms": (_i, [_vp, C.POINTER(_f)]),
     "dmn_bench_dominant_kernel": (_i, [_vp, _i, _i, _i, _i, _vp, _sz, _vp, C.POINTER(_f), C.POINTER(C.c_double)]),
     "dmn_bench_stream": (_i, [_i, _vp, _vp, _sz, _i, _vp, C.POINTER(_f)]),
+    "dmn_streams_share_queue": (_i, [_vp, _vp, C.POINTER(_i)]),
     "dmn_bench_mfma": (_i, [_i, _i, _i, _i, _vp, _vp, C.POINTER(_f), C.POINTER(C.c_double)]),
     "dmn_train_create": (_i, [C.POINTER(DmnUnetCfg), _i, C.POINTER(_vp)]),
     "dmn_train_destroy": (None, [_vp]),

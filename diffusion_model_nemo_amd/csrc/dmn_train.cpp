@@ -931,6 +931,12 @@ int run_step(DmnTrainer* tr, const float* params, float* grads, const StepIO& io
 
 }   // namespace
 
+extern "C" int dmn_streams_share_queue(void* a, void* b, int* shared) {
+    DMN_REQUIRE(shared, DMN_ERR_INVALID, "dmn_streams_share_queue: null argument");
+    *shared = streams_share_queue((hipStream_t)a, (hipStream_t)b) ? 1 : 0;
+    return DMN_OK;
+}
+
 extern "C" int dmn_train_create(const DmnUnetCfg* cfg, int loss_kind, DmnTrainer** out) {
     DMN_REQUIRE(cfg && out, DMN_ERR_INVALID, "dmn_train_create: null argument");
     DMN_REQUIRE(cfg->n_mults >= 1 && cfg->n_mults <= DMN_MAX_MULTS, DMN_ERR_INVALID, "n_mults=%d", cfg->n_mults);

@@ -213,7 +213,11 @@ class GaussianDiffusion(AbstractDiffusionProcess):
             ws = model.workspace(B, H, W, dev, sampling=True)
             handle = model.native_handle()
             cur = torch.cuda.current_stream(dev)
-            side = self.__dict__.setdefault("_streams", {}).setdefault(str(dev), torch.cuda.Stream(dev))
+            # graph capture needs a non-default stream: the caller's own when it already is one
+            if cur != torch.cuda.default_stream(dev):
+                side = cur
+            else:
+                side = self.__dict__.setdefault("_streams", {}).setdefault(str(dev), torch.cuda.Stream(dev))
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 N.check(N.lib().dmn_ddpm_sample_loop(

@@ -162,7 +162,11 @@ class PredictorCorrectorSampler(torch.nn.Module):
         ws = model.workspace(B, H, W, device, sampling=True)
         handle = model.native_handle()
         cur = torch.cuda.current_stream(device)
-        side = self.__dict__.setdefault("_streams", {}).setdefault(str(device), torch.cuda.Stream(device))
+        # graph capture needs a non-default stream: the caller's own when it already is one
+        if cur != torch.cuda.default_stream(device):
+            side = cur
+        else:
+            side = self.__dict__.setdefault("_streams", {}).setdefault(str(device), torch.cuda.Stream(device))
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             N.check(N.lib().dmn_pc_sample_loop(

@@ -142,6 +142,11 @@ int dmn_bench_dominant_kernel(DmnUnet* u, int B, int H, int W, int iters, void* 
 int dmn_bench_stream(int mode, void* dst, const void* src, size_t bytes, int iters, void* stream, float* avg_ms);
 int dmn_bench_mfma(int kind, int wgs_per_cu, int n_outer, int iters, float* sink, void* stream, float* avg_ms, double* flops);
 
+/* Whether kernels launched on streams a and b run in turn because the runtime mapped both onto one hardware queue
+ * (the device exposes few: four by default). A timing probe: two 300 us single-wave waits, twice; synchronises both
+ * streams. No counterpart in the reference: lets a caller that wants concurrent chains pick streams that can overlap. */
+int dmn_streams_share_queue(void* a, void* b, int* shared);
+
 /* ---- training step ------------------------------------------------------------------------------------------------
  * DDPM.training_step (models/ddpm.py:43-57) and what its Lightning trainer does with the returned loss: backward
  * through Unet.forward (modules/unet.py:131-168), gradient clipping (trainer.gradient_clip_val) and AdamW

@@ -279,6 +279,33 @@ def test_sampling_is_shard_invariant_and_graph_equals_eager():
     x2 = torch.empty((4, 3, 32, 32), device="cuda")
     gd._run_chain(lambda a, t: u(a, t), x2, 0, 20, True, "last", 42, 0)
     assert torch.equal(x2.cpu(), full)
+    # on a caller's own (non-default) stream the chain is captured and replayed there; same images
+    st = torch.cuda.Stream("cuda")
+    with torch.cuda.stream(st):
+        own = gd.p_sample_loop(u, (4, 3, 32, 32), device="cuda", seed=42, return_device_tensor=True)
+    st.synchronize()
+    assert torch.equal(own.cpu(), full)
+
+
+def test_stream_queue_probe():
+    """dmn_streams_share_queue: a stream certainly shares a hardware queue with itself; among several fresh streams at
+    least two land on separate queues (the device exposes more than one)."""
+    import ctypes as C
+    from diffusion_model_nemo_amd import _native as N
+    streams = [torch.cuda.Stream("cuda") for _ in range(4)]
+    for st in streams:
+        with torch.cuda.stream(st):
+            torch.zeros(4, device="cuda").add_(1)
+    torch.cuda.synchronize()
+    sh = C.c_int(-1)
+    N.check(N.lib().dmn_streams_share_queue(streams[0].cuda_stream, streams[0].cuda_stream, C.byref(sh)))
+    assert sh.value == 1
+    separate = 0
+    for st in streams[1:]:
+        N.check(N.lib().dmn_streams_share_queue(streams[0].cuda_stream, st.cuda_stream, C.byref(sh)))
+        separate += 1 - sh.value
+    assert separate >= 1
+    assert N.lib().dmn_streams_share_queue(None, None, None) != 0
 
 
 @pytest.mark.parametrize("tag,kind,pred,corr,n_steps", [

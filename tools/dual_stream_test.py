@@ -17,21 +17,64 @@ def build():
                 dropout=0.0, compute_dtype="bf16").to(dev).eval()
 
 
+_all_streams = []
+
+
+def distinct_streams(n):
+    """n torch streams that a timing probe shows on hardware queues of their own (as far as the device has them)."""
+    import ctypes as C
+    from diffusion_model_nemo_amd import _native as N
+    out = []
+    for _ in range(16):
+        if len(out) == n:
+            break
+        st = torch.cuda.Stream(dev)
+        _all_streams.append(st)
+        with torch.cuda.stream(st):
+            torch.zeros(4, device=dev).add_(1)
+        sh = C.c_int(0)
+        ok = True
+        for o in out:
+            N.check(N.lib().dmn_streams_share_queue(st.cuda_stream, o.cuda_stream, C.byref(sh)))
+            if sh.value:
+                ok = False
+                break
+        if ok:
+            out.append(st)
+    print(f"  {len(out)} of {n} streams on separate queues ({len(_all_streams)} created)", flush=True)
+    while len(out) < n:
+        out.append(torch.cuda.Stream(dev))
+    return out
+
+
 def run(nsplit):
     B = 64 // nsplit
     nets = [build() for _ in range(nsplit)]
     gds = [GaussianDiffusion(timesteps=T, schedule_name="cosine") for _ in range(nsplit)]
-    streams = [torch.cuda.Stream(dev) for _ in range(nsplit)]
+    streams = distinct_streams(nsplit)
     outs = [None] * nsplit
 
-    def once():
-        for i in range(nsplit):
-            with torch.cuda.stream(streams[i]):
-                outs[i] = gds[i].p_sample_loop(nets[i], (B, 3, 64, 64), device=dev, seed=7, image_offset=i * B,
-                                               return_device_tensor=True)
+    def chain(i):
+        with torch.cuda.stream(streams[i]):
+            outs[i] = gds[i].p_sample_loop(nets[i], (B, 3, 64, 64), device=dev, seed=7, image_offset=i * B,
+                                           return_device_tensor=True)
+
+    def once(threads=True):
+        if not threads:   # first pass: handle creation, weight upload and graph capture must not overlap another capture
+            for i in range(nsplit):
+                chain(i)
+            torch.cuda.synchronize()
+            return
+        # one host thread per chain (the native loop releases the GIL): a chain's graph launches may block its thread
+        import threading
+        th = [threading.Thread(target=chain, args=(i,)) for i in range(nsplit)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
         torch.cuda.synchronize()
 
-    once()
+    once(threads=False)
     t0 = time.perf_counter()
     once()
     el = time.perf_counter() - t0
