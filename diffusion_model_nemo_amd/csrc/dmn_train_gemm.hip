@@ -312,6 +312,127 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const PGemmArgs a, const int
     if (a.stats) tile_stats<BN>(s1, s2, Bs, n0, a.N, a.N / a.statsG, a.stats + (size_t)(m0 / (a.Ho * a.Wo)) * a.statsG * 2);
 }
 
+// 3x3, stride 1, pad 1 with 32 input and <= 32 output channels (the full-resolution level, where a workgroup's nine
+// weight taps -- 36 KB -- outweigh the 13 KB of input it stages): the weights are loaded ONCE per workgroup and stay in
+// LDS while it walks over `tpw` consecutive 8x8-pixel tiles, the next tile's halo in flight during the current tile's
+// multiplications. Needs the vector epilogue (tile_store_ok), which the launcher checks.
+template <typename T, bool BF>
+__global__ __launch_bounds__(256) void pgemm_halo_c32_kernel(const PGemmArgs a, const int ntiles, const int tpw) {
+    const T* in = reinterpret_cast<const T*>(a.in);
+    T* out = reinterpret_cast<T*>(a.out);
+    constexpr int BN = 32, LDB = BN + 4, NJ = 2, LDH = 36;
+    // BF: both operands live in LDS as bfloat16 in the order the matrix core wants them -- a lane's eight k slots
+    // (channels 16*(i>>2) + 4q + (i&3)) are 16 contiguous bytes, for the weights per (tap, channel tile, lane), for the
+    // halo per pixel at a pitch of 80 bytes -- so an operand is ONE 16-byte LDS read and the loop holds no conversions
+    constexpr int HP = 40;   // halo pitch in bfloat16 elements
+    constexpr int WS_FLOATS = BF ? 9 * NJ * 64 * 4 : 9 * 32 * LDB, HS_FLOATS = BF ? 100 * HP / 2 : 100 * LDH;
+    __shared__ __attribute__((aligned(16))) float Ws[WS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float Hs[HS_FLOATS];
+    __shared__ float Es[64 * LDB];
+    __bf16* Wf = reinterpret_cast<__bf16*>(Ws);
+    __bf16* Hb = reinterpret_cast<__bf16*>(Hs);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+    const int tw = a.Wo >> 3, th = a.Ho >> 3, tpi = tw * th;
+    const int pA = 16 * wave + r, py = pA >> 3, px = pA & 7;
+    const bool wvec = ((reinterpret_cast<uintptr_t>(a.w) & 15) == 0) && ((a.ldw & 3) == 0);
+    const int t0 = blockIdx.x * tpw, t1 = min(t0 + tpw, ntiles);
+    f32x4 hr[4];
+    auto load_halo = [&](int t) {
+        const int b = t / tpi, trem = t - b * tpi;
+        const int oy0 = (trem / tw) * 8, ox0 = (trem % tw) * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (idx < 800) {
+                const int pix = idx >> 3, c4 = (idx & 7) * 4;
+                const int hy = pix / 10, hx = pix - hy * 10;
+                const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+                if (iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi)
+                    v = Io<T>::ld4(in + ((size_t)(b * a.Hi + iy) * a.Wi + ix) * a.ldin + c4);
+            }
+            hr[i] = v;
+        }
+    };
+    load_halo(t0);
+    for (int i = tid; i < 288 * 8; i += 256) {
+        const int row = i >> 3, n = (i & 7) * 4;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* p = a.w + (size_t)row * a.ldw + n;
+        if (wvec && n + 3 < a.N) {
+            v = *reinterpret_cast<const f32x4*>(p);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n + e < a.N) v[e] = p[e];
+        }
+        if constexpr (BF) {
+            const int tap = row >> 5, c = row & 31, qq = (c >> 2) & 3, ii = 4 * (c >> 4) + (c & 3);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Wf[(((tap * NJ + ((n + e) >> 4)) * 64 + qq * 16 + ((n + e) & 15)) << 3) + ii] = (__bf16)v[e];
+        } else {
+            *reinterpret_cast<f32x4*>(&Ws[row * LDB + n]) = v;
+        }
+    }
+    for (int t = t0; t < t1; ++t) {
+        const int b = t / tpi, trem = t - b * tpi;
+        const int oy0 = (trem / tw) * 8, ox0 = (trem % tw) * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < 800) {
+                if constexpr (BF) {
+                    const int c4 = (idx & 7) * 4;
+                    *reinterpret_cast<bf16x4*>(&Hb[(idx >> 3) * HP + ((c4 >> 2) & 3) * 8 + 4 * (c4 >> 4)]) =
+                        bf16x4{(__bf16)hr[i][0], (__bf16)hr[i][1], (__bf16)hr[i][2], (__bf16)hr[i][3]};
+                } else {
+                    *reinterpret_cast<f32x4*>(&Hs[(idx >> 3) * LDH + (idx & 7) * 4]) = hr[i];
+                }
+            }
+        }
+        __syncthreads();   // halo (and, the first time, the weights) visible; the previous tile's Es reads are over
+        if (t + 1 < t1) load_halo(t + 1);
+        f32x4 acc[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int hy = py + (a.tmode ? 2 - ky : ky);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int hx = px + (a.tmode ? 2 - kx : kx);
+                if constexpr (BF) {
+                    const bf16x8 a8 = *reinterpret_cast<const bf16x8*>(&Hb[(hy * 10 + hx) * HP + q * 8]);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const bf16x8 b8 = *reinterpret_cast<const bf16x8*>(&Wf[(((ky * 3 + kx) * NJ + j) * 64 + lane) << 3]);
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, b8, acc[j], 0, 0, 0);
+                    }
+                } else {
+                    const float* hp = &Hs[(hy * 10 + hx) * LDH + 4 * q];
+                    const f32x4 ac0 = *reinterpret_cast<const f32x4*>(hp), ac1 = *reinterpret_cast<const f32x4*>(hp + 16);
+                    const float* Bt = &Ws[(ky * 3 + kx) * 32 * LDB];
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            const float av = c == 0 ? ac0[s] : ac1[s];
+                            const float* brow = &Bt[(16 * c + 4 * q + s) * LDB + r];
+#pragma unroll
+                            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, brow[16 * j], acc[j], 0, 0, 0);
+                        }
+                }
+            }
+        }
+        float s1[NJ], s2[NJ];
+        // the barrier inside store_tile also ends every wave's reads of Hs before the next tile's halo is written
+        store_tile<T, BN>(Es, acc, a.bias, a.accumulate, 0, a.N, [&](int p) -> T* {
+            return out + ((size_t)(b * a.Ho + oy0 + (p >> 3)) * a.Wo + ox0 + (p & 7)) * a.ldout;
+        }, s1, s2);
+        if (a.stats) tile_stats<BN>(s1, s2, Es, 0, a.N, a.N / a.statsG, a.stats + (size_t)b * a.statsG * 2);
+    }
+}
+
 // 3x3, stride 1, pad 1 (forward of the ResnetBlock convolutions and, with the taps mirrored, their input gradient):
 // one workgroup = 8x8 output pixels. For every 32-channel chunk the 10x10 halo of the tile is staged in LDS once and
 // all nine taps read their A operand from it (1.56 x the input instead of 9 x through L2); weights as in pgemm_kernel.
@@ -752,6 +873,16 @@ template <typename T, bool BF> static void pgemm_halo_dispatch(const PGemmArgs& 
     else pgemm_halo_kernel<T, 32, BF><<<grid, 256, 0, s>>>(a);
 }
 
+static int pgemm_c32_tiles() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("DMN_PGEMM_C32_TILES");   // 0 switches the weight-resident kernel off
+        v = e ? atoi(e) : 8;
+        if (v > 64) v = 64;
+    }
+    return v;
+}
+
 static int pgemm_small_below() {
     static int v = -1;
     if (v < 0) {
@@ -784,7 +915,23 @@ int launch_pgemm(const PGemmArgs& a, hipStream_t s) {
     const int bn = (a.N > 32 && !(a.N % 32 == 0 && wgs64 < pgemm_small_below())) ? 64 : 32;
     if (!slow && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && (a.Ho & 7) == 0 && (a.Wo & 7) == 0 && a.Hi == a.Ho &&
         a.Wi == a.Wo) {
-        dim3 hgrid(a.B * (a.Ho >> 3) * (a.Wo >> 3), (a.N + bn - 1) / bn);
+        const int vec = a.adt == 1 ? 8 : 4;
+        const int ntiles = a.B * (a.Ho >> 3) * (a.Wo >> 3);
+        if (a.Cin == 32 && a.N <= 32 && a.N % vec == 0 && a.ldout % vec == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 &&
+            pgemm_c32_tiles() > 0) {
+            // tiles per workgroup: as many as leave the launch with at least 512 workgroups (two per CU fit by LDS),
+            // but never fewer than two, so that small launches run the same multi-tile path as large ones
+            int tpw = pgemm_c32_tiles();
+            if (tpw > ntiles / 512) tpw = ntiles / 512;
+            if (tpw < 2) tpw = 2;
+            const int wgs = (ntiles + tpw - 1) / tpw;
+            if (a.adt == 1) pgemm_halo_c32_kernel<__bf16, true><<<wgs, 256, 0, s>>>(a, ntiles, tpw);
+            else if (a.bf16) pgemm_halo_c32_kernel<float, true><<<wgs, 256, 0, s>>>(a, ntiles, tpw);
+            else pgemm_halo_c32_kernel<float, false><<<wgs, 256, 0, s>>>(a, ntiles, tpw);
+            DMN_LAUNCH_CHECK();
+            return DMN_OK;
+        }
+        dim3 hgrid(ntiles, (a.N + bn - 1) / bn);
         if (a.adt == 1) pgemm_halo_dispatch<__bf16, true>(a, bn, hgrid, s);
         else if (a.bf16) pgemm_halo_dispatch<float, true>(a, bn, hgrid, s);
         else pgemm_halo_dispatch<float, false>(a, bn, hgrid, s);
