@@ -452,7 +452,6 @@ __global__ __launch_bounds__(256) void pgemm_halo_kernel(const PGemmArgs a) {
     const int n0 = blockIdx.y * BN;
     const int pA = 16 * wave + r, py = pA >> 3, px = pA & 7;
     const int nch = a.Cin >> 5, nstage = nch * 3;
-    const bool wvec = ((reinterpret_cast<uintptr_t>(a.w) & 15) == 0) && ((a.ldw & 3) == 0);
 
     f32x4 acc[NJ];
 #pragma unroll
@@ -462,6 +461,12 @@ __global__ __launch_bounds__(256) void pgemm_halo_kernel(const PGemmArgs a) {
     // loads is what a stage costs; two in flight halve it
     f32x4 bn0[3 * NB], bn1[3 * NB], hr[4];
 
+    // Every global load below is issued unconditionally from a clamped address and masked afterwards: a load inside a
+    // branch makes the compiler wait for ALL outstanding loads (vmcnt(0)) before each use, which would turn the two
+    // stages of weight tiles in flight into none. The launcher guarantees 16-byte aligned weight rows and N % 4 == 0.
+    const int wn = n0 + (tid % TPR) * 4;
+    const bool wok = wn + 3 < a.N;
+    const float* wbase = a.w + (wok ? wn : 0);
     auto load_b = [&](int it, f32x4 (&bn)[3 * NB]) {
         const int cc = it / 3, ky = it - cc * 3;
 #pragma unroll
@@ -469,33 +474,28 @@ __global__ __launch_bounds__(256) void pgemm_halo_kernel(const PGemmArgs a) {
             const int krow0 = (ky * 3 + kx) * a.Cin + cc * 32;
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                const int row = tid / TPR + i * RPP, n = n0 + (tid % TPR) * 4;
-                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-                const float* p = a.w + (size_t)(krow0 + row) * a.ldw + n;
-                if (wvec && n + 3 < a.N) {
-                    v = *reinterpret_cast<const f32x4*>(p);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (n + e < a.N) v[e] = p[e];
-                }
-                bn[kx * NB + i] = v;
+                const int row = tid / TPR + i * RPP;
+                bn[kx * NB + i] = *reinterpret_cast<const f32x4*>(wbase + (size_t)(krow0 + row) * a.ldw);   // masked when stored
             }
         }
     };
+    // halo element of this thread: coordinates clamped into the image, value masked when outside (or past the 800 pieces)
+    const T* hptr[4];
+    bool hok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = min(tid + 256 * i, 799);
+        const int pix = idx >> 3, c4 = (idx & 7) * 4;
+        const int hy = pix / 10, hx = pix - hy * 10;
+        const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+        hok[i] = iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi;
+        const int cy = min(max(iy, 0), a.Hi - 1), cx = min(max(ix, 0), a.Wi - 1);
+        hptr[i] = in + ((size_t)(b * a.Hi + cy) * a.Wi + cx) * a.ldin + c4;
+    }
     auto load_halo = [&](int cc) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i;
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (idx < 800) {
-                const int pix = idx >> 3, c4 = (idx & 7) * 4;
-                const int hy = pix / 10, hx = pix - hy * 10;
-                const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-                if (iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi)
-                    v = Io<T>::ld4(in + ((size_t)(b * a.Hi + iy) * a.Wi + ix) * a.ldin + cc * 32 + c4);
-            }
-            hr[i] = v;
+            hr[i] = Io<T>::ld4(hptr[i] + cc * 32);   // masked when stored: a select here would wait for the load at once
         }
     };
 
@@ -505,17 +505,18 @@ __global__ __launch_bounds__(256) void pgemm_halo_kernel(const PGemmArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int idx = tid + 256 * i;
-                if (idx < 800) *reinterpret_cast<f32x4*>(&Hs[(idx >> 3) * LDH + (idx & 7) * 4]) = hr[i];
+                if (idx < 800) *reinterpret_cast<f32x4*>(&Hs[(idx >> 3) * LDH + (idx & 7) * 4]) = hok[i] ? hr[i] : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
             for (int i = 0; i < NB; ++i)
-                *reinterpret_cast<f32x4*>(&Bs[kx * 32 * LDB + (tid / TPR + i * RPP) * LDB + (tid % TPR) * 4]) = bn[kx * NB + i];
+                *reinterpret_cast<f32x4*>(&Bs[kx * 32 * LDB + (tid / TPR + i * RPP) * LDB + (tid % TPR) * 4]) =
+                    wok ? bn[kx * NB + i] : f32x4{0.f, 0.f, 0.f, 0.f};
         __syncthreads();
-        if (it + 2 < nstage) load_b(it + 2, bn);
-        if (ky == 2 && cc + 1 < nch) load_halo(cc + 1);
+        load_b(min(it + 2, nstage - 1), bn);           // past the end: a repeated, unused load instead of a branch
+        if (ky == 2) load_halo(min(cc + 1, nch - 1));
         const int hy = py + (a.tmode ? 2 - ky : ky);
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
@@ -913,8 +914,7 @@ int launch_pgemm(const PGemmArgs& a, hipStream_t s) {
                          a.Hi == a.Ho && a.Wi == a.Wo;
     const long long wgs64 = (is_halo ? (long long)a.B * (a.Ho >> 3) * (a.Wo >> 3) : (long long)(M + 63) / 64) * ((a.N + 63) / 64);
     const int bn = (a.N > 32 && !(a.N % 32 == 0 && wgs64 < pgemm_small_below())) ? 64 : 32;
-    if (!slow && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && (a.Ho & 7) == 0 && (a.Wo & 7) == 0 && a.Hi == a.Ho &&
-        a.Wi == a.Wo) {
+    if (is_halo && (a.N & 3) == 0 && (a.ldw & 3) == 0 && (reinterpret_cast<uintptr_t>(a.w) & 15) == 0) {
         const int vec = a.adt == 1 ? 8 : 4;
         const int ntiles = a.B * (a.Ho >> 3) * (a.Wo >> 3);
         if (a.Cin == 32 && a.N <= 32 && a.N % vec == 0 && a.ldout % vec == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 &&
