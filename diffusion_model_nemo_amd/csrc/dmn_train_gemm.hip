@@ -965,7 +965,7 @@ static int wgemm_wg_target() {
     static int v = 0;
     if (!v) {
         const char* e = getenv("DMN_WGEMM_WGS");
-        v = e ? atoi(e) : 768;
+        v = e ? atoi(e) : 256;
         if (v < 64) v = 64;
     }
     return v;
