@@ -1063,7 +1063,13 @@ int launch_nhwc_to_nchw(const void* in, int adt, float* out, int B, int C, int H
 }
 int linattn_train_splits(int B, int n, int heads) {
     const int tiles = (n + 63) / 64;
-    int splits = 2048 / (B * heads);
+    static int target = 0;   // workgroups a launch aims for (tuning aid: DMN_LINATTN_WGS)
+    if (!target) {
+        const char* e = getenv("DMN_LINATTN_WGS");
+        target = e ? atoi(e) : 2048;
+        if (target < 64) target = 64;
+    }
+    int splits = target / (B * heads);
     if (splits > tiles) splits = tiles;
     if (splits < 1) splits = 1;
     if (splits > 256) splits = 256;
