@@ -30,7 +30,7 @@ GFLOP_PER_IMG_EVAL = 2.6634
 ALG_BYTES_PER_IMG_EVAL = 17.3e6
 WEIGHT_BYTES = 16.2e6
 HBM_PEAK_GBS = 8000.0
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_dominant_kernel_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_dominant_kernel_traffic.json")
 
 
 def parse():
@@ -46,18 +46,30 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the extra training-step measurement")
+    ap.add_argument("--learned-variance", action="store_true",
+                    help="improved DDPM: 6-channel network + LearnedGaussianDiffusion (BASELINE configuration 3 per GPU)")
+    ap.add_argument("--probe-steps", type=int, default=100, help="eager steps for the in-loop timing of the dominant kernel")
     return ap.parse_args()
 
 
-def cpu_baseline(image_size, timesteps, budget_s):
-    """The CPU oracle (a pinned port of the reference path) timed on this host: p_sample steps at B=4."""
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_chain(B, image_size, timesteps, budget_s, learned_variance=False, min_steps=3):
+    """p_sample steps of the CPU oracle (a pinned port of the reference path) on this host until `timesteps` steps or
+    `budget_s` seconds have run; returns (steps done, seconds)."""
     from oracle import philox, ref_cpu as R
     from oracle.weights import make_state_dict, unet_param_shapes
-    cores = min(16, os.cpu_count() or 1)
-    torch.set_num_threads(cores)
-    p = R.to_torch(make_state_dict(unet_param_shapes()))
+    p = R.to_torch(make_state_dict(unet_param_shapes(learned_variance=learned_variance)))
     c = R.ddpm_constants(timesteps, "cosine")
-    B = 4
     shape = (B, 3, image_size, image_size)
     x = torch.from_numpy(philox.normal_like(shape, 0, timesteps, 0))
     n, t0 = 0, time.perf_counter()
@@ -66,15 +78,32 @@ def cpu_baseline(image_size, timesteps, budget_s):
             i = timesteps - 1 - n
             t = torch.full((B,), i, dtype=torch.long)
             eps = R.unet_forward(p, x, t)
-            x = R.p_sample_update(c, x, t, eps, torch.from_numpy(philox.normal_like(shape, 0, i, 1)))
+            x = R.p_sample_update(c, x, t, eps, torch.from_numpy(philox.normal_like(shape, 0, i, 1)),
+                                  learned_variance=learned_variance)
             n += 1
             el = time.perf_counter() - t0
-            if (el >= budget_s and n >= 3) or n >= timesteps:
+            if (el >= budget_s and n >= min_steps) or n >= timesteps:
                 break
-    sec_per_step = el / n
-    return {"value": B / (sec_per_step * timesteps), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"CPU oracle, B={B} {image_size}x{image_size}, {n} p_sample steps in {el:.1f}s "
-                      f"({sec_per_step * 1e3:.1f} ms/step), extrapolated x{timesteps}"}
+    return n, el
+
+
+def cpu_baseline(batch, image_size, timesteps, budget_s, learned_variance=False):
+    """The CPU oracle timed on this host's cores: (1) the timed workload itself (same batch, image size and step count)
+    for a bounded number of steps, extrapolated to the whole chain; (2) BASELINE configuration 1 (32x32, batch 4, the
+    reference's own CPU-runnable case) for up to 1000 steps."""
+    cores = min(16, os.cpu_count() or 1)   # the box's CPU share for one GPU is 16 threads, whatever the machine has
+    torch.set_num_threads(cores)
+    n, el = cpu_chain(batch, image_size, timesteps, budget_s, learned_variance)
+    sps = el / n
+    n1, el1 = cpu_chain(4, 32, 1000, 2.5 * budget_s)
+    c1 = {"value": 4 / (el1 / n1 * 1000), "unit": "images/sec",
+          "sample": f"32x32, batch 4, {n1} of 1000 p_sample steps in {el1:.1f}s"
+                    + ("" if n1 == 1000 else f" ({el1 / n1 * 1e3:.1f} ms/step), extrapolated x1000")}
+    return {"value": batch / (sps * timesteps), "unit": "images/sec", "cores": cores, "kind": "port",
+            "cpu_model": cpu_model_name(), "host_logical_cpus": os.cpu_count(),
+            "sample": f"CPU oracle, batch {batch} {image_size}x{image_size}, {n} p_sample steps in {el:.1f}s "
+                      f"({sps * 1e3:.1f} ms/step), extrapolated x{timesteps}",
+            "config1_32x32_batch4": c1}
 
 
 def train_step_extra(dev, rank, world, dist):
@@ -154,13 +183,13 @@ def main():
     torch.cuda.set_device(dev)
 
     from diffusion_model_nemo_amd import _native as N
-    from diffusion_model_nemo_amd.modules import GaussianDiffusion, Unet
+    from diffusion_model_nemo_amd.modules import GaussianDiffusion, LearnedGaussianDiffusion, Unet
     from diffusion_model_nemo_amd.parallel import gather_images
 
     torch.manual_seed(1234)
     unet = Unet(input_dim=a.image_size, dim=32, dim_mults=[1, 2, 4, 8], channels=3, resnet_block_groups=8,
-                use_convnext=False, dropout=0.0, compute_dtype=a.dtype).to(dev).eval()
-    gd = GaussianDiffusion(timesteps=a.timesteps, schedule_name="cosine")
+                use_convnext=False, dropout=0.0, learned_variance=a.learned_variance, compute_dtype=a.dtype).to(dev).eval()
+    gd = (LearnedGaussianDiffusion if a.learned_variance else GaussianDiffusion)(timesteps=a.timesteps, schedule_name="cosine")
     B, S = a.batch, a.image_size
     shape = (B, 3, S, S)
 
@@ -192,13 +221,23 @@ def main():
     # device time of the last chain, from HIP events recorded on the loop's own stream
     loop_ms = N.loop_last_ms(unet.native_handle())
 
-    # the dominant kernel by itself, HIP events on the stream it is launched on
+    # The dominant kernel where it runs: HIP event pairs around its launch inside an eager (launch by launch) replay of
+    # the same step sequence on the stream the loop uses, so it follows and precedes the same kernels as in the captured
+    # step. Beside it, the same kernel launched back to back on one tensor (warm caches), HIP events on its stream.
     import ctypes as C
-    k_ms, k_bytes = C.c_float(), C.c_double()
+    h = unet.native_handle()
+    probe_steps = max(10, min(a.probe_steps, 250))
+    gdp = type(gd)(timesteps=probe_steps, schedule_name="cosine")
+    N.check(N.lib().dmn_unet_probe_dominant(h, 1))
+    gdp.p_sample_loop(unet, shape, device=dev, seed=7, keep="last", return_device_tensor=True, use_graph=False)
+    N.check(N.lib().dmn_unet_probe_dominant(h, 0))
+    p_ms, p_n, k_bytes = C.c_float(), C.c_int(), C.c_double()
+    N.check(N.lib().dmn_unet_probe_result(h, C.byref(p_ms), C.byref(p_n), C.byref(k_bytes)))
+    k_ms, kb2 = C.c_float(), C.c_double()
     ws = unet.workspace(B, S, S, dev, sampling=True)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    N.check(N.lib().dmn_bench_dominant_kernel(unet.native_handle(), B, S, S, 200, ws.data_ptr(), ws.numel(), stream,
-                                              C.byref(k_ms), C.byref(k_bytes)))
+    N.check(N.lib().dmn_bench_dominant_kernel(h, B, S, S, 200, ws.data_ptr(), ws.numel(), stream,
+                                              C.byref(k_ms), C.byref(kb2)))
     traffic = None
     if os.path.exists(TRAFFIC_FILE):
         with open(TRAFFIC_FILE) as fh:
@@ -228,19 +267,22 @@ def main():
         sec_per_eval = (loop_ms / 1e3) / a.timesteps
         alg_bytes = B * ALG_BYTES_PER_IMG_EVAL + WEIGHT_BYTES
         res = {
-            "metric": "images/sec, 1000-step DDPM sample, 64x64 U-Net",
+            "metric": "images/sec, 1000-step DDPM sample, 64x64 U-Net" + (" (improved DDPM, learned variance)" if a.learned_variance else ""),
             "value": imgs / el, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic (Philox x_T and noise, random-init weights)",
-            "config": {"workload": f"{S}x{S}x3 DDPM U-Net (dim 32, mults 1-2-4-8), {a.timesteps}-step p_sample_loop, "
+            "config": {"workload": f"{S}x{S}x3 {'improved-DDPM (6-channel head)' if a.learned_variance else 'DDPM'} U-Net (dim 32, mults 1-2-4-8), {a.timesteps}-step p_sample_loop, "
                                    f"batch {B} per GPU", "global_batch": world * B, "parallelism": f"dp{world}",
                        "graph": not a.no_graph},
-            "roofline": {"bound": "hbm", "achieved": k_bytes.value / (k_ms.value / 1e3) / 1e9, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": k_bytes.value / (k_ms.value / 1e3) / 1e9 / HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "achieved": k_bytes.value / (p_ms.value / 1e3) / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": k_bytes.value / (p_ms.value / 1e3) / 1e9 / HBM_PEAK_GBS,
                          "traffic": traffic,
                          "kernel": "conv_igemm_kernel<bf16, 3x3, 16x16 px, 32 cout, GN+SiLU prologue> "
                                    f"[{B},{S},{S},32] -> [{B},{S},{S},32]",
-                         "algorithmic_bytes": k_bytes.value, "launch_us": k_ms.value * 1e3},
+                         "algorithmic_bytes": k_bytes.value, "launch_us": p_ms.value * 1e3,
+                         "launch_us_measured": f"HIP event pairs around {p_n.value} launches inside eager denoising steps",
+                         "launch_us_back_to_back": k_ms.value * 1e3,
+                         "frac_back_to_back": kb2.value / (k_ms.value / 1e3) / 1e9 / HBM_PEAK_GBS},
             # the whole captured step (time MLP + U-Net + posterior update) against the same roof
             "step": {"device_ms": sec_per_eval * 1e3, "algorithmic_bytes": alg_bytes,
                      "achieved_GBs": alg_bytes / sec_per_eval / 1e9,
@@ -253,7 +295,7 @@ def main():
         if train is not None:
             res["train_step"] = train
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(S, a.timesteps, a.cpu_seconds)
+            res["cpu_baseline"] = cpu_baseline(B, S, a.timesteps, a.cpu_seconds, a.learned_variance)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()

@@ -36,6 +36,7 @@ SIGNATURES = {
     "dmn_unet_destroy": (None, [_vp]),
     "dmn_unet_load_weights": (_i, [_vp, C.POINTER(DmnTensorDesc), _i]),
     "dmn_unet_set_class_labels": (_i, [_vp, _vp]),
+    "dmn_unet_set_plan_batch": (_i, [_vp, _i]),
     "dmn_unet_workspace_bytes": (_i, [_vp, _i, _i, _i, C.POINTER(_sz)]),
     "dmn_unet_forward": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "dmn_ddpm_step": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _u64, _i64, _vp]),
@@ -49,6 +50,8 @@ SIGNATURES = {
     "dmn_sample_workspace_bytes": (_i, [_vp, _i, _i, _i, C.POINTER(_sz)]),
     "dmn_loop_last_ms": (_i, [_vp, C.POINTER(_f)]),
     "dmn_bench_dominant_kernel": (_i, [_vp, _i, _i, _i, _i, _vp, _sz, _vp, C.POINTER(_f), C.POINTER(C.c_double)]),
+    "dmn_unet_probe_dominant": (_i, [_vp, _i]),
+    "dmn_unet_probe_result": (_i, [_vp, C.POINTER(_f), C.POINTER(_i), C.POINTER(C.c_double)]),
     "dmn_bench_stream": (_i, [_i, _vp, _vp, _sz, _i, _vp, C.POINTER(_f)]),
     "dmn_streams_share_queue": (_i, [_vp, _vp, C.POINTER(_i)]),
     "dmn_bench_mfma": (_i, [_i, _i, _i, _i, _vp, _vp, C.POINTER(_f), C.POINTER(C.c_double)]),

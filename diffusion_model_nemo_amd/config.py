@@ -107,13 +107,27 @@ def to_config(obj, overrides: Optional[Iterable[str]] = None) -> Config:
     return _resolve(raw, raw)
 
 
+ALLOWED_TARGET_PREFIXES = ("diffusion_model_nemo_amd.",)
+
+
 def resolve_target(target: str):
+    """Maps a `_target_` string onto a class of THIS package. Only targets of the reference package
+    (`diffusion_model_nemo.*`, aliased) or of this package are accepted: configs also arrive inside `.nemo` archives,
+    and an arbitrary dotted path there would let a file name any importable callable to be run with its own arguments."""
+    if not isinstance(target, str):
+        raise ValueError(f"`_target_` must be a string, got {type(target).__name__}")
     for old, new in TARGET_ALIASES:
         if target.startswith(old):
             target = new + target[len(old):]
             break
+    if not target.startswith(ALLOWED_TARGET_PREFIXES):
+        raise ValueError(f"`_target_: {target}` is outside the diffusion_model_nemo / diffusion_model_nemo_amd packages; "
+                         "refusing to import it")
     mod, _, name = target.rpartition(".")
-    return getattr(importlib.import_module(mod), name)
+    obj = getattr(importlib.import_module(mod), name)
+    if not (isinstance(obj, type) and getattr(obj, "__module__", "").startswith(ALLOWED_TARGET_PREFIXES)):
+        raise ValueError(f"`_target_: {target}` does not name a class defined in this package")
+    return obj
 
 
 def instantiate(cfg, **extra):

@@ -239,7 +239,10 @@ extern "C" int dmn_pc_sample_loop(DmnUnet* u, const float* table, int nsteps, fl
                 if ((r = unet_forward_impl(u, x, nullptr, 1, table, lb.step_idx, lb.net, B, H, W, lb.arena, lb.arena_bytes, s, false, nullptr))) return r;
                 LangevinArgs a;
                 memset(&a, 0, sizeof(a));
-                a.c = step_common(table, lb.step_idx, 0, x, lb.net, nullptr, x, B, C, H * W, seed, img_offset, nullptr);
+                // without a predictor the image kept for an iteration is the corrector's x (NonePredictor returns
+                // (x, x), predictor_corrector_sampler.py:105-113): the last inner step writes it
+                a.c = step_common(table, lb.step_idx, 0, x, lb.net, nullptr, x, B, C, H * W, seed, img_offset,
+                                  (!predictor && k == n_corrector_steps - 1) ? keep : nullptr);
                 a.partials = lb.partials;
                 a.inner = k;
                 a.use_norms = corrector == 1;

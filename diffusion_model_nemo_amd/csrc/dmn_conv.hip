@@ -518,8 +518,9 @@ TileCfg pick_cfg(const ConvArgs& a) {
         c.bn = a.cfg_bn;
         return c;
     }
+    const int planB = a.plan_B > 0 ? a.plan_B : a.B;
     auto blocks = [&](const TileCfg& t) {
-        return (long long)((a.Ho + t.th - 1) / t.th) * ((a.Wo + t.tw - 1) / t.tw) * (a.Cout / t.bn) * a.B * a.nphase;
+        return (long long)((a.Ho + t.th - 1) / t.th) * ((a.Wo + t.tw - 1) / t.tw) * (a.Cout / t.bn) * planB * a.nphase;
     };
     const bool big = a.kind != DMN_K4X4S2 && a.Ho >= 32 && a.Wo >= 32;   // 16x16 images: four 8x8 tiles beat one big tile split over channels
     c.th = c.tw = big ? 16 : 8;

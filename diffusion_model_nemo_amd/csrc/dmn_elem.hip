@@ -423,8 +423,9 @@ int launch_norm_apply(NormApplyArgs& a, hipStream_t s) {
     const int per = a.dtype == DMN_F32 ? 4 : 8;
     DMN_REQUIRE(a.C % per == 0 && a.C % a.norm.G == 0, DMN_ERR_INVALID, "norm_apply: C=%d groups=%d", a.C, a.norm.G);
     DMN_REQUIRE(kNormThreads % (a.C / per) == 0 && a.C <= kNormElemsSmall, DMN_ERR_INVALID, "norm_apply: C=%d must be a power-of-two multiple of %d", a.C, per);
-    const int slots = norm_apply_slots(a.B, a.HW, a.C);
-    const bool small = norm_apply_elems(a.B, a.HW, a.C) == kNormElemsSmall;
+    const int planB = a.plan_B > 0 ? a.plan_B : a.B;
+    const int slots = norm_apply_slots(planB, a.HW, a.C);
+    const bool small = norm_apply_elems(planB, a.HW, a.C) == kNormElemsSmall;
     const int pix = (a.HW + slots - 1) / slots;
     int Go = 1;
     if (a.epi.stats) {

@@ -62,6 +62,8 @@ struct ConvArgs {
     int cg, lg_upp;       // channels staged per group and log2 of its 16-byte units per pixel; set by the launcher
     long long* dbg;       // optional [workgroups][8] phase timestamps (tuning aid; nullptr in production)
     int cfg_tile, cfg_bn; // 0 = choose automatically; otherwise force the pixel tile (8 or 16) / channel tile (32 or 64)
+    int plan_B;           // batch the tile heuristic plans for (0: B). A fixed value makes the choice -- and with it the
+                          // order in which GroupNorm partial sums are formed -- independent of how a batch is sharded
 };
 int launch_conv(ConvArgs& a, hipStream_t s);
 int conv_epi_slots(const ConvArgs& a);   // slots per (image, group) launch_conv will write
@@ -78,9 +80,10 @@ struct NormApplyArgs {
     int B, HW, C;
     NormIn norm;
     NormOut epi;
+    int plan_B;           // batch the slice heuristic plans for (0: B)
 };
 int launch_norm_apply(NormApplyArgs& a, hipStream_t s);
-int norm_apply_slots(int B, int HW, int C);
+int norm_apply_slots(int B, int HW, int C);   // B: the planning batch
 
 // time path: sinusoid -> Linear -> GELU -> Linear -> SiLU -> all per-block Linear(4*dim, Cout_i)
 struct TimeArgs {

@@ -177,7 +177,9 @@ __global__ void __launch_bounds__(256) langevin_apply_kernel(const LangevinArgs 
         if (e >= per) break;
         const size_t xi = (size_t)b * per + e;
         const float mean = c.x[xi] + step * (sscale * c.net[xi]);
-        c.x_out[xi] = mean + nz * z[r];
+        const float xn = mean + nz * z[r];
+        c.x_out[xi] = xn;
+        if (c.keep) c.keep[(size_t)row * c.keep_stride + xi] = xn;   // sampler without a predictor: the kept image
     }
 }
 

@@ -1054,11 +1054,11 @@ extern "C" int dmn_adamw_step(float* params, const float* grads, float* exp_avg,
     a.bias1 = (float)(1.0 - pow((double)beta1, (double)step));
     a.bias2 = (float)(1.0 - pow((double)beta2, (double)step));
     a.max_norm = max_norm;
-    a.sq_norm = scratch;
+    a.sq_parts = scratch;
+    a.n_parts = 0;
     a.grad_scale = grad_scale;
     if (max_norm > 0.f) {
-        DMN_HIP_CHECK(hipMemsetAsync(scratch, 0, 4, s));
-        int rc = launch_sqnorm(grads, n, scratch, s);
+        int rc = launch_sqnorm(grads, n, scratch, &a.n_parts, s);
         if (rc) return rc;
     }
     return launch_adamw(a, s);

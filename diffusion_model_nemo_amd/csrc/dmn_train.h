@@ -135,7 +135,10 @@ int launch_unpack_grads(const RepackDesc* descs_dev, int n_desc, long long max_n
                         hipStream_t s);
 
 // Global gradient norm and AdamW (torch.nn.utils.clip_grad_norm_, torch.optim.AdamW semantics).
-int launch_sqnorm(const float* g, long long n, float* out_sq, hipStream_t s);   // out_sq += sum g^2 (zeroed by the caller)
+// parts[i] = sum of g^2 over the elements workgroup i visits, i < *n_parts <= kSqnormMaxParts: every slot written once,
+// summed in index order by the consumer, so the norm is the same bit pattern on every run and every rank
+constexpr int kSqnormMaxParts = 1024;
+int launch_sqnorm(const float* g, long long n, float* parts, int* n_parts, hipStream_t s);
 struct AdamWArgs {
     float* p;
     const float* g;
@@ -144,7 +147,8 @@ struct AdamWArgs {
     float lr, beta1, beta2, eps, weight_decay;
     float bias1, bias2;     // 1 - beta^step
     float max_norm;         // <= 0: no clipping
-    const float* sq_norm;   // device scalar: sum g^2 over ALL parameters
+    const float* sq_parts;  // device [n_parts]: partial sums of g^2 over ALL parameters (launch_sqnorm)
+    int n_parts;
     float grad_scale;       // multiplies g before everything else (1/world_size after a summing all-reduce)
 };
 int launch_adamw(const AdamWArgs& a, hipStream_t s);

@@ -925,12 +925,16 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g
     float acc = 0.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) acc += g[i] * g[i];
     acc = block_sum(acc, sh);
-    if (threadIdx.x == 0) unsafeAtomicAdd(out, acc);
+    if (threadIdx.x == 0) out[blockIdx.x] = acc;
 }
 __global__ __launch_bounds__(256) void adamw_kernel(const AdamWArgs a) {
+    __shared__ float sh[4];
     float coef = a.grad_scale;
     if (a.max_norm > 0.f) {
-        const float norm = sqrtf(*a.sq_norm) * a.grad_scale;
+        // every workgroup adds the same partial sums in the same order: one norm, bit for bit, everywhere
+        float acc = 0.f;
+        for (int i = threadIdx.x; i < a.n_parts; i += 256) acc += a.sq_parts[i];
+        const float norm = sqrtf(block_sum(acc, sh)) * a.grad_scale;
         coef *= fminf(1.0f, a.max_norm / (norm + 1e-6f));
     }
     const float step_size = a.lr / a.bias1, inv_sqrt_b2 = 1.0f / sqrtf(a.bias2);
@@ -1147,9 +1151,11 @@ int launch_spin(int us, hipStream_t s) {
     return DMN_OK;
 }
 
-int launch_sqnorm(const float* g, long long n, float* out_sq, hipStream_t s) {
-    sqnorm_kernel<<<grid_for(n, 2048, 1024), 256, 0, s>>>(g, n, out_sq);
+int launch_sqnorm(const float* g, long long n, float* parts, int* n_parts, hipStream_t s) {
+    const int grid = grid_for(n, 2048, kSqnormMaxParts);
+    sqnorm_kernel<<<grid, 256, 0, s>>>(g, n, parts);
     DMN_LAUNCH_CHECK();
+    *n_parts = grid;
     return DMN_OK;
 }
 int launch_adamw(const AdamWArgs& a, hipStream_t s) {

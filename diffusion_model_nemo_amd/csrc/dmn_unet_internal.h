@@ -62,13 +62,23 @@ struct DmnUnet {
     void* init_wfrag = nullptr;   // bf16 handles: ingest weights as MFMA fragments
     float* class_embed = nullptr; // [num_classes + 1][dim] fp32 (class-conditional networks)
     const long long* labels = nullptr;   // borrowed device labels of the coming forwards
+    // Batch the launch heuristics (tile sizes, pixel slices) plan for, whatever the batch of a call: the partial sums
+    // of the GroupNorm statistics are then formed in the same order for an image however its batch is sharded, so
+    // per-image results are bit-identical across splits. 0: plan for the batch of each call.
+    int plan_batch = 64;
     // cached step graph of the sampling loops
     hipGraphExec_t graph_exec = nullptr;
     SampleKey graph_key = {};
     // HIP events bracketing the last sampling loop on its stream (device time of the loop)
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool ev_valid = false;
+    // measurement hook: HIP event pairs around the launches of the step's dominant convolution (eager launches only)
+    std::vector<hipEvent_t> probe_ev;    // 2 * kProbePairs events once enabled
+    int probe_n = 0;                     // pairs recorded since the probe was switched on
+    bool probe_on = false;
+    double probe_bytes = 0.0;            // algorithmic bytes of one probed launch
 };
+constexpr int kProbePairs = 256;
 
 int pack_conv(PackedConv& pc, int dtype, const float* w, const float* bias, int Cout, int Cin, int kh, int kw, int stride,
               int pad, bool transposed);

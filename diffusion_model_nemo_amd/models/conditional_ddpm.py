@@ -1,13 +1,15 @@
-"""`ConditionalDDPM`: class-conditional sampling with the reference's interface
-(mirror of diffusion_model_nemo/models/conditional_ddpm.py:23-111).
+"""`ConditionalDDPM`: class-conditional sampling and training with the reference's interface
+(diffusion_model_nemo/models/conditional_ddpm.py:23-111).
 
-The network adds a learned class-embedding row after the ingest convolution (modules/unet.py:134-141); row
-`num_classes` is the "no class" row used for unconditional generation and, during the reference's training, for the
-randomly dropped labels. Sampling hands the sampler `functools.partial(self.forward, classes=label)`, exactly like
-the reference; the samplers of this package recognise that callable and keep the loop on the device.
+The network adds a learned class-embedding row after the ingest convolution (modules/unet.py:134-141). Row
+`num_classes` is the "no class" row: it stands for unconditional generation and, in training, for the labels that
+the reference drops at random. Everything that produces labels goes through `resolve_labels`, so the sampler, the
+interpolation and the training step agree on defaults and on the drop-out. The samplers receive
+`functools.partial(self.forward, classes=labels)` as in the reference; the samplers of this package recognise that
+callable and keep the whole loop on the device.
 """
 from functools import partial
-from typing import Dict, Optional
+from typing import Dict, Optional, Union
 
 import torch
 
@@ -17,52 +19,72 @@ from .ddpm import DDPM
 class ConditionalDDPM(DDPM):
     def __init__(self, cfg, trainer=None):
         super().__init__(cfg, trainer=trainer)
-        if 'num_classes' not in self.cfg or self.cfg.num_classes is None:
+        n = self.cfg.get('num_classes', None)
+        if n is None:   # same exception type and text as conditional_ddpm.py:27-28
             raise RuntimeWarning("Conditional ddpm must have the `num_classes` value inside cfg.model !")
-        self.num_classes = self.cfg.num_classes
-        self.random_class_index = self.num_classes
-        self.sampler.use_class_conditioning = True  # force set
+        self.num_classes = n
+        self._force_conditioning()
 
-    def forward(self, x_t: torch.Tensor, t: torch.Tensor, classes: torch.Tensor = None):
-        if self.sampler.use_class_conditioning:
-            if classes is None:
-                classes = torch.ones(x_t.size(0), device=x_t.device, dtype=torch.long) * self.random_class_index
-        return self.diffusion_model(x_t, t, classes)
+    @property
+    def random_class_index(self) -> int:
+        """Index of the "no class" embedding row (conditional_ddpm.py:31)."""
+        return self.num_classes
 
-    def get_diffusion_model(self, batch: Dict):
-        if self.sampler.use_class_conditioning:
-            device = next(self.parameters()).device
-            label = batch["label"].to(device=device)
-            if self.training:
-                # a random half of the labels becomes the "no class" index (conditional_ddpm.py:58-61)
-                sample_mask = torch.randint(0, 2, size=[label.size(0)], dtype=torch.bool, device=label.device)
-                label = torch.masked_fill(label, sample_mask, value=self.random_class_index)
-            return partial(self.forward, classes=label)
-        return self.forward
+    def _force_conditioning(self):
+        self.sampler.use_class_conditioning = True
 
     def change_sampler(self, sampler_cfg):
         super().change_sampler(sampler_cfg)
-        self.sampler.use_class_conditioning = True
+        self._force_conditioning()
 
-    def _labels(self, batch_size: int, label, device):
+    # ---- labels ---------------------------------------------------------------------------------------------------
+    def resolve_labels(self, batch_size: int, device, label: Union[None, int, torch.Tensor] = None,
+                       drop: bool = False) -> torch.Tensor:
+        """int64 labels [batch_size] on `device`. `label` None: the "no class" row for every image; an int: that class
+        for every image (conditional_ddpm.py:78-81); a tensor: used as given. `drop`: every label is replaced by the
+        "no class" row with probability 1/2, the classifier-free style drop-out of the training step
+        (conditional_ddpm.py:58-61; one `torch.randint(0, 2)` draw of the batch size on the labels' device)."""
         if label is None:
-            return torch.ones(batch_size, dtype=torch.long, device=device) * self.random_class_index
-        return torch.full([batch_size], fill_value=int(label), dtype=torch.long, device=device)
+            out = torch.full([batch_size], self.random_class_index, dtype=torch.long, device=device)
+        elif isinstance(label, torch.Tensor):
+            out = label.to(device=device)
+        else:
+            out = torch.full([batch_size], int(label), dtype=torch.long, device=device)
+        if drop:
+            dropped = torch.randint(0, 2, size=[out.size(0)], dtype=torch.bool, device=out.device)
+            out = out.masked_fill(dropped, self.random_class_index)
+        return out
 
+    def forward(self, x_t: torch.Tensor, t: torch.Tensor, classes: torch.Tensor = None):
+        if classes is None and self.sampler.use_class_conditioning:
+            classes = self.resolve_labels(x_t.size(0), x_t.device)
+        return self.diffusion_model(x_t, t, classes)
+
+    def get_diffusion_model(self, batch: Dict):
+        """The callable the samplers and the loss evaluate: `forward` with the batch's labels bound
+        (conditional_ddpm.py:51-69); in training mode half of them are dropped first."""
+        if not self.sampler.use_class_conditioning:
+            return self.forward
+        given = batch["label"]
+        labels = self.resolve_labels(given.size(0), next(self.parameters()).device, given, drop=self.training)
+        return partial(self.forward, classes=labels)
+
+    def _bound_network(self, batch_size: int, label):
+        device = next(self.parameters()).device
+        return self.get_diffusion_model({'label': self.resolve_labels(batch_size, device, label)}), device
+
+    # ---- generation -----------------------------------------------------------------------------------------------
     def sample(self, batch_size: int, image_size: int, label=None, **kwargs):
         with torch.inference_mode():
             self.eval()
-            device = next(self.parameters()).device
-            shape = [batch_size, self.channels, image_size, image_size]
-            fn = self.get_diffusion_model({'label': self._labels(batch_size, label, device)})
-            return self.sampler.sample(fn, shape=shape, device=device, **kwargs)
+            fn, device = self._bound_network(batch_size, label)
+            return self.sampler.sample(fn, shape=[batch_size, self.channels, image_size, image_size], device=device, **kwargs)
 
     def interpolate(self, x1: torch.Tensor, x2: torch.Tensor, t: Optional[int] = None, lambd: float = 0.5, label=None,
                     **kwargs):
         with torch.inference_mode():
             self.eval()
-            device = next(self.parameters()).device
-            assert x1.ndim == 4, f"x1 is not a batch of tensors ! Given shape {x1.shape}"
-            assert x2.ndim == 4, f"x2 is not a batch of tensors ! Given shape {x2.shape}"
-            fn = self.get_diffusion_model({'label': self._labels(x1.shape[0], label, device)})
+            for name, x in (("x1", x1), ("x2", x2)):
+                assert x.ndim == 4, f"{name} is not a batch of tensors ! Given shape {x.shape}"
+            fn, device = self._bound_network(x1.shape[0], label)
             return self.sampler.interpolate(fn, x1=x1.to(device), x2=x2.to(device), t=t, lambd=lambd)

@@ -30,7 +30,10 @@ class AbstractDiffusionModel(nn.Module):
         """Loads a reference YAML (e.g. examples/configs/ddpm/unet_small.yaml) with Hydra-style overrides such as
         ``model.image_size=64`` and builds the model from its ``model:`` section."""
         full = load_config(path, overrides)
-        return cls(full.model, trainer=trainer)
+        model = cls(full.model, trainer=trainer)
+        # the trainer section carries what Lightning applies around training_step (gradient_clip_val, max_steps)
+        model.trainer_cfg = full.get('trainer', None)
+        return model
 
     def get_diffusion_model(self, batch: Dict):
         return self.forward
@@ -39,6 +42,7 @@ class AbstractDiffusionModel(nn.Module):
     # model_weights.ckpt; used by examples/ddpm/eval_ddpm.py:70 and the other example scripts) --------------------
     CONFIG_MEMBER = "model_config.yaml"
     WEIGHTS_MEMBER = "model_weights.ckpt"
+    OPTIM_PREFIX = "__optimizer__."   # extra entries of the weights file: flat AdamW moments + step count
 
     def save_to(self, save_path: str):
         """Writes the model section of the config and the state_dict in the `.nemo` layout (uncompressed tar)."""
@@ -56,7 +60,11 @@ class AbstractDiffusionModel(nn.Module):
 
         blobs = {self.CONFIG_MEMBER: yaml.safe_dump(plain(self.cfg), sort_keys=False).encode()}
         buf = io.BytesIO()
-        torch.save({k: v.detach().cpu() for k, v in self.state_dict().items()}, buf)
+        tensors = {k: v.detach().cpu() for k, v in self.state_dict().items()}
+        tr = getattr(self, "_native_trainer", None)
+        if tr is not None and tr.step_count > 0:   # AdamW moments and step count, so a restored run resumes them
+            tensors.update({self.OPTIM_PREFIX + k: v.cpu() for k, v in tr.state_dict().items()})
+        torch.save(tensors, buf)
         blobs[self.WEIGHTS_MEMBER] = buf.getvalue()
         with tarfile.open(save_path, "w:") as tar:
             for name, data in blobs.items():
@@ -67,7 +75,8 @@ class AbstractDiffusionModel(nn.Module):
     @classmethod
     def restore_from(cls, restore_path: str, trainer=None, map_location=None, strict: bool = True, overrides=None):
         """Builds the model from a `.nemo` archive (plain or gzip-compressed tar). The weights are read with
-        `torch.load(..., weights_only=True)`: nothing stored in the file is executed."""
+        `torch.load(..., weights_only=True)` and the config with `yaml.SafeLoader`; its `_target_` entries may only
+        name classes of this package (or their `diffusion_model_nemo.*` aliases), anything else raises ValueError."""
         import io
         import tarfile
 
@@ -85,7 +94,10 @@ class AbstractDiffusionModel(nn.Module):
         state = torch.load(io.BytesIO(blob), map_location=map_location or "cpu", weights_only=True)
         if isinstance(state, dict) and "state_dict" in state and not any(k.startswith("diffusion_model.") for k in state):
             state = state["state_dict"]
+        opt_state = {k[len(cls.OPTIM_PREFIX):]: state.pop(k) for k in [k for k in state if k.startswith(cls.OPTIM_PREFIX)]}
         model.load_state_dict(state, strict=strict)
+        if opt_state:
+            model._pending_optimizer_state = opt_state   # handed to the trainer when it is created on a device
         return model
 
     def change_sampler(self, sampler_cfg):
@@ -187,8 +199,53 @@ class DDPM(AbstractDiffusionModel):
             if getattr(self.loss, "_reduction", "mean") != "mean":
                 raise NotImplementedError("the training step is built for reduction='mean'")
             tr = UnetTrainer(self.diffusion_model, loss_type=loss_type)
+            pending = self.__dict__.pop("_pending_optimizer_state", None)
+            if pending:
+                tr.load_state_dict(pending)
             object.__setattr__(self, "_native_trainer", tr)
         return tr
+
+    def _optim_settings(self):
+        """AdamW arguments, learning-rate policy and clip value as the reference's trainer would apply them
+        (examples/configs/ddpm/unet_small.yaml:65-78,83-84,90)."""
+        optim = self.cfg.get('optim', None) or {}
+        name = optim.get('name', 'adamw')
+        if name != 'adamw':
+            raise NotImplementedError(f"optimizer '{name}': only adamw is built")
+        sched = optim.get('sched', None) or {}
+        def trainer_value(key):   # a trainer object / mapping handed to the constructor wins over the YAML's section
+            for src in (self.trainer, getattr(self, 'trainer_cfg', None)):
+                if src is None:
+                    continue
+                v = src.get(key, None) if isinstance(src, dict) else getattr(src, key, None)
+                if v is not None:
+                    return v
+            return None
+
+        sname = sched.get('name', None)
+        if sname not in (None, 'CosineAnnealing'):
+            raise NotImplementedError(f"learning-rate policy '{sname}': only CosineAnnealing is built")
+        max_steps = sched.get('max_steps', None) or trainer_value('max_steps')
+        if max_steps is not None and int(max_steps) <= 0:
+            max_steps = None
+        clip = trainer_value('gradient_clip_val')
+        return {"lr": float(optim.get('lr', 1e-3)), "betas": tuple(optim.get('betas', (0.9, 0.999))),
+                "eps": float(optim.get('eps', 1e-8)), "weight_decay": float(optim.get('weight_decay', 0.01)),
+                "sched": sname, "min_lr": float(sched.get('min_lr', 0.0) or 0.0),
+                "warmup_steps": int(sched.get('warmup_steps', 0) or 0),
+                "max_steps": None if max_steps is None else int(max_steps),
+                "clip": 0.0 if clip is None else float(clip)}
+
+    def learning_rate(self, step: int) -> float:
+        """Learning rate of optimisation step `step` (0-based) under the config's policy: CosineAnnealing from `lr` to
+        `min_lr` over `optim.sched.max_steps` / `trainer.max_steps` when a policy and a horizon are configured (Lightning
+        derives the horizon from the data loader when max_steps is null; without a loader here it must be given),
+        constant `lr` otherwise."""
+        from ..training import cosine_annealing_lr
+        o = self._optim_settings()
+        if o["sched"] == 'CosineAnnealing' and o["max_steps"]:
+            return cosine_annealing_lr(step, o["max_steps"], o["lr"], o["min_lr"], o["warmup_steps"])
+        return o["lr"]
 
     def _training_classes(self, batch):
         """Class labels of a training batch: what `get_diffusion_model(batch)` binds to `classes` (none here; the
@@ -219,8 +276,9 @@ class DDPM(AbstractDiffusionModel):
 
     def train_batch(self, batch, lr: Optional[float] = None, t=None, noise=None):
         """One complete optimisation step on the device: loss + gradients, ONE all-reduce of the flat gradient
-        buffer when torch.distributed is initialised, gradient clipping (trainer.gradient_clip_val) and AdamW with
-        the `optim` section of the config (examples/configs/ddpm/unet_small.yaml:65-78). Returns the loss."""
+        buffer when torch.distributed is initialised, gradient clipping (`trainer.gradient_clip_val`; off when no
+        trainer section is known) and AdamW with the `optim` section of the config, the learning rate following
+        `optim.sched` (examples/configs/ddpm/unet_small.yaml:65-78,90) unless `lr` overrides it. Returns the loss."""
         samples = batch["pixel_values"]
         B = samples.shape[0]
         dev = samples.device
@@ -233,15 +291,9 @@ class DDPM(AbstractDiffusionModel):
         value = tr.loss_and_grads(samples, t, noise, s.sqrt_alphas_cumprod, s.sqrt_one_minus_alphas_cumprod,
                                   classes=self._training_classes(batch))
         scale = tr.all_reduce_grads()
-        optim = self.cfg.get('optim', None) or {}
-        name = optim.get('name', 'adamw')
-        if name != 'adamw':
-            raise NotImplementedError(f"optimizer '{name}': only adamw is built")
-        base_lr = float(optim.get('lr', 1e-3))
-        betas = tuple(optim.get('betas', (0.9, 0.999)))
-        tr.optimizer_step(lr=base_lr if lr is None else lr, betas=betas, eps=float(optim.get('eps', 1e-8)),
-                          weight_decay=float(optim.get('weight_decay', 0.01)),
-                          max_grad_norm=float(getattr(self, 'gradient_clip_val', 1.0)), grad_scale=scale)
+        o = self._optim_settings()
+        tr.optimizer_step(lr=self.learning_rate(tr.step_count) if lr is None else lr, betas=o["betas"], eps=o["eps"],
+                          weight_decay=o["weight_decay"], max_grad_norm=o["clip"], grad_scale=scale)
         return value
 
 
@@ -251,14 +303,16 @@ class _NativeLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, value, trainer, names, *params):
-        ctx.trainer = trainer
-        ctx.names = names
+        # the trainer's gradient buffer is overwritten by its next step: keep this step's own copy
+        ctx.layout = [trainer.layout[n] for n in names]
+        ctx.flat = trainer.grads.clone()
         return value.clone()
 
     @staticmethod
     def backward(ctx, grad_out):
-        tr = ctx.trainer
-        grads = tuple(tr.grad_of(n).clone() * grad_out for n in ctx.names)
+        import math
+        flat = ctx.flat * grad_out
+        grads = tuple(flat[off:off + int(math.prod(shape))].view(shape) for off, shape in ctx.layout)
         return (None, None, None) + grads
 
 

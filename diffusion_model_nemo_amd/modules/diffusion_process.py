@@ -105,14 +105,19 @@ class AbstractDiffusionProcess(torch.nn.Module):
         return tab.gather(-1, t.long()).reshape(t.shape[0], *((1,) * (len(x_shape) - 1)))
 
     def _device_table(self, a: torch.Tensor, device):
+        """Device copy of a schedule vector. Only the vectors that are attributes of this object are cached (the cache
+        keeps its keys alive); a temporary such as `1 - alphas_cumprod` is copied per call and dropped."""
         if a.device == device:
             return a
         cache = self.__dict__.setdefault("_tab_cache", {})
         key = (id(a), str(device))
         hit = cache.get(key)
-        if hit is None or hit[0] is not a:
-            cache[key] = (a, a.to(device))
-        return cache[key][1]
+        if hit is not None and hit[0] is a:
+            return hit[1]
+        moved = a.to(device)
+        if any(v is a for v in self.__dict__.values()):
+            cache[key] = (a, moved)
+        return moved
 
     def forward(self, *args, **kwargs):
         raise RuntimeWarning(f"{self.__class__.__name__} should not be used with forward(), please explicitly call "

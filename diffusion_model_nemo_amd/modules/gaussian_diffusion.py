@@ -181,12 +181,13 @@ class GaussianDiffusion(AbstractDiffusionProcess):
         if noise is not None:
             noise = noise.to(x.device, torch.float32).contiguous()
         groups = [(0, B, int(tl[0].item()))] if uniform else [(b, 1, int(tl[b].item())) for b in range(B)]
-        for b0, nb, tv in groups:
-            row = self.timesteps - 1 - tv
-            N.check(N.lib().dmn_ddpm_step(
-                table.data_ptr(), row, x[b0:b0 + nb].data_ptr(), net[b0:b0 + nb].data_ptr(),
-                None if noise is None else noise[b0:b0 + nb].data_ptr(), out[b0:b0 + nb].data_ptr(),
-                nb, Cc, H, W, lv, pred_x0, seed, image_offset + b0, stream))
+        with torch.cuda.device(x.device):   # the library launches on the current device
+            for b0, nb, tv in groups:
+                row = self.timesteps - 1 - tv
+                N.check(N.lib().dmn_ddpm_step(
+                    table.data_ptr(), row, x[b0:b0 + nb].data_ptr(), net[b0:b0 + nb].data_ptr(),
+                    None if noise is None else noise[b0:b0 + nb].data_ptr(), out[b0:b0 + nb].data_ptr(),
+                    nb, Cc, H, W, lv, pred_x0, seed, image_offset + b0, stream))
         return out
 
     def _resolve_seed(self, seed):
@@ -200,6 +201,10 @@ class GaussianDiffusion(AbstractDiffusionProcess):
     def _run_chain(self, model, x, first_row, nsteps, draw_prior, keep, seed, image_offset, use_graph=True):
         """Runs rows [first_row, first_row + nsteps) of the step table on x (in place). Returns the history
         tensor [nsteps, B, C, H, W] (device) when keep == 'all', else None."""
+        with torch.cuda.device(x.device):   # the library launches on the current device
+            return self._run_chain_on_device(model, x, first_row, nsteps, draw_prior, keep, seed, image_offset, use_graph)
+
+    def _run_chain_on_device(self, model, x, first_row, nsteps, draw_prior, keep, seed, image_offset, use_graph):
         B, Cc, H, W = x.shape
         dev = x.device
         table = self.step_table(dev)
@@ -278,15 +283,18 @@ class GaussianDiffusion(AbstractDiffusionProcess):
         return self.p_sample_loop(model, shape=shape, device=device, **kwargs)
 
     @torch.no_grad()
-    def interpolate(self, model, x1, x2, t: Optional[int] = None, lambd: float = 0.5, seed: Optional[int] = None):
-        """gaussian_diffusion.py:195-218: diffuse both images to step t, mix, then denoise from t-1 down to 0."""
+    def interpolate(self, model, x1, x2, t: Optional[int] = None, lambd: float = 0.5, seed: Optional[int] = None,
+                    noise=None):
+        """gaussian_diffusion.py:195-218: diffuse both images to step t, mix, then denoise from t-1 down to 0.
+        ``noise = (n1, n2)`` injects the two q_sample draws (default: torch.randn_like, as in the reference)."""
         t = self.timesteps - 1 if t is None else t
         if t >= self.timesteps:
             raise ValueError(f"`t` must be < {self.timesteps} during interpolation")
         assert x1.shape == x2.shape
         B = x1.size(0)
         t_batched = torch.full((B,), t, device=x1.device, dtype=torch.long)
-        xt1, xt2 = (self.q_sample(x, t=t_batched) for x in (x1, x2))
+        n1, n2 = (None, None) if noise is None else noise
+        xt1, xt2 = self.q_sample(x1, t=t_batched, noise=n1), self.q_sample(x2, t=t_batched, noise=n2)
         img = ((1 - lambd) * xt1 + lambd * xt2).float().contiguous()
         if t == 0:
             return []

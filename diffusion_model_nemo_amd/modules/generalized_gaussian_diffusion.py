@@ -87,9 +87,10 @@ class GeneralizedGaussianDiffusion(GaussianDiffusion):
         if noise is not None:
             noise = noise.to(x.device, torch.float32).contiguous()
         pred_x0 = (0 if self.objective == 'pred_noise' else 1) | self._step_flags
-        N.check(N.lib().dmn_ddpm_step(self.step_table(x.device).data_ptr(), row, x.data_ptr(), net.data_ptr(),
-                                      None if noise is None else noise.data_ptr(), out.data_ptr(), B, Cc, H, W, 0,
-                                      pred_x0, self._resolve_seed(seed), image_offset, N.current_stream_handle(x.device)))
+        with torch.cuda.device(x.device):
+            N.check(N.lib().dmn_ddpm_step(self.step_table(x.device).data_ptr(), row, x.data_ptr(), net.data_ptr(),
+                                          None if noise is None else noise.data_ptr(), out.data_ptr(), B, Cc, H, W, 0,
+                                          pred_x0, self._resolve_seed(seed), image_offset, N.current_stream_handle(x.device)))
         if self.objective == 'pred_noise':
             x0 = self.generalized_predict_start_from_noise(x, t, net).clamp(-1.0, 1.0)
         else:
@@ -117,8 +118,9 @@ class GeneralizedGaussianDiffusion(GaussianDiffusion):
         nsteps = len(self.sequence())
         # the x_T draw is keyed by T (as in the ancestral sampler), the per-step draws by their timestep
         if img is None:
-            N.check(N.lib().dmn_fill_normal(x.data_ptr(), x.shape[0], x[0].numel(), seed, self.timesteps, image_offset, 1.0,
-                                            N.current_stream_handle(device)))
+            with torch.cuda.device(device):
+                N.check(N.lib().dmn_fill_normal(x.data_ptr(), x.shape[0], x[0].numel(), seed, self.timesteps, image_offset,
+                                                1.0, N.current_stream_handle(device)))
         hist = self._run_chain(model, x, 0, nsteps, False, keep, seed, image_offset, use_graph=use_graph)
         if return_device_tensor:
             return x

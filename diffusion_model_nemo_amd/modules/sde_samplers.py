@@ -86,6 +86,10 @@ class PredictorCorrectorSampler(torch.nn.Module):
                 # the reference reads `sde.discrete_betas`, which VPSDE never defines
                 # (sde_predictors/ancestral_sampling_predictor.py:32)
                 raise AttributeError("'VPSDE' object has no attribute 'discrete_betas'")
+        if pk == 1 and self.probability_flow:
+            # the reverse SDE hands back the Python float 0.0 as diffusion (sde_lib.py:97) and the Euler-Maruyama
+            # update subscripts it (euler_maruyama_predictor.py:16)
+            raise TypeError("'float' object is not subscriptable")
         if ck and isinstance(sde, sde_lib.subVPSDE):
             # langevin_corrector.py:20-22 reads `sde.alphas`, which subVPSDE lacks
             raise AttributeError("'subVPSDE' object has no attribute 'alphas'")
@@ -168,7 +172,7 @@ class PredictorCorrectorSampler(torch.nn.Module):
         else:
             side = self.__dict__.setdefault("_streams", {}).setdefault(str(device), torch.cuda.Stream(device))
         side.wait_stream(cur)
-        with torch.cuda.stream(side):
+        with torch.cuda.device(device), torch.cuda.stream(side):   # the library launches on the current device
             N.check(N.lib().dmn_pc_sample_loop(
                 handle, table.data_ptr(), sde.N, x.data_ptr(), B, H, W, 1 if pk else 0, ck, self.n_steps if ck else 0,
                 float(self.snr), 1 if self.denoise else 0, 1, float(sde.prior_scale), seed, image_offset,
@@ -181,8 +185,8 @@ class PredictorCorrectorSampler(torch.nn.Module):
         nfe = sde.N * (self.n_steps + 1)
         if return_device_tensor:
             out = final
-        elif keep == "last" or not pk:
-            out = [((final + 1.0) * 0.5).cpu()]
+        elif keep == "last" or not (pk or ck):
+            out = [((final + 1.0) * 0.5).cpu()] * (1 if keep == "last" else sde.N)
         else:
             out = list(((hist + 1.0) * 0.5).cpu().unbind(0))
         return (out, nfe) if return_nfe else out

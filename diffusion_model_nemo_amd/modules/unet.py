@@ -155,9 +155,30 @@ class Unet(nn.Module):
             self.class_embed = nn.Embedding(self.num_classes + 1, embedding_dim=self.dim, padding_idx=self.num_classes)
 
         self._handle = None
+        self._handle_device = None
         self._weights_version = None
         self._workspace = None
         self._ws_key = None
+        self._plan_batch = 64
+
+    def set_plan_batch(self, batch: int):
+        """Batch the launch heuristics plan for (default 64). With a fixed value the result for an image does not
+        depend on how the batch holding it is split over calls or ranks; 0 plans for the batch of each call."""
+        if batch < 0:
+            raise ValueError("plan batch must be >= 0")
+        self._plan_batch = int(batch)
+        self._workspace = None
+        self._ws_key = None
+        if self._handle is not None:
+            with torch.cuda.device(self._handle_device):
+                N.check(N.lib().dmn_unet_set_plan_batch(self._handle, self._plan_batch))
+        return self
+
+    def _device(self) -> torch.device:
+        dev = self.init_conv.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("the network's parameters must live on an MI355X device (no CPU implementation)")
+        return dev
 
     # ---- native handle -------------------------------------------------------------------------------
     def _cfg(self) -> N.DmnUnetCfg:
@@ -190,27 +211,35 @@ class Unet(nn.Module):
             if int(classes.min()) < 0 or int(classes.max()) > self.num_classes:
                 raise IndexError("class label out of range")
             self._labels = classes
-        N.check(N.lib().dmn_unet_set_class_labels(self.native_handle(), None if self._labels is None
-                                                  else self._labels.data_ptr()))
+        with torch.cuda.device(device):
+            N.check(N.lib().dmn_unet_set_class_labels(self.native_handle(), None if self._labels is None
+                                                      else self._labels.data_ptr()))
 
     def _version(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def native_handle(self) -> int:
-        """Creates the DmnUnet handle / repacks the weights when parameters changed."""
+        """Creates the DmnUnet handle / repacks the weights when parameters changed. The library works on the current
+        HIP device: the handle, its packed weights and every call on it are bound to the device of the parameters."""
         lib = N.lib()
-        if self._handle is None:
-            h = C.c_void_p()
-            cfg = self._cfg()
-            N.check(lib.dmn_unet_create(C.byref(cfg), C.byref(h)))
-            self._handle = h
-        ver = self._version()
-        if ver != self._weights_version:
-            params = {k: v.detach().to("cpu", torch.float32).contiguous().numpy() for k, v in self.state_dict().items()}
-            descs, keep = N.make_tensor_descs(params)
-            N.check(lib.dmn_unet_load_weights(self._handle, descs, len(params)))
-            del keep
-            self._weights_version = ver
+        dev = self._device()
+        if self._handle is not None and self._handle_device != dev:
+            self.release()   # the module moved to another GPU: packed weights and graphs belong to the old one
+        with torch.cuda.device(dev):
+            if self._handle is None:
+                h = C.c_void_p()
+                cfg = self._cfg()
+                N.check(lib.dmn_unet_create(C.byref(cfg), C.byref(h)))
+                N.check(lib.dmn_unet_set_plan_batch(h, self._plan_batch))
+                self._handle = h
+                self._handle_device = dev
+            ver = self._version()
+            if ver != self._weights_version:
+                params = {k: v.detach().to("cpu", torch.float32).contiguous().numpy() for k, v in self.state_dict().items()}
+                descs, keep = N.make_tensor_descs(params)
+                N.check(lib.dmn_unet_load_weights(self._handle, descs, len(params)))
+                del keep
+                self._weights_version = ver
         return self._handle
 
     def set_compute_dtype(self, compute_dtype: str):
@@ -223,9 +252,11 @@ class Unet(nn.Module):
 
     def release(self):
         if self._handle is not None:
-            torch.cuda.synchronize()
-            N.lib().dmn_unet_destroy(self._handle)
+            with torch.cuda.device(self._handle_device):
+                torch.cuda.synchronize()
+                N.lib().dmn_unet_destroy(self._handle)
         self._handle = None
+        self._handle_device = None
         self._weights_version = None
         self._workspace = None
         self._ws_key = None
@@ -238,7 +269,7 @@ class Unet(nn.Module):
             pass
 
     def workspace(self, B, H, W, device, sampling=False) -> torch.Tensor:
-        key = (B, H, W, str(device), sampling)
+        key = (B, H, W, str(device), sampling, self._plan_batch)
         if self._ws_key != key:
             lib = N.lib()
             n = C.c_size_t()
@@ -262,10 +293,13 @@ class Unet(nn.Module):
             t, is_float = time.to(device=x.device, dtype=torch.float32).contiguous(), 1
         else:
             t, is_float = time.to(device=x.device, dtype=torch.int64).contiguous(), 0
+        if x.device != self._device():
+            raise RuntimeError(f"input on {x.device}, network on {self._device()}")
         handle = self.native_handle()
         self.set_class_labels(classes, B, x.device)
         ws = self.workspace(B, H, W, x.device)
         out = torch.empty((B, self.out_dim, H, W), dtype=torch.float32, device=x.device)
-        N.check(N.lib().dmn_unet_forward(handle, x.data_ptr(), t.data_ptr(), is_float, out.data_ptr(), B, H, W,
-                                         ws.data_ptr(), ws.numel(), N.current_stream_handle(x.device)))
+        with torch.cuda.device(x.device):
+            N.check(N.lib().dmn_unet_forward(handle, x.data_ptr(), t.data_ptr(), is_float, out.data_ptr(), B, H, W,
+                                             ws.data_ptr(), ws.numel(), N.current_stream_handle(x.device)))
         return out

@@ -70,3 +70,18 @@ def all_reduce_flat_grads(grads: torch.Tensor, group=None) -> float:
         return 1.0
     dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=group)
     return 1.0 / world
+
+
+def broadcast_training_state(tensors, step_count: int, group=None, src: int = 0) -> int:
+    """Rank `src`'s flat training tensors (parameters, AdamW moments) and optimiser step count to every rank, in place.
+    Lightning DDP broadcasts the parameters when it wraps the module (the reference's `strategy: ddp`,
+    examples/configs/ddpm/unet_small.yaml:88); replicas that started from different random initialisations or
+    checkpoints would otherwise train apart unnoticed. Returns the step count to adopt. No-op without a process group."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return step_count
+    root = dist.get_global_rank(group, src) if group is not None else src
+    for t in tensors:
+        dist.broadcast(t, src=root, group=group)
+    sc = torch.tensor([step_count], dtype=torch.int64, device=tensors[0].device)
+    dist.broadcast(sc, src=root, group=group)
+    return int(sc.item())

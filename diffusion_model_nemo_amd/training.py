@@ -52,12 +52,17 @@ class UnetTrainer:
         self.activations = activations
         self.unet = unet
         self.device = torch.device(device) if device is not None else next(unet.parameters()).device
+        if self.device.type != "cuda":
+            raise RuntimeError("UnetTrainer needs the network on an MI355X device (no CPU implementation): "
+                               "move it with .cuda() / .to(device) first")
+        self._synced = False   # data-parallel replicas agree on parameters and optimiser state
         lib = N.lib()
         h = C.c_void_p()
         cfg = unet._cfg()
         if activations == "bf16":
             cfg.dtype = 2
-        N.check(lib.dmn_train_create(C.byref(cfg), LOSS_KINDS[loss_type], C.byref(h)))
+        with torch.cuda.device(self.device):   # the library works on the current device (streams, descriptors)
+            N.check(lib.dmn_train_create(C.byref(cfg), LOSS_KINDS[loss_type], C.byref(h)))
         self._handle = h
         self.layout: Dict[str, tuple] = {}
         for i in range(lib.dmn_train_num_tensors(h)):
@@ -72,7 +77,7 @@ class UnetTrainer:
         self.grads = torch.zeros_like(self.params)
         self.exp_avg = torch.zeros_like(self.params)
         self.exp_avg_sq = torch.zeros_like(self.params)
-        self._scratch = torch.zeros(64, dtype=torch.float32, device=self.device)
+        self._scratch = torch.zeros(1024, dtype=torch.float32, device=self.device)
         self._loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._ws = None
         self._ws_key = None
@@ -94,6 +99,36 @@ class UnetTrainer:
         except Exception:
             pass
 
+    # ---- optimiser state (AdamW moments + step count) for checkpoints -------------------------------------------
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return {"exp_avg": self.exp_avg.detach().clone(), "exp_avg_sq": self.exp_avg_sq.detach().clone(),
+                "step_count": torch.tensor(self.step_count, dtype=torch.int64)}
+
+    def load_state_dict(self, state: Dict[str, torch.Tensor]):
+        for k in ("exp_avg", "exp_avg_sq"):
+            if state[k].numel() != self.flat_size:
+                raise ValueError(f"optimizer state '{k}' has {state[k].numel()} elements, expected {self.flat_size}")
+            getattr(self, k).copy_(state[k].to(self.device, torch.float32).reshape(-1))
+        self.step_count = int(state["step_count"])
+
+    def _check_views(self):
+        """The module's parameters must still be the views of the flat buffer made at construction: `.to()`, `.float()`
+        or `set_compute_dtype` on the module after that re-allocate them and the kernels would train a stale copy."""
+        p = self.unet.init_conv.weight
+        off, shape = self.layout["init_conv.weight"]
+        if p.data_ptr() != self.params.data_ptr() + 4 * off or p.device != self.device:
+            raise RuntimeError("the network's parameters no longer alias the trainer's flat buffer (the module was moved "
+                               "or converted after UnetTrainer was created): build a new UnetTrainer")
+
+    def sync_replicas(self, group=None):
+        """Data parallel: rank 0's parameters, AdamW moments and step count to every rank (what Lightning DDP does for
+        parameters when it wraps the module). Called by the first `all_reduce_grads`; a no-op without
+        torch.distributed."""
+        from .parallel import broadcast_training_state
+        self.step_count = broadcast_training_state((self.params, self.exp_avg, self.exp_avg_sq), self.step_count, group)
+        self.unet._weights_version = None   # the sampling handle repacks from the (possibly replaced) parameters
+        self._synced = True
+
     def grad_of(self, name: str) -> torch.Tensor:
         off, shape = self.layout[name]
         return self.grads[off:off + int(math.prod(shape))].view(shape)
@@ -102,7 +137,8 @@ class UnetTrainer:
         key = (B, H, W)
         if self._ws_key != key:
             n = C.c_size_t()
-            N.check(N.lib().dmn_train_workspace_bytes(self._handle, B, H, W, C.byref(n)))
+            with torch.cuda.device(self.device):
+                N.check(N.lib().dmn_train_workspace_bytes(self._handle, B, H, W, C.byref(n)))
             self._ws = torch.empty(n.value + 256, dtype=torch.uint8, device=self.device)
             self._ws_key = key
         return self._ws
@@ -115,6 +151,9 @@ class UnetTrainer:
         (overwritten). Without the two schedule tables x0 is taken as x_t. Returns the loss as a device scalar."""
         if not x0.is_cuda:
             raise RuntimeError("the training step runs only on MI355X device tensors (no CPU implementation)")
+        if x0.device != self.device:
+            raise RuntimeError(f"batch on {x0.device}, trainer on {self.device}")
+        self._check_views()
         B, Cc, H, W = x0.shape
         if Cc != self.unet.channels:
             raise ValueError(f"expected {self.unet.channels} channels, got {Cc}")
@@ -140,10 +179,11 @@ class UnetTrainer:
         base = ws.data_ptr()
         aligned = (base + 255) & ~255
         loss = torch.zeros(1, dtype=torch.float32, device=self.device)
-        N.check(N.lib().dmn_train_loss_and_grads(
-            self._handle, self.params.data_ptr(), self.grads.data_ptr(), x0.data_ptr(), noise.data_ptr(), t.data_ptr(),
-            N.ptr(sa), N.ptr(sb), 0 if sa is None else sa.numel(), B, H, W, loss.data_ptr(), N.ptr(model_out), aligned, ws.numel() - (aligned - base),
-            N.current_stream_handle(self.device)))
+        with torch.cuda.device(self.device):
+            N.check(N.lib().dmn_train_loss_and_grads(
+                self._handle, self.params.data_ptr(), self.grads.data_ptr(), x0.data_ptr(), noise.data_ptr(), t.data_ptr(),
+                N.ptr(sa), N.ptr(sb), 0 if sa is None else sa.numel(), B, H, W, loss.data_ptr(), N.ptr(model_out), aligned,
+                ws.numel() - (aligned - base), N.current_stream_handle(self.device)))
         self._keep = (x0, noise, t, sa, sb, labels)   # borrowed by the kernels until the stream has run them
         return loss[0]
 
@@ -151,16 +191,19 @@ class UnetTrainer:
         """Data parallel: ONE summing all-reduce (RCCL over xGMI under backend 'nccl') of the flat gradient tensor.
         Returns the factor that turns the sum into the mean; `optimizer_step` applies it on the device."""
         from .parallel import all_reduce_flat_grads
+        if not self._synced:
+            self.sync_replicas()
         return all_reduce_flat_grads(self.grads)
 
     def optimizer_step(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01,
                        max_grad_norm: float = 0.0, grad_scale: float = 1.0):
         """clip_grad_norm_(max_grad_norm) + torch.optim.AdamW semantics on the flat buffers, on the device."""
         self.step_count += 1
-        N.check(N.lib().dmn_adamw_step(
-            self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
-            self.flat_size, lr, betas[0], betas[1], eps, weight_decay, self.step_count, max_grad_norm, grad_scale,
-            self._scratch.data_ptr(), N.current_stream_handle(self.device)))
+        with torch.cuda.device(self.device):
+            N.check(N.lib().dmn_adamw_step(
+                self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                self.flat_size, lr, betas[0], betas[1], eps, weight_decay, self.step_count, max_grad_norm, grad_scale,
+                self._scratch.data_ptr(), N.current_stream_handle(self.device)))
         self.unet._weights_version = None   # the sampling handle repacks from the updated parameters
 
 

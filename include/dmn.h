@@ -64,6 +64,13 @@ int dmn_unet_workspace_bytes(const DmnUnet* u, int B, int H, int W, size_t* byte
  * NULL selects the extra "null" row num_classes for every image, like classes=None in the reference. */
 int dmn_unet_set_class_labels(DmnUnet* u, const int64_t* labels);
 
+/* Batch that the launch heuristics (convolution tiles, pixel slices of the normalisation and attention kernels) plan
+ * for; default 64. The choice fixes the order in which per-image GroupNorm partial sums are formed, so with a fixed
+ * planning batch the output for an image is bit-identical however the batch that contains it is sharded over calls or
+ * ranks. 0 plans for the batch of each call (fastest for small batches; rounding then depends on the split).
+ * Workspace sizes depend on it: set it before dmn_unet_workspace_bytes. No counterpart in the reference. */
+int dmn_unet_set_plan_batch(DmnUnet* u, int batch);
+
 /* eps = Unet(x, t).  t: [B] int64 (t_is_float = 0) or float32 (1), device memory. out: [B][out_dim][H][W]. */
 int dmn_unet_forward(DmnUnet* u, const float* x, const void* t, int t_is_float, float* out, int B, int H, int W,
                      void* workspace, size_t workspace_bytes, void* stream);
@@ -132,6 +139,15 @@ int dmn_loop_last_ms(DmnUnet* u, float* ms);
 int dmn_bench_dominant_kernel(DmnUnet* u, int B, int H, int W, int iters, void* workspace, size_t workspace_bytes,
                               void* stream, float* avg_ms, double* alg_bytes);
 
+/* The same kernel timed where it runs: HIP event pairs around its launch inside eager (use_graph = 0) network
+ * evaluations or sampling loops on one stream, so that it follows and precedes the same kernels as in a captured step
+ * and finds its operands in the same cache state. dmn_unet_probe_dominant(u, 1) starts collecting (at most 256
+ * launches), (u, 0) stops; dmn_unet_probe_result waits for the recorded pairs and returns their average distance (the
+ * kernel plus the two marker packets), their number and the algorithmic bytes of one launch.
+ * No counterpart in the reference: measurement hooks used by bench.py. */
+int dmn_unet_probe_dominant(DmnUnet* u, int enable);
+int dmn_unet_probe_result(DmnUnet* u, float* avg_ms, int* launches, double* alg_bytes);
+
 /* Measured ceilings of the device: `iters` back-to-back launches timed with HIP events on `stream`.
  * dmn_bench_stream: mode 0 copies `bytes` from src to dst (HBM traffic 2 x bytes per launch), mode 1 only reads src
  * (dst: any 4 writable bytes). Buffers 16-byte aligned, bytes a multiple of 16.
@@ -181,7 +197,8 @@ int dmn_train_loss_and_grads(DmnTrainer* tr, const float* params, float* grads, 
                              int W, float* loss, float* model_out, void* workspace, size_t workspace_bytes, void* stream);
 /* torch.nn.utils.clip_grad_norm_(max_norm) (max_norm <= 0: off) followed by one torch.optim.AdamW step on flat
  * buffers, all on the device (no host read of the norm). grads are multiplied by grad_scale first (1/world_size after
- * a summing all-reduce). step counts from 1. scratch: device, >= 4 bytes. */
+ * a summing all-reduce). step counts from 1. scratch: device, >= 4096 bytes (partial sums of the squared norm, added
+ * in a fixed order: replicas that hold the same gradients compute the same clip factor bit for bit). */
 int dmn_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int step, float max_norm, float grad_scale, float* scratch,
                    void* stream);

@@ -329,6 +329,24 @@ def bits_per_dimension(model_fn, c, x_start: Tensor, noise_fn, learned_variance:
     return {"total_bpd": terms.sum(dim=1) + prior, "terms_bpd": terms, "prior_bpd": prior}
 
 
+def ddpm_interpolate(model_fn, c, x1: Tensor, x2: Tensor, t: int, lambd: float, q_noise, noise_fn):
+    """GaussianDiffusion.interpolate (gaussian_diffusion.py:195-218): both images diffused to step t with the draws
+    ``q_noise = (n1, n2)``, mixed (1 - lambd) / lambd, then ancestral steps t-1 .. 0 with ``noise_fn(i)``. Returns the
+    list of x after every step, in model range."""
+    T = int(c["betas"].shape[0])
+    if t >= T:
+        raise ValueError(f"`t` must be < {T} during interpolation")
+    B = x1.shape[0]
+    tb = torch.full((B,), t, dtype=torch.long)
+    img = (1 - lambd) * q_sample(c, x1, tb, q_noise[0]) + lambd * q_sample(c, x2, tb, q_noise[1])
+    out = []
+    for i in reversed(range(t)):
+        ti = torch.full((B,), i, dtype=torch.long)
+        img = p_sample_update(c, img, ti, model_fn(img, ti), noise_fn(i))
+        out.append(img.clone())
+    return out
+
+
 def ddim_sequence(timesteps: int, ddim_timesteps: int):
     """(t, t_next) pairs in execution order (generalized_gaussian_diffusion.py:111-113,121-123)."""
     n = ddim_timesteps if ddim_timesteps > 0 else timesteps
@@ -360,12 +378,12 @@ def ddim_sample_update(k: Dict[str, Tensor], x: Tensor, model_output: Tensor, no
 
 
 def ddim_sample_chain(model_fn: Callable[[Tensor, Tensor], Tensor], betas: Tensor, shape, noise_fn, eta: float = 0.0,
-                      ddim_timesteps: int = -1, objective: str = "pred_noise"):
+                      ddim_timesteps: int = -1, objective: str = "pred_noise", img: Tensor = None):
     """generalized_gaussian_diffusion.py:100-137 with injected noise: ``noise_fn(T)`` is the x_T draw and
     ``noise_fn(t)`` the draw of the step at timestep t (drawn even when eta == 0). Returns the list of x after
     every step, in model range."""
     T = int(betas.shape[0])
-    x = noise_fn(T)
+    x = noise_fn(T) if img is None else img   # `img`: GeneralizedGaussianDiffusion.interpolate (:138-140), no x_T draw
     out = []
     for t, t_next in ddim_sequence(T, ddim_timesteps):
         tt = torch.full((shape[0],), t, dtype=torch.long)
@@ -452,36 +470,41 @@ def score_fn_for(sde, model_fn, continuous: bool = True):
     return score_fn
 
 
-def reverse_sde(sde, score_fn, x, t):
-    """RSDE.sde with probability_flow=False (sde_lib/sde_lib.py:91-98)."""
+def reverse_sde(sde, score_fn, x, t, probability_flow: bool = False):
+    """RSDE.sde (sde_lib/sde_lib.py:91-98). With probability_flow the score term is halved and the diffusion is the
+    Python float 0.0, as in the reference."""
     drift, diffusion = sde.sde(x, t)
-    return drift - diffusion[:, None, None, None] ** 2 * score_fn(x, t), diffusion
+    drift = drift - diffusion[:, None, None, None] ** 2 * score_fn(x, t) * (0.5 if probability_flow else 1.0)
+    return drift, (0.0 if probability_flow else diffusion)
 
 
-def reverse_discretize(sde, score_fn, x, t):
-    """RSDE.discretize with probability_flow=False (sde_lib/sde_lib.py:100-105)."""
+def reverse_discretize(sde, score_fn, x, t, probability_flow: bool = False):
+    """RSDE.discretize (sde_lib/sde_lib.py:100-105)."""
     f, G = sde.discretize(x, t)
-    return f - G[:, None, None, None] ** 2 * score_fn(x, t), G
+    rev_f = f - G[:, None, None, None] ** 2 * score_fn(x, t) * (0.5 if probability_flow else 1.0)
+    return rev_f, (torch.zeros_like(G) if probability_flow else G)
 
 
-def predictor_step(name, sde, score_fn, x, t, z):
+def predictor_step(name, sde, score_fn, x, t, z, probability_flow: bool = False):
     """One predictor update with injected noise ``z``; returns (x, x_mean).
     euler_maruyama_predictor.py:11-17, reverse_diffusion_predictor.py:11-16,
-    ancestral_sampling_predictor.py:17-28 (VE branch)."""
+    ancestral_sampling_predictor.py:17-28 (VE branch). Euler-Maruyama with probability_flow raises TypeError like the
+    reference, which subscripts the float diffusion 0.0 (euler_maruyama_predictor.py:16)."""
     if name in (None, "none", "null"):
         return x, x
     if name == "euler_maruyama":
         dt = -1.0 / sde.N
-        drift, diffusion = reverse_sde(sde, score_fn, x, t)
+        drift, diffusion = reverse_sde(sde, score_fn, x, t, probability_flow)
         x_mean = x + drift * dt
         return x_mean + diffusion[:, None, None, None] * np.sqrt(-dt) * z, x_mean
     if name == "reverse_diffusion":
-        f, G = reverse_discretize(sde, score_fn, x, t)
+        f, G = reverse_discretize(sde, score_fn, x, t, probability_flow)
         x_mean = x - f
         return x_mean + G[:, None, None, None] * z, x_mean
     if name == "ancestral_sampling":
         if not isinstance(sde, VESDE):
             raise NotImplementedError("VP ancestral sampling reads sde.discrete_betas, which VPSDE lacks")
+        assert not probability_flow, "Probability flow not supported by ancestral sampling"
         timestep = (t * (sde.N - 1) / sde.T).long()
         sigma = sde.discrete_sigmas[timestep]
         adjacent = torch.where(timestep == 0, torch.zeros_like(t), sde.discrete_sigmas[timestep - 1])
@@ -526,7 +549,8 @@ def corrector_step(name, sde, score_fn, x, t, z_fn, snr, n_steps):
 
 
 def pc_sample_chain(model_fn, sde, shape, noise_fn, predictor="euler_maruyama", corrector=None,
-                    snr=0.16, n_steps=1, continuous=True, denoise=True, eps=None, n_iter=None, keep=None):
+                    snr=0.16, n_steps=1, continuous=True, denoise=True, eps=None, n_iter=None, keep=None,
+                    probability_flow=False):
     """sde_samplers/predictor_corrector_sampler.py:58-120 with injected noise.
 
     ``noise_fn(step, stream)``: stream 0 = prior draw (step == N), stream 1 = predictor noise of
@@ -546,7 +570,8 @@ def pc_sample_chain(model_fn, sde, shape, noise_fn, predictor="euler_maruyama", 
         vec_t = torch.ones(shape[0]) * timesteps[i]
         x, x_mean = corrector_step(corrector, sde, score_fn, x, vec_t,
                                    lambda k, i=i: noise_fn(i, 2 + k), snr, n_steps)
-        x, x_mean = predictor_step(predictor, sde, score_fn, x, vec_t, noise_fn(i, 1))
+        x, x_mean = predictor_step(predictor, sde, score_fn, x, vec_t,
+                                   None if predictor in (None, "none", "null") else noise_fn(i, 1), probability_flow)
         if i in keep:
             out[i] = (x_mean if denoise else x).clone()
     out["x_last"] = x.clone()

@@ -382,3 +382,226 @@ def test_models_build_from_reference_style_config_and_sample():
     assert len(imgs) == 12 and imgs[-1].shape == (2, 3, 32, 32) and torch.isfinite(imgs[-1]).all()
     loss = m.training_loss({"pixel_values": torch.rand(2, 3, 32, 32, device="cuda") * 2 - 1})
     assert torch.isfinite(loss)
+
+
+def test_interpolation_matches_reference_golden():
+    """GaussianDiffusion.interpolate (gaussian_diffusion.py:195-218; t = 50, lambda = 0.3, the two q_sample draws injected)
+    and GeneralizedGaussianDiffusion.interpolate (generalized_gaussian_diffusion.py:138-140)."""
+    from diffusion_model_nemo_amd.modules import GaussianDiffusion, GeneralizedGaussianDiffusion
+    g = load_golden("switches")
+    u = build_unet("fp32")
+    Tn, t_mix, lam = g["interp_meta"]
+    Tn, t_mix, seed, shape = int(Tn), int(t_mix), 6, (2, 3, 32, 32)
+    gd = GaussianDiffusion(timesteps=Tn, schedule_name="cosine")
+    qn = [T(philox.normal_like(shape, seed, t_mix, s)).cuda() for s in (4, 5)]
+    imgs = gd.interpolate(u, T(g["interp_x1"]).cuda(), T(g["interp_x2"]).cuda(), t=t_mix, lambd=float(lam), seed=seed, noise=qn)
+    assert len(imgs) == t_mix and imgs[0].device.type == "cpu"
+    for k, i in enumerate((0, 24, 49)):
+        mx, _ = err(imgs[i] * 2 - 1, g["interp_xs"][k])
+        assert mx <= 1e-4, (i, mx)
+    with pytest.raises(ValueError):
+        gd.interpolate(u, qn[0], qn[1], t=Tn)
+    gg = GeneralizedGaussianDiffusion(timesteps=Tn, schedule_name="cosine", eta=0.0, ddim_timesteps=10)
+    imgs = gg.interpolate(u, T(g["ddim_interp_latent"]).cuda(), seed=seed)
+    want = g["ddim_interp_xs"]
+    assert len(imgs) == want.shape[0] == 10
+    for i in range(10):
+        mx, _ = err(imgs[i] * 2 - 1, want[i])
+        assert mx <= 1e-4, (i, mx)
+
+
+@pytest.mark.parametrize("tag,kind,pred,corr,kw", [
+    ("vp_rd_langevin_disc", "vp", "reverse_diffusion", "langevin", dict(continuous=False)),
+    ("ve_em_none_disc", "ve", "euler_maruyama", None, dict(continuous=False)),
+    ("ve_rd_langevin_pf", "ve", "reverse_diffusion", "langevin", dict(probability_flow=True)),
+    ("vp_rd_none_pf", "vp", "reverse_diffusion", None, dict(probability_flow=True)),
+    ("ve_rd_langevin_raw", "ve", "reverse_diffusion", "langevin", dict(denoise=False)),
+    ("vp_none_langevin", "vp", None, "langevin", dict())])
+def test_pc_sampler_options_match_reference_golden(tag, kind, pred, corr, kw):
+    """PredictorCorrectorSampler(continuous=False | probability_flow=True | denoise=False | predictor=None)
+    (predictor_corrector_sampler.py:19-29,97-113) on N = 20 chains; tolerance relative to the golden's maximum."""
+    from diffusion_model_nemo_amd.modules import VESDE, VPSDE, PredictorCorrectorSampler
+    g = load_golden("switches")
+    N = 20
+    sde = VESDE(0.01, 50.0, N) if kind == "ve" else VPSDE(0.1, 20.0, N)
+    u = build_unet("fp32", groups=4)
+    s = PredictorCorrectorSampler(predictor=pred, corrector=corr, snr=0.16, n_steps=1, **kw)
+    s.update_sde(sde)
+    imgs, nfe = s.forward(u, [2, 3, 32, 32], "cuda", return_nfe=True, seed=7)
+    assert nfe == int(g[f"{tag}_nfe"]) and len(imgs) == N
+    for i in (0, 9, 19):
+        ref = g[f"{tag}_img_{i}"]
+        scale = max(1.0, float(np.abs(ref).max()))
+        mx, _ = err(imgs[i] * 2 - 1, ref)
+        assert mx <= 2e-4 * scale, (tag, i, mx, scale)
+    last = s.forward(u, [2, 3, 32, 32], "cuda", return_nfe=False, seed=7, keep="last")
+    assert len(last) == 1 and torch.equal(last[0], imgs[-1])
+
+
+def test_pc_sampler_error_behaviour_follows_reference():
+    from diffusion_model_nemo_amd.modules import VESDE, VPSDE, PredictorCorrectorSampler
+    u = build_unet("fp32", groups=4)
+    s = PredictorCorrectorSampler(predictor="euler_maruyama", corrector=None, snr=0.16, probability_flow=True)
+    s.update_sde(VESDE(0.01, 50.0, 4))
+    with pytest.raises(TypeError):        # euler_maruyama_predictor.py:16 subscripts the float diffusion of the ODE
+        s.forward(u, [1, 3, 32, 32], "cuda")
+    s = PredictorCorrectorSampler(predictor="ancestral_sampling", corrector=None, snr=0.16)
+    s.update_sde(VPSDE(0.1, 20.0, 4))
+    with pytest.raises(AttributeError):   # ancestral_sampling_predictor.py:32 reads VPSDE.discrete_betas
+        s.forward(u, [1, 3, 32, 32], "cuda")
+    s = PredictorCorrectorSampler(predictor="reverse_diffusion", corrector=None, snr=0.16)
+    with pytest.raises(ValueError):       # predictor_corrector_sampler.py:66-67
+        s.forward(u, [1, 3, 32, 32], "cuda")
+    # neither predictor nor corrector: N copies of the prior draw, like the reference's loop
+    s = PredictorCorrectorSampler(predictor=None, corrector=None, snr=0.16)
+    s.update_sde(VESDE(0.01, 50.0, 4))
+    imgs = s.forward(u, [1, 3, 32, 32], "cuda", return_nfe=False, seed=1)
+    assert len(imgs) == 4 and all(torch.equal(imgs[0], im) for im in imgs)
+
+
+def test_sde_corrector_single_steps_match_reference_golden():
+    """dmn_sde_corrector_step (the batch-mean-norm reduction, langevin_corrector.py:26-33, and the fixed-step annealed
+    form, annealed_langevin_dynamics_corrector.py:34-39) against the reference's own corrector objects: the per-sample-time
+    fixtures of sde_units.npz where the update does not couple samples at different times (VE Langevin: no time
+    dependence; annealed Langevin: one call per sample), and the one-time fixtures of switches.npz for all four."""
+    from diffusion_model_nemo_amd import _native as N
+    from diffusion_model_nemo_amd.modules import VESDE, VPSDE, PredictorCorrectorSampler
+    lib = N.lib()
+
+    def run(sde, cname, tab, row, x, score, zs, b0, nb):
+        """len(zs) inner steps on images [b0, b0 + nb) with table row `row`; returns x after the last step."""
+        _, Cc, H, W = x.shape
+        cur = x[b0:b0 + nb].contiguous().clone()
+        net = (score[b0:b0 + nb] / tab[row, 4]).contiguous()   # the kernel takes the network output: score / score scale
+        scratch = torch.empty(lib.dmn_sde_scratch_bytes(nb, Cc, H, W), dtype=torch.uint8, device="cuda")
+        for k, z in enumerate(zs):
+            out = torch.empty_like(cur)
+            N.check(lib.dmn_sde_corrector_step(tab.data_ptr(), row, cur.data_ptr(), net.data_ptr(),
+                                               z[b0:b0 + nb].contiguous().data_ptr(), out.data_ptr(), nb, Cc, H, W, 0.16, k,
+                                               1 if cname == "langevin" else 0, 0, 0, scratch.data_ptr(), None))
+            cur = out
+        return cur
+
+    def table(sde, cname, times):
+        s = PredictorCorrectorSampler(predictor="reverse_diffusion", corrector=cname, snr=0.16)
+        s.update_sde(sde)
+        return s.step_table("cuda", times=times)
+
+    g = load_golden("sde_units")
+    x, z, z2, score = (T(g[k]).cuda().contiguous() for k in ("x", "z", "z2", "score"))
+    ve, vp = VESDE(0.01, 50.0, 1000), VPSDE(0.1, 20.0, 1000)
+    got = run(ve, "langevin", table(ve, "langevin", T(g["t"])), 0, x, score, [z, z2], 0, 2)
+    assert err(got, g["ve_langevin_x"])[0] <= 3e-6 * max(1.0, float(np.abs(g["ve_langevin_x"]).max()))
+    for sname, sde in (("ve", ve), ("vp", vp)):
+        tab = table(sde, "ald", T(g["t"]))
+        for b in range(2):
+            got = run(sde, "ald", tab, b, x, score, [z, z2], b, 1)
+            ref = g[f"{sname}_ald_x"][b:b + 1]
+            assert err(got, ref)[0] <= 3e-6 * max(1.0, float(np.abs(ref).max())), (sname, b)
+
+    g = load_golden("switches")
+    x, score = T(g["corr_x"]).cuda().contiguous(), T(g["corr_score"]).cuda().contiguous()
+    zs = [T(g["corr_z0"]).cuda().contiguous(), T(g["corr_z1"]).cuda().contiguous()]
+    for sname, sde in (("ve", ve), ("vp", vp)):
+        for cname in ("langevin", "ald"):
+            tab = table(sde, cname, T(g["corr_t"]))
+            for n in (1, 2):
+                got = run(sde, cname, tab, 0, x, score, zs[:n], 0, 2)
+                ref = g[f"corr_{sname}_{cname}_n{n}_x"]
+                assert err(got, ref)[0] <= 3e-6 * max(1.0, float(np.abs(ref).max())), (sname, cname, n)
+
+
+def build_unet64(compute_dtype, learned_variance=False):
+    from diffusion_model_nemo_amd.modules import Unet
+    u = Unet(input_dim=64, dim=32, dim_mults=[1, 2, 4, 8], channels=3, resnet_block_groups=8, use_convnext=False,
+             dropout=0.0, learned_variance=learned_variance, compute_dtype=compute_dtype)
+    sd = make_state_dict(unet_param_shapes(learned_variance=learned_variance))
+    u.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return u.cuda().eval()
+
+
+def test_learned_variance_forward_at_the_bench_shape_matches_oracle():
+    """BASELINE configuration 3 per GPU: the 6-channel network on [64, 3, 64, 64]; images 0 and 63 against the oracle."""
+    u = build_unet64("fp32", learned_variance=True)
+    p = R.to_torch(make_state_dict(unet_param_shapes(learned_variance=True)))
+    B = 64
+    x = T(philox.normal_like((B, 3, 64, 64), 6, 0, 7))
+    t = torch.arange(B) * 13 % 1000
+    y = u(x.cuda(), t.cuda()).cpu()
+    assert y.shape == (B, 6, 64, 64)
+    idx = [0, B - 1]
+    with torch.no_grad():
+        ref = R.unet_forward(p, x[idx], t[idx])
+    assert float((y[idx] - ref).abs().max()) <= 2e-4
+    yb = build_unet64("bf16", learned_variance=True)(x.cuda(), t.cuda()).cpu()
+    d = (yb[idx] - ref).abs()
+    assert float(d.max()) <= 0.15 and float(d.mean()) <= 1.5e-2
+
+
+def test_bf16_chain_at_the_bench_shape_stays_near_the_fp32_chain():
+    """The timed configuration itself (64 images of 64x64, 1000 steps, cosine schedule): the bf16 handle against the
+    fp32 handle (the one held to the reference within 1e-4) on the same noise, images 0 and 63. Band: the reference
+    under bf16 autocast drifts from its fp32 run by max 4.7e-2 / mean 1.8e-3 on x over such a chain."""
+    from diffusion_model_nemo_amd.modules import GaussianDiffusion
+    gd = GaussianDiffusion(timesteps=1000, schedule_name="cosine")
+    shape = (64, 3, 64, 64)
+    x32 = gd.p_sample_loop(build_unet64("fp32"), shape, device="cuda", seed=11, return_device_tensor=True).cpu()
+    x16 = gd.p_sample_loop(build_unet64("bf16"), shape, device="cuda", seed=11, return_device_tensor=True).cpu()
+    assert torch.isfinite(x32).all() and torch.isfinite(x16).all()
+    d = (x16 - x32).abs()[[0, 63]]
+    print(f"bf16 vs fp32 chain, 64x64 B=64 T=1000: max {float(d.max()):.3e} mean {float(d.mean()):.3e}")
+    assert float(d.max()) <= 1e-1 and float(d.mean()) <= 5e-3, (float(d.max()), float(d.mean()))
+
+
+@pytest.mark.parametrize("dtype,lv", [("fp32", False), ("fp32", True), ("bf16", False), ("bf16", True)])
+def test_sampling_is_bit_identical_across_batch_splits_at_the_bench_shape(dtype, lv):
+    """64 images of 64x64 sampled as one batch, as 2 x 32 and as 8 x 8 (what 1, 2 and 8 ranks would each run): the
+    launch heuristics plan for a fixed batch, so every image comes out bit for bit the same."""
+    from diffusion_model_nemo_amd.modules import GaussianDiffusion, LearnedGaussianDiffusion
+    u = build_unet64(dtype, learned_variance=lv)
+    gd = (LearnedGaussianDiffusion if lv else GaussianDiffusion)(timesteps=12, schedule_name="cosine")
+    full = gd.p_sample_loop(u, (64, 3, 64, 64), device="cuda", seed=21, return_device_tensor=True).cpu()
+    for per in (32, 8):
+        parts = [gd.p_sample_loop(u, (per, 3, 64, 64), device="cuda", seed=21, image_offset=o, return_device_tensor=True).cpu()
+                 for o in range(0, 64, per)]
+        assert torch.equal(torch.cat(parts), full), (dtype, lv, per)
+
+
+def test_plan_batch_zero_plans_for_the_call_and_still_matches_oracle():
+    """set_plan_batch(0): launch geometry chosen for the batch of each call (the small-batch tile and slice choices);
+    same parity bar as the default."""
+    u = build_unet("fp32").set_plan_batch(0)
+    p = R.to_torch(make_state_dict(unet_param_shapes()))
+    x = T(philox.normal_like((3, 3, 48, 40), 77, 0, 7))
+    t = torch.tensor([1, 400, 998])
+    with torch.no_grad():
+        ref = R.unet_forward(p, x, t)
+    assert err(u(x.cuda(), t.cuda()), ref.numpy())[0] <= 2e-4
+    g = load_golden("unet")
+    assert err(u(T(g["x"]).cuda(), torch.full((2,), 500, dtype=torch.long, device="cuda")), g["ddpm_t500"])[0] <= 2e-4
+
+
+def test_nemo_archive_round_trip_samples_bit_for_bit(tmp_path):
+    """save_to -> restore_from -> sample through the HIP loop (what examples/ddpm/eval_ddpm.py:70-102 does with a
+    trained checkpoint): the restored model reproduces the saved model's chain exactly."""
+    from diffusion_model_nemo_amd.models import DDPM
+    cfg = {"image_size": 32, "timesteps": 25, "channels": 3,
+           "diffusion_model": {"_target_": "diffusion_model_nemo.modules.Unet", "input_dim": 32, "dim": 32,
+                               "dim_mults": [1, 2, 4, 8], "use_convnext": False, "dropout": 0.0},
+           "sampler": {"_target_": "diffusion_model_nemo.modules.GaussianDiffusion", "timesteps": 25, "schedule_name": "cosine"},
+           "loss": {"_target_": "diffusion_model_nemo.loss.DiffusionLoss", "loss_type": "l2", "reduction": "mean"}}
+    torch.manual_seed(3)
+    m = DDPM(cfg).cuda()
+    before = m.sample(batch_size=3, image_size=32, seed=9)
+    path = str(tmp_path / "model.nemo")
+    m.save_to(path)
+    r = DDPM.restore_from(path).cuda()
+    assert all(torch.equal(a.cpu(), b.cpu()) for a, b in zip(m.state_dict().values(), r.state_dict().values()))
+    after = r.sample(batch_size=3, image_size=32, seed=9)
+    assert len(after) == len(before) == 25
+    assert all(torch.equal(a, b) for a, b in zip(before, after))
+    # the DDIM sampler swapped in afterwards, as eval_ddpm.py:48-60 does by default
+    r.change_sampler({"_target_": "diffusion_model_nemo.modules.GeneralizedGaussianDiffusion", "timesteps": 25,
+                      "schedule_name": "cosine", "eta": 0.0, "ddim_timesteps": 5})
+    imgs = r.sample(batch_size=3, image_size=32, seed=9)
+    assert len(imgs) == 5 and torch.isfinite(imgs[-1]).all()

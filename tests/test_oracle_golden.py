@@ -312,3 +312,71 @@ def test_bits_per_dimension_matches_reference(golden):
         close(r["terms_bpd"], g[f"{tag}_terms"], atol=2e-5, rtol=2e-5)
         close(r["prior_bpd"], g[f"{tag}_prior"], atol=1e-6, rtol=1e-6)
         close(r["total_bpd"], g[f"{tag}_total"], atol=1e-4, rtol=2e-5)
+
+
+def test_interpolation_matches_reference(golden):
+    """GaussianDiffusion.interpolate (gaussian_diffusion.py:195-218) and GeneralizedGaussianDiffusion.interpolate
+    (generalized_gaussian_diffusion.py:138-140)."""
+    g = golden("switches")
+    p = R.to_torch(make_state_dict(unet_param_shapes()))
+    model = lambda x, t: R.unet_forward(p, x, t)  # noqa: E731
+    Tn, t_mix, lam = g["interp_meta"]
+    Tn, t_mix, seed, shape = int(Tn), int(t_mix), 6, (2, 3, 32, 32)
+    c = R.ddpm_constants(Tn, "cosine")
+    qn = [T(philox.normal_like(shape, seed, t_mix, s)) for s in (4, 5)]
+    with torch.no_grad():
+        xs = R.ddpm_interpolate(model, c, T(g["interp_x1"]), T(g["interp_x2"]), t_mix, float(lam), qn,
+                                lambda i: T(philox.normal_like(shape, seed, i, 1)))
+    assert len(xs) == t_mix
+    for k, i in enumerate((0, 24, 49)):
+        close(xs[i], g["interp_xs"][k], 2e-5)
+    with pytest.raises(ValueError):
+        R.ddpm_interpolate(model, c, T(g["interp_x1"]), T(g["interp_x2"]), Tn, 0.5, qn, None)
+    betas = R.beta_schedule("cosine", Tn)
+    with torch.no_grad():
+        xs = R.ddim_sample_chain(model, betas, shape, lambda i: T(philox.normal_like(shape, seed, i, 1)), eta=0.0,
+                                 ddim_timesteps=10, img=T(g["ddim_interp_latent"]))
+    want = g["ddim_interp_xs"]
+    assert len(xs) == want.shape[0] == 10
+    for i in range(10):
+        close(xs[i], want[i], 2e-5)
+
+
+@pytest.mark.parametrize("tag,kind,pred,corr,kw", [
+    ("vp_rd_langevin_disc", "vp", "reverse_diffusion", "langevin", dict(continuous=False)),
+    ("ve_em_none_disc", "ve", "euler_maruyama", None, dict(continuous=False)),
+    ("ve_rd_langevin_pf", "ve", "reverse_diffusion", "langevin", dict(probability_flow=True)),
+    ("vp_rd_none_pf", "vp", "reverse_diffusion", None, dict(probability_flow=True)),
+    ("ve_rd_langevin_raw", "ve", "reverse_diffusion", "langevin", dict(denoise=False)),
+    ("vp_none_langevin", "vp", None, "langevin", dict())])
+def test_pc_chain_options_match_reference(golden, tag, kind, pred, corr, kw):
+    """PredictorCorrectorSampler with continuous=False, probability_flow=True, denoise=False and without a predictor
+    (predictor_corrector_sampler.py:19-29,97-113)."""
+    g = golden("switches")
+    N, shape, seed = 20, (2, 3, 32, 32), 7
+    sde = R.VESDE(0.01, 50.0, N) if kind == "ve" else R.VPSDE(0.1, 20.0, N)
+    p = R.to_torch(make_state_dict(unet_param_shapes()))
+    model = lambda x, t: R.unet_forward(p, x, t, groups=4)  # noqa: E731
+    noise = lambda step, stream: T(philox.normal_like(shape, seed, step, stream))  # noqa: E731
+    with torch.no_grad():
+        out = R.pc_sample_chain(model, sde, shape, noise, pred, corr, 0.16, 1, keep=(0, 9, 19), **kw)
+    for i in (0, 9, 19):
+        ref = g[f"{tag}_img_{i}"]
+        close(out[i], ref, 5e-5 * max(1.0, float(np.abs(ref).max())), 0)
+    assert int(g[f"{tag}_nfe"]) == N * 2
+    with pytest.raises(TypeError):   # the reference subscripts the float diffusion 0.0 (euler_maruyama_predictor.py:16)
+        R.pc_sample_chain(model, sde, shape, noise, "euler_maruyama", None, probability_flow=True, n_iter=1)
+
+
+def test_corrector_steps_at_one_time_match_reference(golden):
+    """Langevin / annealed-Langevin inner steps with one time for the whole batch (langevin_corrector.py:15-35,
+    annealed_langevin_dynamics_corrector.py:21-41)."""
+    g = golden("switches")
+    x, score, t = T(g["corr_x"]), T(g["corr_score"]), T(g["corr_t"])
+    zs = [T(g["corr_z0"]), T(g["corr_z1"])]
+    for sname, sde in (("ve", R.VESDE(0.01, 50.0, 1000)), ("vp", R.VPSDE(0.1, 20.0, 1000))):
+        for cname in ("langevin", "ald"):
+            for n in (1, 2):
+                xo, xm = R.corrector_step(cname, sde, lambda a, b: score.clone(), x, t, lambda k: zs[k], 0.16, n)
+                close(xo, g[f"corr_{sname}_{cname}_n{n}_x"], 1e-6, 2e-6)
+                close(xm, g[f"corr_{sname}_{cname}_n{n}_mean"], 1e-6, 2e-6)

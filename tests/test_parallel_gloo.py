@@ -153,3 +153,34 @@ def test_two_rank_gradient_all_reduce_equals_full_batch_gradient(tmp_path):
     want = _oracle_flat_grads(*_train_inputs(4), layout, n).numpy()
     got = np.load(out)
     assert np.abs(got - want).max() <= 1e-6 + 1e-4 * np.abs(want).max()
+
+
+# ---- data-parallel training: replicas that start apart are brought together before the first exchange -------------------
+def _sync_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from diffusion_model_nemo_amd.parallel import all_reduce_flat_grads, broadcast_training_state
+        gen = torch.Generator().manual_seed(100 + rank)          # every rank starts from its own initialisation
+        params, m, v = (torch.randn(1000, generator=gen) for _ in range(3))
+        step = broadcast_training_state((params, m, v), 7 + rank)
+        assert step == 7
+        grads = torch.randn(1000, generator=gen)                  # per-rank gradients
+        scale = all_reduce_flat_grads(grads)
+        params -= 0.1 * grads * scale                              # any deterministic update of identical inputs
+        np.save(os.path.join(out_dir, f"rank{rank}.npy"), torch.stack([params, m, v]).numpy())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_replicas_hold_equal_parameters_after_a_step(tmp_path):
+    mp.spawn(_sync_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "rank0.npy"), np.load(tmp_path / "rank1.npy")
+    assert np.array_equal(a, b)
+    want = torch.randn(1000, generator=torch.Generator().manual_seed(100))   # rank 0's parameters won
+    g0 = torch.Generator().manual_seed(100)
+    p0 = torch.randn(1000, generator=g0)
+    assert torch.equal(p0, want)
+    assert np.array_equal(a[1], torch.randn(1000, generator=g0).numpy())     # rank 0's first moment everywhere

@@ -479,6 +479,81 @@ def gen_ddim(M, out, seed=3):
     npz(out, "chain_ddim_T1000_B2_32", **arrays)
 
 
+def gen_switches(M, out, seed=6):
+    """Boundary methods and sampler options the other fixtures leave out: GaussianDiffusion.interpolate
+    (gaussian_diffusion.py:195-218), GeneralizedGaussianDiffusion.interpolate (generalized_gaussian_diffusion.py:138-140),
+    PredictorCorrectorSampler with continuous=False / probability_flow=True / denoise=False
+    (predictor_corrector_sampler.py:19-29,97-113; sde_lib.py:91-105; score_function_loss.py:60-72,80-90), and Langevin /
+    annealed-Langevin corrector steps in which every sample shares one time (langevin_corrector.py:15-35)."""
+    B = 2
+    shape = (B, 3, 32, 32)
+    arrays = {}
+    u = build_unet(M)
+    # DDPM interpolation: q_sample of both images at t (two randn_like draws), mix, then t ancestral steps
+    T, t_mix, lam = 1000, 50, 0.3
+    gd = M.GaussianDiffusion(timesteps=T, schedule_name="cosine")
+    x1 = torch.tanh(x_input(shape, seed=61))
+    x2 = torch.tanh(x_input(shape, seed=62))
+    plan = [(t_mix, 4), (t_mix, 5)] + [(i, 1) for i in reversed(range(t_mix))]
+    with NoiseInjector(plan, seed=seed), torch.no_grad():
+        imgs = gd.interpolate(u, x1, x2, t=t_mix, lambd=lam)
+    assert len(imgs) == t_mix
+    arrays.update(interp_x1=x1, interp_x2=x2, interp_meta=np.array([T, t_mix, lam], dtype=np.float64),
+                  interp_xs=torch.stack([imgs[i] for i in (0, 24, 49)]) * 2.0 - 1.0)
+    # DDIM "interpolation": the whole strided sequence applied to a given latent (no x_T draw)
+    g = M.GeneralizedGaussianDiffusion(timesteps=T, schedule_name="cosine", eta=0.0, ddim_timesteps=10)
+    lat = x_input(shape, seed=63)
+    seq = list(range(0, T, T // 10))
+    with NoiseInjector([(i, 1) for i in reversed(seq)], seed=seed), torch.no_grad():
+        imgs = g.interpolate(u, lat)
+    arrays.update(ddim_interp_latent=lat, ddim_interp_xs=torch.stack(imgs) * 2.0 - 1.0)
+
+    # predictor-corrector options, N = 20, the score network of the score_sde YAML (groups = 4)
+    N = 20
+    u4 = build_unet(M, groups=4)
+    for tag, sde, pred, corr, kw in (
+            ("vp_rd_langevin_disc", M.VPSDE(0.1, 20.0, N), "reverse_diffusion", "langevin", dict(continuous=False)),
+            ("ve_em_none_disc", M.VESDE(0.01, 50.0, N), "euler_maruyama", None, dict(continuous=False)),
+            ("ve_rd_langevin_pf", M.VESDE(0.01, 50.0, N), "reverse_diffusion", "langevin", dict(probability_flow=True)),
+            # (Euler-Maruyama with probability_flow=True raises in the reference: RSDE.sde returns the float 0.0 as diffusion,
+            #  sde_lib.py:97, which euler_maruyama_predictor.py:16 then subscripts)
+            ("vp_rd_none_pf", M.VPSDE(0.1, 20.0, N), "reverse_diffusion", None, dict(probability_flow=True)),
+            ("ve_rd_langevin_raw", M.VESDE(0.01, 50.0, N), "reverse_diffusion", "langevin", dict(denoise=False)),
+            ("vp_none_langevin", M.VPSDE(0.1, 20.0, N), None, "langevin", dict())):
+        sampler = M.PredictorCorrectorSampler(predictor=pred, corrector=corr, snr=0.16, n_steps=1, **kw)
+        sampler.update_sde(sde)
+        plan = [(N, 0)]
+        for i in range(N):
+            if corr is not None:
+                plan += [(i, 2)]
+            if pred is not None:
+                plan += [(i, 1)]   # NonePredictor draws nothing
+        with NoiseInjector(plan, seed=seed + 1):
+            imgs, nfe = sampler.forward(u4, list(shape), torch.device("cpu"), return_nfe=True, use_tqdm=False)
+        for i in (0, 9, 19):
+            arrays[f"{tag}_img_{i}"] = imgs[i] * 2.0 - 1.0
+        arrays[f"{tag}_nfe"] = np.int64(nfe)
+
+    # corrector steps at ONE time for the whole batch (what a sampling loop feeds them): two inner steps
+    sshape = (B, 3, 8, 8)
+    x = x_input(sshape, seed=64)
+    score = x_input(sshape, seed=65) * 0.3
+    zs = [x_input(sshape, seed=66), x_input(sshape, seed=67)]
+    tv = torch.tensor([0.5005, 0.5005], dtype=torch.float32)
+    arrays.update(corr_x=x, corr_score=score, corr_z0=zs[0], corr_z1=zs[1], corr_t=tv)
+    for sname, sde in (("ve", M.VESDE(0.01, 50.0, 1000)), ("vp", M.VPSDE(0.1, 20.0, 1000))):
+        for cname in ("langevin", "ald"):
+            for n_inner in (1, 2):
+                corr = M.get_corrector(cname)(sde, lambda a, b: score.clone(), 0.16, n_inner)
+                it = iter([z.clone() for z in zs])
+                with NoiseInjector(iter([(0, 0)] * 2), seed=0):
+                    torch.randn_like = lambda _x, **kw: next(it)
+                    xo, xm = corr.update_fn(x.clone(), tv)
+                arrays[f"corr_{sname}_{cname}_n{n_inner}_x"] = xo
+                arrays[f"corr_{sname}_{cname}_n{n_inner}_mean"] = xm
+    npz(out, "switches", **arrays)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -491,7 +566,8 @@ def main():
     torch.set_num_threads(8)
     os.makedirs(args.out, exist_ok=True)
     jobs = dict(schedules=gen_schedules, blocks=gen_blocks, unet=gen_unet, p_sample=gen_psample,
-                sde=gen_sde, train=gen_train, chain=gen_chain, ddim=gen_ddim, cond=gen_cond, bpd=gen_bpd)
+                sde=gen_sde, train=gen_train, chain=gen_chain, ddim=gen_ddim, cond=gen_cond, bpd=gen_bpd,
+                switches=gen_switches)
     for name, fn in jobs.items():
         if args.only and name not in args.only:
             continue
