@@ -44,6 +44,7 @@ SIGNATURES = {
     "dmn_sde_predictor_step": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _u64, _i64, _vp]),
     "dmn_sde_corrector_step": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _u64, _i64, _vp, _vp]),
     "dmn_sde_scratch_bytes": (_sz, [_i, _i, _i, _i]),
+    "dmn_sde_corrector_step_static": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _u64, _i64, _vp]),
     "dmn_pc_sample_loop": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _f, _u64, _i64, _vp, _vp, _vp,
                                 _sz, _vp, _i]),
     "dmn_bpd_loop": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _u64, _i64, _vp, _i, _vp, _f, _f, _vp, _sz, _vp, _i]),

@@ -7,6 +7,11 @@
 //   * Langevin corrector (batch-mean of per-sample norms) sde_correctors/langevin_corrector.py:26-33
 // All per-step scalars come from a device table indexed by a device-resident step counter, so one
 // captured graph replays for every step. Noise is Philox (dmn_rng.h) or an injected tensor.
+#include <string.h>
+
+#include <mutex>
+
+#include "../../include/dmn.h"
 #include "dmn_rng.h"
 #include "dmn_sampler.h"
 
@@ -353,4 +358,60 @@ int launch_advance(int* step_idx, hipStream_t s) {
     hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, s, step_idx);
     DMN_HIP_CHECK(hipGetLastError());
     return DMN_OK;
+}
+
+// ---- Langevin corrector step for callers that cannot allocate -------------------------------------------------------
+// Same kernels as dmn_sde_corrector_step; the per-sample partial sums live in a device array of the library instead
+// of a caller's workspace. `scratch` is a host-side stand-in for the array: its device address is resolved once per
+// device with hipGetSymbolAddress and only that address is ever handed to a kernel.
+namespace {
+constexpr size_t kStaticScratchBytes = 64 * 1024;
+constexpr int kMaxDevices = 64;
+}  // namespace
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+static float* g_scratch_ptr[kMaxDevices] = {};
+static std::mutex g_scratch_mu;
+
+extern "C" int dmn_sde_corrector_step_static(const float* table, int row, const float* x, const float* model_out,
+                                             const float* noise, float* x_out, int B, int C, int H, int W, float snr,
+                                             int inner, int use_norms, uint64_t seed, int64_t img_offset, void* stream) {
+    DMN_REQUIRE(table && x && model_out && x_out && row >= 0 && B > 0 && C > 0 && H > 0 && W > 0, DMN_ERR_INVALID,
+                "dmn_sde_corrector_step_static: bad argument");
+    const size_t need = (size_t)B * langevin_slots(C * H * W) * 2 * sizeof(float);
+    DMN_REQUIRE(need <= kStaticScratchBytes, DMN_ERR_LIMIT,
+                "dmn_sde_corrector_step_static: %d images of %d elements need %zu bytes of partial sums, the built-in "
+                "scratch holds %zu (use dmn_sde_corrector_step with a workspace)", B, C * H * W, need, kStaticScratchBytes);
+    int dev = -1;
+    DMN_HIP_CHECK(hipGetDevice(&dev));
+    DMN_REQUIRE(dev >= 0 && dev < kMaxDevices, DMN_ERR_LIMIT, "dmn_sde_corrector_step_static: device ordinal %d", dev);
+    float* part;
+    {
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        if (!g_scratch_ptr[dev]) {   // every device holds its own copy of the array at its own address
+            void* p = nullptr;
+            DMN_HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+            DMN_REQUIRE(p != nullptr, DMN_ERR_HIP, "dmn_sde_corrector_step_static: no device address for the scratch array");
+            g_scratch_ptr[dev] = static_cast<float*>(p);
+        }
+        part = g_scratch_ptr[dev];
+    }
+    LangevinArgs a;
+    memset(&a, 0, sizeof(a));
+    a.c.x = x;
+    a.c.net = model_out;
+    a.c.x_out = x_out;
+    a.c.table = table;
+    a.c.step = row;
+    a.c.B = B;
+    a.c.C = C;
+    a.c.HW = H * W;
+    a.c.seed = seed;
+    a.c.img_offset = img_offset;
+    a.c.noise = noise;
+    a.c.keep_stride = (long long)B * C * H * W;
+    a.partials = part;   // every slot the second kernel reads is written by the first: nothing to clear
+    a.inner = inner;
+    a.use_norms = use_norms;
+    a.snr = snr;
+    return launch_langevin(a, (hipStream_t)stream);
 }

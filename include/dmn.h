@@ -110,6 +110,16 @@ int dmn_sde_corrector_step(const float* table, int row, const float* x, const fl
                            float* x_out, int B, int C, int H, int W, float snr, int inner, int use_norms, uint64_t seed,
                            int64_t img_offset, void* scratch, void* stream);
 size_t dmn_sde_scratch_bytes(int B, int C, int H, int W);
+/* dmn_sde_corrector_step without the `scratch` argument, for callers that cannot allocate device memory (code under
+ * HIP graph capture, serving loops, harnesses that forbid hipMalloc). No counterpart in the reference. The per-sample
+ * partial sums live in a 64 KiB device array of the library (one copy per GPU, held until the process ends), so
+ * B * min(16, ceil(C*H*W / 1024)) * 8 bytes must not exceed 65536 (DMN_ERR_LIMIT otherwise); the call allocates and
+ * frees nothing. Results are bit-identical to dmn_sde_corrector_step. Every call on one GPU shares that GPU's array:
+ * calls that overlap on one GPU (different streams) race; calls on one stream do not. The device that is current at
+ * the call must be the one that owns the tensors. */
+int dmn_sde_corrector_step_static(const float* table, int row, const float* x, const float* model_out, const float* noise,
+                                  float* x_out, int B, int C, int H, int W, float snr, int inner, int use_norms,
+                                  uint64_t seed, int64_t img_offset, void* stream);
 
 /* PredictorCorrectorSampler.forward (sde_samplers/predictor_corrector_sampler.py:58-120): corrector then predictor
  * per iteration. corrector: 0 none, 1 langevin, 2 ald. predictor: 0 none, 1 affine (table rows). `keep` receives
