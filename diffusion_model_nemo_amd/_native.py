@@ -52,7 +52,7 @@ SIGNATURES = {
     "dmn_loop_last_ms": (_i, [_vp, C.POINTER(_f)]),
     "dmn_bench_dominant_kernel": (_i, [_vp, _i, _i, _i, _i, _vp, _sz, _vp, C.POINTER(_f), C.POINTER(C.c_double)]),
     "dmn_unet_probe_dominant": (_i, [_vp, _i]),
-    "dmn_unet_probe_result": (_i, [_vp, C.POINTER(_f), C.POINTER(_i), C.POINTER(C.c_double)]),
+    "dmn_unet_probe_result": (_i, [_vp, C.POINTER(_f), C.POINTER(_f), C.POINTER(_i), C.POINTER(C.c_double)]),
     "dmn_bench_stream": (_i, [_i, _vp, _vp, _sz, _i, _vp, C.POINTER(_f)]),
     "dmn_streams_share_queue": (_i, [_vp, _vp, C.POINTER(_i)]),
     "dmn_bench_mfma": (_i, [_i, _i, _i, _i, _vp, _vp, C.POINTER(_f), C.POINTER(C.c_double)]),
@@ -66,6 +66,12 @@ SIGNATURES = {
     "dmn_train_loss_and_grads": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "dmn_adamw_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _f, _vp, _vp]),
     "dmn_fill_normal": (_i, [_vp, _i, _i, _u64, C.c_uint32, _i64, _f, _vp]),
+    "dmn_test_attention": (_i, [_i, _vp, _vp, _i, _i, _i, _vp]),
+    "dmn_test_unet_trace": (_i, [_vp, _vp, _i]),
+    "dmn_test_unet_trace_count": (_i, [_vp]),
+    "dmn_test_unet_trace_stop": (_i, [_vp, _i]),
+    "dmn_test_unet_trace_poison": (_i, [_vp, C.c_uint32]),
+    "dmn_test_unet_trace_name": (C.c_char_p, [_vp, _i]),
     "dmn_test_set_conv_debug": (_i, [_vp]),
     "dmn_test_linattn": (_i, [_i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i), _vp, _sz, _vp]),
     "dmn_test_conv2d": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp,

@@ -38,7 +38,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIB_DIR, exist_ok=True)
     hdr_time = _newest_header()
     flags = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
-             "-ffp-contract=off", "-fno-honor-nans"]
+             "-ffp-contract=off", "-fno-honor-nans",
+             # No packed-FP32 instructions (v_pk_add/mul/fma_f32) in device code, neither from the SLP vectoriser nor from
+             # vector-typed source: with them, kernels of this library returned wrong sums in lanes 48..63 of a wave
+             # whenever another stream's kernel shared the CU (measured on MI355X with ROCm 7.2: GroupNorm partial sums
+             # short by a lane's share, linear-attention merge rows off by up to 20 %; never when the kernels ran alone).
+             # The scalar forms cost nothing measurable here (the denoising step got 0.5 % faster). The host pass prints
+             # "not a recognized feature" for the second option and ignores it.
+             "-fno-slp-vectorize", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
     # Kernels whose MFMA accumulators feed VALU code inside the loop (softmax, operand re-packing): MFMA results in
     # plain VGPRs, or the compiler shuttles them through the accumulator file and back on every iteration.
     extra = {"dmn_linattn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "dmn_attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],

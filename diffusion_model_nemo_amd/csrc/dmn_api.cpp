@@ -361,3 +361,18 @@ extern "C" int dmn_test_conv2d(int dtype, const void* in0, const void* in1, int 
     if (db) (void)hipFree(db);
     return rc;
 }
+
+// Softmax attention core on caller-provided tensors (unit parity tests).
+extern "C" int dmn_test_attention(int dtype, const void* qkv, void* out, int B, int n, int heads, void* stream) {
+    DMN_REQUIRE(qkv && out && B > 0 && n > 0 && heads > 0, DMN_ERR_INVALID, "dmn_test_attention: bad argument");
+    AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dtype = dtype;
+    a.qkv = qkv;
+    a.out = out;
+    a.B = B;
+    a.n = n;
+    a.heads = heads;
+    a.d = 32;
+    return launch_attention(a, (hipStream_t)stream);
+}

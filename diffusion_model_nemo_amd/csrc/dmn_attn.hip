@@ -275,6 +275,140 @@ __global__ void __launch_bounds__(256) attention_kernel(const AttnArgs a, int pa
     }
 }
 
+// Softmax attention on the matrix cores, for 64 <= n <= 256 keys with n % 32 == 0 (the bottleneck of 64x64 and 128x128
+// inputs; smaller bottlenecks are not dense contractions and keep the VALU kernel above). grid (heads, B, n / 64);
+// a wave owns 16 queries, a workgroup 64.
+//   S^T = K Q^T per 16-key block: A = 16 keys x 32 channels, B = 32 channels x 16 queries, both 16-byte fragments read
+//         straight from the qkv rows; the result has the query on the lane (lane & 15) and four keys per lane group in
+//         its registers, so the soft-max over keys is a reduction over registers plus two cross-group shuffles;
+//   O^T = V^T P^T: the exponentials, still in their accumulator registers, ARE the B operand (32 keys x 16 queries) of
+//         the second product, no lane movement; only V is transposed, once per workgroup, through LDS.
+// Two stacked 16-key tiles form one 32-deep bf16 step in the order (tile 0 regs 0..3, tile 1 regs 0..3) of a lane
+// group, i.e. keys {4g..4g+3, 16+4g..16+4g+3}; the V^T fragment is read in the same order. In f32 mode each 16-key tile
+// is one step of four exact-f32 instructions in natural key order.
+template <typename T>
+__global__ void __launch_bounds__(256) attention_mfma_kernel(const AttnArgs a) {
+    constexpr int PER = ElemTraits<T>::kPer16B;      // elements per 16-byte fragment: 8 (bf16) / 4 (f32)
+    constexpr int KCH = ElemTraits<T>::kChunk;       // channels per MFMA step: 32 / 16
+    constexpr int QS = kD / KCH;                     // steps over the 32 head channels: 1 / 2
+    constexpr int MAXT = 16;                         // 16-key tiles kept in registers (n <= 256)
+    using V = decltype(Vec16<T>::v);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* sVt = reinterpret_cast<T*>(smem);             // V^T [32 channels][n + pad] of this (image, head)
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int n = a.n, hidden = a.heads * kD, pitch = n + 16 / (int)sizeof(T);   // +16 bytes: rows on different banks
+    const T* base = static_cast<const T*>(a.qkv) + (size_t)b * n * 3 * hidden;
+    const int q0 = (blockIdx.z * 4 + wave) * 16;
+
+    // Q fragments of the wave's queries first (B operand: query on the lane, 16 bytes of its channels)
+    Vec16<T> qf[QS];
+#pragma unroll
+    for (int ks = 0; ks < QS; ++ks)
+        qf[ks].v = *reinterpret_cast<const V*>(base + (size_t)(q0 + l15) * 3 * hidden + h * kD + ks * KCH + lq * PER);
+    // V^T into LDS: a thread takes 16 bytes of a key's channels and scatters them over the channel rows
+    for (int u = tid; u < n * (kD / PER); u += 256) {
+        const int key = u / (kD / PER), part = u % (kD / PER);
+        Vec16<T> v;
+        v.v = *reinterpret_cast<const V*>(base + (size_t)key * 3 * hidden + 2 * hidden + h * kD + part * PER);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) sVt[(part * PER + j) * pitch + key] = v.v[j];
+    }
+    const int nt = n / 16;
+    const float scale = 0.17677669529663687f;        // 32^-0.5, applied to the products (the reference scales q)
+    f32x4 sreg[MAXT];
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        if (t < nt) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < QS; ++ks) {
+                Vec16<T> kf;   // A operand: key on the lane
+                kf.v = *reinterpret_cast<const V*>(base + (size_t)(t * 16 + l15) * 3 * hidden + hidden + h * kD + ks * KCH + lq * PER);
+                mma_step(kf, qf[ks], acc);
+            }
+            acc *= scale;
+            sreg[t] = acc;
+            m = fmaxf(fmaxf(m, fmaxf(acc[0], acc[1])), fmaxf(acc[2], acc[3]));
+        }
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        if (t < nt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float e;
+                if constexpr (sizeof(T) == 2) {
+                    e = __expf(sreg[t][r] - m);
+                    e = (float)(__bf16)e;             // the denominator sums what the second product multiplies
+                } else {
+                    e = expf(sreg[t][r] - m);
+                }
+                sreg[t][r] = e;
+                l += e;
+            }
+        }
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    __syncthreads();                                  // V^T complete
+    f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int u = 0; u < MAXT / 2; ++u) {
+            if (2 * u < nt) {
+                Vec16<T> pf;   // B operand: keys {4g..4g+3} of tile 2u, then of tile 2u+1
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pf.v[r] = (__bf16)sreg[2 * u][r];
+                    pf.v[4 + r] = (__bf16)sreg[2 * u + 1][r];
+                }
+#pragma unroll
+                for (int et = 0; et < 2; ++et) {
+                    const T* row = sVt + (et * 16 + l15) * pitch + 32 * u + 4 * lq;
+                    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(row);
+                    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(row + 16);
+                    Vec16<T> vf;
+                    vf.v = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    mma_step(vf, pf, o[et]);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+            if (t < nt) {
+                Vec16<T> pf;
+                pf.v = sreg[t];
+#pragma unroll
+                for (int et = 0; et < 2; ++et) {
+                    Vec16<T> vf;
+                    vf.v = *reinterpret_cast<const V*>(sVt + (et * 16 + l15) * pitch + 16 * t + 4 * lq);
+                    mma_step(vf, pf, o[et]);
+                }
+            }
+        }
+    }
+    // O^T: query on the lane, channels 16 et + 4 g + r in the registers
+    const float inv = 1.0f / l;
+    T* orow = static_cast<T*>(a.out) + ((size_t)b * n + q0 + l15) * hidden + h * kD;
+#pragma unroll
+    for (int et = 0; et < 2; ++et) {
+        if constexpr (sizeof(T) == 2) {
+            bf16x4 ov;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ov[r] = (__bf16)(o[et][r] * inv);
+            *reinterpret_cast<bf16x4*>(orow + et * 16 + lq * 4) = ov;
+        } else {
+            *reinterpret_cast<f32x4*>(orow + et * 16 + lq * 4) = o[et] * inv;
+        }
+    }
+}
+
 }  // namespace
 
 int linear_attention_splits(int n) { return (n + kLaChunk - 1) / kLaChunk; }
@@ -298,6 +432,17 @@ int launch_linear_attention(LinAttnArgs& a, hipStream_t s) {
 
 int launch_attention(AttnArgs& a, hipStream_t s) {
     DMN_REQUIRE(a.d == kD, DMN_ERR_INVALID, "attention: dim_head=%d (only 32)", a.d);
+    if (!a.no_mfma && a.n >= 64 && a.n <= 256 && a.n % 64 == 0) {   // a dense contraction: matrix cores
+        const size_t esz = a.dtype == DMN_F32 ? 4 : 2;
+        const size_t lds = (size_t)kD * (a.n * esz + 16);
+        dim3 grid(a.heads, a.B, a.n / 64);
+        if (a.dtype == DMN_F32)
+            hipLaunchKernelGGL(attention_mfma_kernel<float>, grid, dim3(256), lds, s, a);
+        else
+            hipLaunchKernelGGL(attention_mfma_kernel<__bf16>, grid, dim3(256), lds, s, a);
+        DMN_HIP_CHECK(hipGetLastError());
+        return DMN_OK;
+    }
     const int parts = a.n <= 64 ? 4 : a.n <= 128 ? 2 : 1;
     const int qpw = 256 / parts;
     dim3 grid(a.heads, a.B, (a.n + qpw - 1) / qpw);

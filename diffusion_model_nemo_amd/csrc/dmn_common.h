@@ -11,6 +11,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 #define DMN_WAVE 64
 
+
 // Activation element type of a network instance: float (exact-f32 MFMA path, used for parity with the
 // reference's fp32 CPU results) or __bf16 (bf16 MFMA path, fp32 accumulate, the fast path).
 template <typename T> struct ElemTraits;

@@ -26,6 +26,9 @@
 // Fusions: GroupNorm + SiLU + time-embedding bias of the PREVIOUS Block applied while the input tile is
 // written to LDS (parts/convnext.py:35-41,81-85), bias, optional residual add, and partial GroupNorm
 // statistics of the output for the next consumer.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "dmn_kernels.h"
 #include "dmn_norm.h"
 
@@ -517,6 +520,18 @@ TileCfg pick_cfg(const ConvArgs& a) {
         c.th = c.tw = a.cfg_tile;
         c.bn = a.cfg_bn;
         return c;
+    }
+    {   // tuning override: DMN_CONV_TILE_<Ho>_<Cout>_<kind>="<tile>,<bn>" (tile 8|16, bn 32|64) for launches of that shape
+        char key[64];
+        snprintf(key, sizeof(key), "DMN_CONV_TILE_%d_%d_%d", a.Ho, a.Cout, a.kind);
+        const char* v = getenv(key);
+        int t = 0, n = 0;
+        if (v && sscanf(v, "%d,%d", &t, &n) == 2 && (t == 8 || t == 16) && (n == 32 || n == 64) &&
+            !(a.kind == DMN_K4X4S2 && t == 16) && !(a.w2 && t == 16 && n == 64)) {
+            c.th = c.tw = t;
+            c.bn = n;
+            return c;
+        }
     }
     const int planB = a.plan_B > 0 ? a.plan_B : a.B;
     auto blocks = [&](const TileCfg& t) {

@@ -406,7 +406,45 @@ __global__ void __launch_bounds__(256) egress_kernel(const EgressArgs a) {
         if (o < Cout) __builtin_nontemporal_store(acc[o], &a.out[((size_t)b * Cout + o) * a.HW + p]);
 }
 
+__global__ void __launch_bounds__(256) checksum_kernel(const uint4* p, size_t n16, unsigned long long* slot) {
+    unsigned long long acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+        const uint4 v = p[i];
+        acc += (unsigned long long)v.x + v.y + v.z + v.w;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(slot, acc);
+}
+
+// Fills the whole LDS of the CU a workgroup lands on with `pattern` (one workgroup per CU: it asks for all 160 KiB).
+__global__ void __launch_bounds__(256) lds_poison_kernel(unsigned pattern, unsigned* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned* w = reinterpret_cast<unsigned*>(smem);
+    for (int i = threadIdx.x; i < 160 * 1024 / 4; i += 256) w[i] = pattern;
+    __syncthreads();
+    if (sink && w[threadIdx.x] != pattern) *sink = 1;   // keeps the stores alive
+}
+
 }  // namespace
+
+int launch_lds_poison(unsigned pattern, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        DMN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_poison_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL(lds_poison_kernel, dim3(1024), dim3(256), 160 * 1024, s, pattern, (unsigned*)nullptr);
+    DMN_HIP_CHECK(hipGetLastError());
+    return DMN_OK;
+}
+
+int launch_checksum(const void* p, size_t bytes, unsigned long long* slot, hipStream_t s) {
+    hipLaunchKernelGGL(checksum_kernel, dim3(2048), dim3(256), 0, s, static_cast<const uint4*>(p), bytes / 16, slot);
+    DMN_HIP_CHECK(hipGetLastError());
+    return DMN_OK;
+}
 
 static int norm_apply_elems(int B, int HW, int C) {
     return (long long)B * HW * C / kNormElems >= 1024 ? kNormElems : kNormElemsSmall;

@@ -171,5 +171,11 @@ struct AttnArgs {
     const void* qkv;
     void* out;
     int B, n, heads, d;
+    bool no_mfma;   // keep to the VALU kernel (diagnosis)
 };
 int launch_attention(AttnArgs& a, hipStream_t s);
+
+// *slot += sum of the 32-bit words of [p, p + bytes) (bytes a multiple of 16; integer sum: independent of the order)
+int launch_checksum(const void* p, size_t bytes, unsigned long long* slot, hipStream_t s);
+// overwrites the LDS of every CU with `pattern` (diagnosis of reads of LDS a kernel did not write)
+int launch_lds_poison(unsigned pattern, hipStream_t s);

@@ -3,6 +3,7 @@
 // use_convnext=False; every tensor op is one of the gfx950 kernels declared in dmn_kernels.h.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <cmath>
@@ -14,6 +15,8 @@
 #include "dmn_kernels.h"
 #include "dmn_sampler.h"
 #include "dmn_unet_internal.h"
+
+#include <stdlib.h>
 
 // ---- error string ----------------------------------------------------------------------------------
 static thread_local char g_err[1024] = "";
@@ -210,6 +213,8 @@ struct Act {            // an NHWC activation + optional statistics of it
     int sG = 0, sSlots = 0;
 };
 
+constexpr int kTraceStop = 1;   // Fwd::rc of a traced forward that was asked to end after a given launch
+
 struct Fwd {
     DmnUnet* u;
     Arena ar;
@@ -243,8 +248,19 @@ struct Fwd {
     }
     int planB() const { return u->plan_batch > 0 ? u->plan_batch : B; }
     bool ok() const { return rc == DMN_OK; }
-    void run(int r) {
+    // every launch of the forward reports here; with a trace buffer attached, a checksum of the whole workspace is
+    // taken behind it (slot k = state after launch k), which locates the first launch whose result differs between runs
+    void run(int r, const char* what) {
         if (rc == DMN_OK && r != DMN_OK) rc = r;
+        if (u->trace_slots && !dry && rc == DMN_OK && u->trace_n < u->trace_max) {
+            if ((int)u->trace_names.size() <= u->trace_n) u->trace_names.resize(u->trace_n + 1);
+            u->trace_names[u->trace_n] = what;
+            unsigned long long* slot = u->trace_slots + u->trace_n++;
+            if (hipMemsetAsync(slot, 0, 8, s) != hipSuccess) rc = DMN_ERR_HIP;
+            else rc = launch_checksum(ar.base, ar.cap, slot, s);
+            if (rc == DMN_OK && u->trace_poison) rc = launch_lds_poison(u->trace_poison, s);   // in front of the next launch
+            if (rc == DMN_OK && u->trace_n - 1 == u->trace_stop) rc = kTraceStop;   // skips every later launch
+        }
     }
 };
 
@@ -300,10 +316,17 @@ static Act do_conv(Fwd& f, const PackedConv& pc, const Act& in0, const Act* in1,
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
             probe = hipStreamIsCapturing(f.s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
         }
-        if (probe) (void)hipEventRecord(u->probe_ev[2 * u->probe_n], f.s);
-        f.run(launch_conv(a, f.s));
+        if (probe) {   // two markers back to back (what a marker itself costs), then the launch, then a third
+            (void)hipEventRecord(u->probe_ev[3 * u->probe_n], f.s);
+            (void)hipEventRecord(u->probe_ev[3 * u->probe_n + 1], f.s);
+        }
+        char what[160];
+        snprintf(what, sizeof(what), "conv kind %d %d->%d at %dx%d%s%s%s out@%zu stats@%zu", pc.kind, pc.Cin, pc.Cout, in0.H,
+                 in0.W, pro ? (pro->silu ? " norm+silu" : " norm") : "", res ? " +res" : "", shortcut ? " +shortcut" : "",
+                 (size_t)((char*)a.out - f.ar.base), out.stats ? (size_t)((char*)out.stats - f.ar.base) : (size_t)0);
+        f.run(launch_conv(a, f.s), what);
         if (probe) {
-            (void)hipEventRecord(u->probe_ev[2 * u->probe_n + 1], f.s);
+            (void)hipEventRecord(u->probe_ev[3 * u->probe_n + 2], f.s);
             u->probe_bytes = (double)f.B * in0.H * in0.W * (pc.Cin + pc.Cout) * f.esz() + (double)pc.Cin * pc.Cout * pc.ntaps * f.esz();
             ++u->probe_n;
         }
@@ -348,7 +371,7 @@ static Act resblock(Fwd& f, const ResBlockW& w, Act& x, Act* x2, const float* tb
         h1.sSlots = conv_epi_slots(a);
         h1.stats = f.new_stats(G, h1.sSlots);
         a.epi.stats = h1.stats;
-        if (f.ok() && !f.dry) f.run(launch_conv(a, f.s));
+        if (f.ok() && !f.dry) f.run(launch_conv(a, f.s), "conv1 + previous block's tail");
         f.free_act(pending->h2);
         if (pending->has_r) f.free_act(pending->r);
         pending->active = false;
@@ -387,7 +410,7 @@ static Act resblock(Fwd& f, const ResBlockW& w, Act& x, Act* x2, const float* tb
         na.epi.stats = out.stats;
         na.epi.G = statsG;
     }
-    if (f.ok() && !f.dry) f.run(launch_norm_apply(na, f.s));
+    if (f.ok() && !f.dry) f.run(launch_norm_apply(na, f.s), "block tail");
     f.free_act(h2);
     if (w.has_res) f.free_act(r);
     return out;
@@ -406,7 +429,7 @@ static Act lin_attn_tail(Fwd& f, const AttnW& w, Act& x, Act& y) {
     na.C = x.C;
     na.norm = norm_in(y, w.og, w.ob, f.B, 0, nullptr, 0);
     na.plan_B = f.planB();
-    if (f.ok() && !f.dry) f.run(launch_norm_apply(na, f.s));
+    if (f.ok() && !f.dry) f.run(launch_norm_apply(na, f.s), "linear attention tail");
     f.free_act(y);
     return out;
 }
@@ -415,7 +438,7 @@ static Act lin_attn_tail(Fwd& f, const AttnW& w, Act& x, Act& y) {
 static Act lin_attn(Fwd& f, const AttnW& w, Act& x) {
     const DmnUnetCfg& c = f.u->cfg;
     const int hidden = c.heads * c.dim_head;
-    if (w.fq) {
+    if (w.fq && !(f.u->path_mask & 2)) {
         LinAttnFusedArgs fa;
         memset(&fa, 0, sizeof(fa));
         fa.dtype = c.dtype;
@@ -440,7 +463,11 @@ static Act lin_attn(Fwd& f, const AttnW& w, Act& x) {
         fa.y = y.p;
         fa.y_stats = y.stats;
         fa.ctx_part = part;
-        if (f.ok() && !f.dry) f.run(launch_linattn_fused(fa, f.s));
+        char what[160];
+        snprintf(what, sizeof(what), "fused linear attention C=%d n=%d y@%zu stats@%zu part@%zu ctxT@%zu", fa.C, fa.n,
+                 (size_t)((char*)y.p - f.ar.base), (size_t)((char*)y.stats - f.ar.base), (size_t)((char*)part - f.ar.base),
+                 (size_t)((char*)ctxT - f.ar.base));
+        if (f.ok() && !f.dry) f.run(launch_linattn_fused(fa, f.s), what);
         f.ar.release(part);
         f.ar.release(ctxT);
         return lin_attn_tail(f, w, x, y);
@@ -460,7 +487,7 @@ static Act lin_attn(Fwd& f, const AttnW& w, Act& x) {
     aa.splits = linear_attention_splits(aa.n);
     float* part = (float*)f.alloc((size_t)f.B * c.heads * aa.splits * (c.dim_head * c.dim_head + 2 * c.dim_head) * 4);
     aa.ctx_part = part;
-    if (f.ok() && !f.dry) f.run(launch_linear_attention(aa, f.s));
+    if (f.ok() && !f.dry) f.run(launch_linear_attention(aa, f.s), "linear attention core");
     f.free_act(qkv);
     f.ar.release(part);
     Act y = do_conv(f, w.out, la, nullptr, nullptr, nullptr, 1);
@@ -484,7 +511,8 @@ static Act full_attn(Fwd& f, const AttnW& w, Act& x) {
     aa.n = x.H * x.W;
     aa.heads = c.heads;
     aa.d = c.dim_head;
-    if (f.ok() && !f.dry) f.run(launch_attention(aa, f.s));
+    aa.no_mfma = (f.u->path_mask & 8) != 0;
+    if (f.ok() && !f.dry) f.run(launch_attention(aa, f.s), "attention core");
     f.free_act(qkv);
     Act out = do_conv(f, w.out, o, nullptr, nullptr, &x, 0);
     f.free_act(o);
@@ -506,6 +534,10 @@ int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float,
     f.B = B;
     f.dry = dry;
     f.ar.reset(ws, ws_bytes, dry);
+    if (!dry) {
+        u->trace_n = 0;
+        if (u->trace_slots && u->trace_poison) (void)launch_lds_poison(u->trace_poison, s);
+    }
 
     float* tb = nullptr;
     int tb_rows = B;
@@ -552,11 +584,11 @@ int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float,
             ia.num_classes = c.num_classes;
         }
         if (f.ok() && !dry) {
-            if (c.with_time_emb && ingest_time_fusable(ia, ta)) {
-                f.run(launch_ingest_time(ia, ta, s));   // the two independent openers of the network in one launch
+            if (c.with_time_emb && !(u->path_mask & 1) && ingest_time_fusable(ia, ta)) {
+                f.run(launch_ingest_time(ia, ta, s), "ingest + time");   // the two independent openers of the network in one launch
             } else {
-                if (c.with_time_emb) f.run(launch_time_mlp(ta, s));
-                f.run(launch_ingest(ia, s));
+                if (c.with_time_emb) f.run(launch_time_mlp(ta, s), "time");
+                f.run(launch_ingest(ia, s), "ingest");
             }
         }
     }
@@ -565,7 +597,7 @@ int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float,
     for (int i = 0; i < nlev; ++i) {
         // the first block's tail is applied by the second block's first convolution (which also stores it)
         LazyTail lt;
-        const bool lazy = u->downs[i].rb[1].c1.kind == DMN_K3X3 && !u->downs[i].rb[1].has_res;
+        const bool lazy = !(u->path_mask & 4) && u->downs[i].rb[1].c1.kind == DMN_K3X3 && !u->downs[i].rb[1].has_res;
         Act a1 = resblock(f, u->downs[i].rb[0], cur, nullptr, tb, tbs, 0, nullptr, lazy ? &lt : nullptr);
         Act a2 = resblock(f, u->downs[i].rb[1], a1, nullptr, tb, tbs, 1, &lt, nullptr);
         f.free_act(cur);   // the block input stays alive as the deferred tail's residual
@@ -592,7 +624,7 @@ int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float,
         Act sk = skips.back();
         skips.pop_back();
         LazyTail lt;
-        const bool lazy = u->ups[i].rb[1].c1.kind == DMN_K3X3 && !u->ups[i].rb[1].has_res;
+        const bool lazy = !(u->path_mask & 4) && u->ups[i].rb[1].c1.kind == DMN_K3X3 && !u->ups[i].rb[1].has_res;
         Act a1 = resblock(f, u->ups[i].rb[0], cur, &sk, tb, tbs, 0, nullptr, lazy ? &lt : nullptr);
         f.free_act(cur);
         f.free_act(sk);
@@ -615,11 +647,11 @@ int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float,
         ea.bias = u->tail_bias;
         ea.out = out;
         ea.B = B; ea.HW = H * W; ea.C = c.dim; ea.Cout = c.out_dim;
-        if (f.ok() && !dry) f.run(launch_egress(ea, s));
+        if (f.ok() && !dry) f.run(launch_egress(ea, s), "egress");
         f.free_act(fin);
     }
     if (high) *high = f.ar.high;
-    return f.rc;
+    return f.rc == kTraceStop ? DMN_OK : f.rc;
 }
 
 static int pack_fragments(int dtype, const float* W, int rows, int K, bool acc_order, void** dev);
@@ -726,12 +758,13 @@ extern "C" int dmn_bench_dominant_kernel(DmnUnet* u, int B, int H, int W, int it
 // Event pairs around the dominant convolution as it runs INSIDE eager (not graph-replayed) network evaluations: the
 // launch then follows and precedes the same kernels as in a sampling step and finds its operands in the same cache
 // state, unlike back-to-back launches of the kernel by itself. Enable, run evaluations / an eager sampling loop on one
-// stream, then read the average. The host enqueues faster than the device executes, so the two markers of a pair sit
-// in the queue directly around the kernel; their distance includes the two marker packets.
+// stream, then read the averages. The host enqueues faster than the device executes, so the markers sit in the queue
+// directly around the kernel. Three markers per probed launch: the distance of the first two (nothing between them) is
+// what a marker packet itself costs, the distance of the last two is the kernel plus one marker.
 extern "C" int dmn_unet_probe_dominant(DmnUnet* u, int enable) {
     DMN_REQUIRE(u, DMN_ERR_INVALID, "dmn_unet_probe_dominant: null handle");
     if (enable && u->probe_ev.empty()) {
-        u->probe_ev.resize(2 * kProbePairs, nullptr);
+        u->probe_ev.resize(3 * kProbePairs, nullptr);
         for (auto& e : u->probe_ev) DMN_HIP_CHECK(hipEventCreate(&e));
     }
     u->probe_on = enable != 0;
@@ -739,17 +772,20 @@ extern "C" int dmn_unet_probe_dominant(DmnUnet* u, int enable) {
     return DMN_OK;
 }
 
-extern "C" int dmn_unet_probe_result(DmnUnet* u, float* avg_ms, int* launches, double* alg_bytes) {
-    DMN_REQUIRE(u && avg_ms && launches, DMN_ERR_INVALID, "dmn_unet_probe_result: null argument");
+extern "C" int dmn_unet_probe_result(DmnUnet* u, float* avg_ms, float* marker_ms, int* launches, double* alg_bytes) {
+    DMN_REQUIRE(u && avg_ms && marker_ms && launches, DMN_ERR_INVALID, "dmn_unet_probe_result: null argument");
     DMN_REQUIRE(u->probe_n > 0, DMN_ERR_INVALID, "dmn_unet_probe_result: no probed launch recorded");
-    double sum = 0.0;
+    double sum = 0.0, empty = 0.0;
     for (int i = 0; i < u->probe_n; ++i) {
-        DMN_HIP_CHECK(hipEventSynchronize(u->probe_ev[2 * i + 1]));
+        DMN_HIP_CHECK(hipEventSynchronize(u->probe_ev[3 * i + 2]));
         float ms = 0.f;
-        DMN_HIP_CHECK(hipEventElapsedTime(&ms, u->probe_ev[2 * i], u->probe_ev[2 * i + 1]));
+        DMN_HIP_CHECK(hipEventElapsedTime(&ms, u->probe_ev[3 * i], u->probe_ev[3 * i + 1]));
+        empty += ms;
+        DMN_HIP_CHECK(hipEventElapsedTime(&ms, u->probe_ev[3 * i + 1], u->probe_ev[3 * i + 2]));
         sum += ms;
     }
     *avg_ms = (float)(sum / u->probe_n);
+    *marker_ms = (float)(empty / u->probe_n);
     *launches = u->probe_n;
     if (alg_bytes) *alg_bytes = u->probe_bytes;
     return DMN_OK;
@@ -941,10 +977,42 @@ extern "C" int dmn_unet_create(const DmnUnetCfg* cfg, DmnUnet** out) {
     if (rc) return rc;
     DmnUnet* u = new DmnUnet();
     u->cfg = *cfg;
+    if (const char* e = getenv("DMN_UNET_PATHS")) u->path_mask = atoi(e);
     u->downs.resize(cfg->n_mults);
     u->ups.resize(cfg->n_mults - 1);
     *out = u;
     return DMN_OK;
+}
+
+// Diagnosis: attach a device array of `max_slots` 64-bit slots; every forward from then on writes a checksum of its
+// whole workspace after each of its launches (slot k: after launch k) and restarts at slot 0. nullptr detaches.
+extern "C" int dmn_test_unet_trace(DmnUnet* u, unsigned long long* slots, int max_slots) {
+    DMN_REQUIRE(u && max_slots >= 0, DMN_ERR_INVALID, "dmn_test_unet_trace: bad argument");
+    u->trace_slots = slots;
+    u->trace_max = slots ? max_slots : 0;
+    u->trace_n = 0;
+    u->trace_stop = -1;
+    return DMN_OK;
+}
+
+// Diagnosis: traced forwards overwrite the LDS of every CU with `pattern` in front of each launch (0: off).
+extern "C" int dmn_test_unet_trace_poison(DmnUnet* u, unsigned pattern) {
+    DMN_REQUIRE(u, DMN_ERR_INVALID, "dmn_test_unet_trace_poison: null handle");
+    u->trace_poison = pattern;
+    return DMN_OK;
+}
+
+// Diagnosis: the following forwards end after launch k (the workspace then holds the state behind it); -1: run all.
+extern "C" int dmn_test_unet_trace_stop(DmnUnet* u, int k) {
+    DMN_REQUIRE(u, DMN_ERR_INVALID, "dmn_test_unet_trace_stop: null handle");
+    u->trace_stop = k;
+    return DMN_OK;
+}
+
+// Launches traced by the last forward, and the description of launch k (valid until the next forward).
+extern "C" int dmn_test_unet_trace_count(const DmnUnet* u) { return u ? u->trace_n : 0; }
+extern "C" const char* dmn_test_unet_trace_name(const DmnUnet* u, int k) {
+    return (u && k >= 0 && k < (int)u->trace_names.size()) ? u->trace_names[k].c_str() : "";
 }
 
 extern "C" int dmn_unet_set_class_labels(DmnUnet* u, const int64_t* labels) {

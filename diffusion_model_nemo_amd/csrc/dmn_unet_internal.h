@@ -1,5 +1,6 @@
 // Private layout of the DmnUnet handle (weights packed for the gfx950 kernels).
 #pragma once
+#include <string>
 #include <vector>
 
 #include "../../include/dmn.h"
@@ -66,6 +67,15 @@ struct DmnUnet {
     // of the GroupNorm statistics are then formed in the same order for an image however its batch is sharded, so
     // per-image results are bit-identical across splits. 0: plan for the batch of each call.
     int plan_batch = 64;
+    // Diagnosis switches (environment DMN_UNET_PATHS, read when the handle is created): bit 0 launches the ingest and
+    // the time path separately, bit 1 uses the unfused linear attention, bit 2 closes every ResnetBlock with its own
+    // pass instead of leaving it to the next convolution, bit 3 keeps the bottleneck attention off the matrix cores.
+    int path_mask = 0;
+    // diagnosis: workspace checksums after every launch of a forward (dmn_test_unet_trace)
+    unsigned long long* trace_slots = nullptr;
+    int trace_max = 0, trace_n = 0, trace_stop = -1;
+    unsigned trace_poison = 0;
+    std::vector<std::string> trace_names;
     // cached step graph of the sampling loops
     hipGraphExec_t graph_exec = nullptr;
     SampleKey graph_key = {};
@@ -73,7 +83,7 @@ struct DmnUnet {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool ev_valid = false;
     // measurement hook: HIP event pairs around the launches of the step's dominant convolution (eager launches only)
-    std::vector<hipEvent_t> probe_ev;    // 2 * kProbePairs events once enabled
+    std::vector<hipEvent_t> probe_ev;    // 3 * kProbePairs events once enabled
     int probe_n = 0;                     // pairs recorded since the probe was switched on
     bool probe_on = false;
     double probe_bytes = 0.0;            // algorithmic bytes of one probed launch

@@ -152,11 +152,13 @@ int dmn_bench_dominant_kernel(DmnUnet* u, int B, int H, int W, int iters, void* 
 /* The same kernel timed where it runs: HIP event pairs around its launch inside eager (use_graph = 0) network
  * evaluations or sampling loops on one stream, so that it follows and precedes the same kernels as in a captured step
  * and finds its operands in the same cache state. dmn_unet_probe_dominant(u, 1) starts collecting (at most 256
- * launches), (u, 0) stops; dmn_unet_probe_result waits for the recorded pairs and returns their average distance (the
- * kernel plus the two marker packets), their number and the algorithmic bytes of one launch.
+ * launches), (u, 0) stops; dmn_unet_probe_result waits for the recorded markers and returns avg_ms = the average
+ * distance of the two markers around the kernel (the kernel plus one marker packet), marker_ms = the average distance of
+ * two markers with nothing between them (recorded just before each probed launch), the number of probed launches and
+ * the algorithmic bytes of one launch. avg_ms - marker_ms estimates the kernel's own duration.
  * No counterpart in the reference: measurement hooks used by bench.py. */
 int dmn_unet_probe_dominant(DmnUnet* u, int enable);
-int dmn_unet_probe_result(DmnUnet* u, float* avg_ms, int* launches, double* alg_bytes);
+int dmn_unet_probe_result(DmnUnet* u, float* avg_ms, float* marker_ms, int* launches, double* alg_bytes);
 
 /* Measured ceilings of the device: `iters` back-to-back launches timed with HIP events on `stream`.
  * dmn_bench_stream: mode 0 copies `bytes` from src to dst (HBM traffic 2 x bytes per launch), mode 1 only reads src
@@ -226,6 +228,17 @@ int dmn_fill_normal(float* x, int B, int per, uint64_t seed, uint32_t step, int6
 int dmn_test_linattn(int dtype, const void* x, const float* x_stats, int B, int n, int C, const float* gamma_host,
                      const float* beta_host, const float* wqkv_host, const float* wout_host, const float* bout_host,
                      void* y, float* y_stats, int* slices_out, void* scratch, size_t scratch_bytes, void* stream);
+/* Softmax attention core (parts/mha.py:21-28: scale, q k^T, row maximum, softmax, attn v) on qkv [B][n][3 * heads * 32]
+ * (channels q | k | v, each head-major) -> out [B][n][heads * 32], both in the internal dtype. 64 <= n <= 256 with
+ * n % 64 == 0 runs on the matrix cores, other sizes on the vector units. */
+int dmn_test_attention(int dtype, const void* qkv, void* out, int B, int n, int heads, void* stream);
+
+/* Diagnosis: after every launch of a forward, a checksum of the whole workspace goes to slot k of a device array. */
+int dmn_test_unet_trace(DmnUnet* u, unsigned long long* slots, int max_slots);
+int dmn_test_unet_trace_count(const DmnUnet* u);
+int dmn_test_unet_trace_poison(DmnUnet* u, unsigned pattern);   /* fill every CU's LDS with pattern before each launch; 0: off */
+int dmn_test_unet_trace_stop(DmnUnet* u, int k);   /* following forwards end after launch k; -1: run all */
+const char* dmn_test_unet_trace_name(const DmnUnet* u, int k);
 /* Tuning aid: every later convolution / fused linear-attention launch writes per-workgroup phase timestamps (int64,
  * 8 per workgroup; the second linear-attention kernel writes at workgroup offset 65536) to `dev`, device memory of
  * at least 2 * 65536 * 8 int64; NULL switches it off. */

@@ -239,3 +239,26 @@ def test_fused_linear_attention_matches_oracle(dtype, n_side, cch):
         assert torch.allclose(st.double(), want, rtol=1e-4, atol=1e-2)
     else:   # statistics are taken from the fp32 values before rounding to bf16
         assert torch.allclose(st.double(), want, rtol=3e-2, atol=1.0)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("n", [16, 48, 64, 128, 192, 256, 320])
+def test_softmax_attention_core_matches_torch(dtype, n):
+    """Attention core (parts/mha.py:21-28) on [B][n][384]: the matrix-core kernel (n = 64, 128, 192, 256) and the vector
+    kernel (other n) against fp32 torch. Large logits on purpose (a row maximum far from 0 must not overflow)."""
+    N = _N()
+    B, heads, d = 3, 4, 32
+    qkv = rnd((B, n, 3 * heads * d), 31 + n, 1.5)
+    qkv[0, :, :heads * d] *= 3.0                      # sharper soft-max rows in image 0
+    q, k, v = (t.reshape(B, n, heads, d).permute(0, 2, 1, 3) for t in qkv.chunk(3, dim=2))
+    if dtype == 1:
+        q, k, v = (t.to(torch.bfloat16).float() for t in (q, k, v))
+    sim = torch.einsum("bhid,bhjd->bhij", q * d ** -0.5, k)
+    attn = (sim - sim.amax(dim=-1, keepdim=True)).softmax(dim=-1)
+    ref = torch.einsum("bhij,bhjd->bhid", attn, v).permute(0, 2, 1, 3).reshape(B, n, heads * d)
+    dev = qkv.cuda().to(torch.bfloat16 if dtype == 1 else torch.float32).contiguous()
+    out = torch.full((B, n, heads * d), float("nan"), device="cuda", dtype=dev.dtype)
+    N.check(N.lib().dmn_test_attention(dtype, dev.data_ptr(), out.data_ptr(), B, n, heads, None))
+    torch.cuda.synchronize()
+    err = float((out.float().cpu() - ref).abs().max())
+    assert err <= (5e-5 if dtype == 0 else 3e-2), (dtype, n, err)   # outputs reach |7|: 1e-5 relative in f32

@@ -567,6 +567,49 @@ def test_sampling_is_bit_identical_across_batch_splits_at_the_bench_shape(dtype,
         assert torch.equal(torch.cat(parts), full), (dtype, lv, per)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_forward_is_bit_identical_beside_a_foreign_stream(dtype):
+    """A network evaluation must not change when kernels of another stream share the CUs. (Built with packed-FP32
+    instructions, the bf16 kernels lost contributions in lanes 48..63 of a wave in that situation: about 40 % of the
+    evaluations below differed; the build switches those instructions off.) A second host thread keeps a memory-bound
+    elementwise kernel stream busy while the forward runs 60 times on its own stream."""
+    import threading
+    u = build_unet64(dtype)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(32, 3, 64, 64, device="cuda", generator=g)
+    t = torch.full((32,), 500, device="cuda", dtype=torch.long)
+    ref = u(x, t).clone()
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    stop = threading.Event()
+    bad, batches = [], [0]
+
+    def forwards():
+        with torch.cuda.stream(streams[0]):
+            for i in range(60):
+                if not torch.equal(u(x, t), ref):
+                    bad.append(i)
+        stop.set()
+
+    def foreign():
+        with torch.cuda.stream(streams[1]):
+            big = torch.zeros(16 << 20, device="cuda")
+            while not stop.is_set():
+                for _ in range(20):
+                    big.add_(1.0)
+                batches[0] += 1
+                streams[1].synchronize()
+
+    th = [threading.Thread(target=forwards), threading.Thread(target=foreign)]
+    for h in th:
+        h.start()
+    for h in th:
+        h.join(timeout=100)
+    torch.cuda.synchronize()
+    assert batches[0] > 10, "the foreign stream did not run beside the forwards"
+    assert not bad, f"forwards {bad} differ from the forward run alone"
+
+
 def test_plan_batch_zero_plans_for_the_call_and_still_matches_oracle():
     """set_plan_batch(0): launch geometry chosen for the batch of each call (the small-batch tile and slice choices);
     same parity bar as the default."""

@@ -47,7 +47,7 @@ def distinct_streams(n):
     return out
 
 
-def run(nsplit):
+def run(nsplit, skew_us=0.0):
     B = 64 // nsplit
     nets = [build() for _ in range(nsplit)]
     gds = [GaussianDiffusion(timesteps=T, schedule_name="cosine") for _ in range(nsplit)]
@@ -56,6 +56,8 @@ def run(nsplit):
 
     def chain(i):
         with torch.cuda.stream(streams[i]):
+            if skew_us and i:   # delay chain i by i * skew_us on the device, so the chains run out of phase
+                torch.cuda._sleep(int(i * skew_us * 1e-6 * 2.0e9))
             outs[i] = gds[i].p_sample_loop(nets[i], (B, 3, 64, 64), device=dev, seed=7, image_offset=i * B,
                                            return_device_tensor=True)
 
@@ -78,11 +80,15 @@ def run(nsplit):
     t0 = time.perf_counter()
     once()
     el = time.perf_counter() - t0
-    print(f"{nsplit} x B={B}: {el * 1e3 / T:.3f} ms per step for 64 images ({64 / (el * 1000 / T):.1f} img/s at 1000 steps)", flush=True)
+    print(f"{nsplit} x B={B} skew {skew_us:.0f} us: {el * 1e3 / T:.3f} ms per step for 64 images ({64 / (el * 1000 / T):.1f} img/s at 1000 steps)", flush=True)
     return torch.cat(outs)
 
 
 a = run(1)
 b = run(2)
+for sk in (100.0, 200.0, 300.0, 400.0):
+    b2 = run(2, sk)
 c = run(4)
-print("max |1x - 2x| =", float((a - b).abs().max()), " max |1x - 4x| =", float((a - c).abs().max()))
+c2 = run(4, 200.0)
+print("max |1x - 2x| =", float((a - b).abs().max()), " max |1x - 2x skewed| =", float((a - b2).abs().max()),
+      " max |1x - 4x| =", float((a - c).abs().max()))

@@ -1,0 +1,35 @@
+"""Device time of one denoising step of the headline configuration (64x64, 64 images, bf16), from HIP events around a
+graph-replayed chain: python tools/step_time.py [--steps 300] [--reps 3] [--lv] [--size 64] [--batch 64]"""
+import argparse
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+from diffusion_model_nemo_amd import _native as N  # noqa: E402
+import os as _os
+from diffusion_model_nemo_amd import _native as _N
+if _os.environ.get("DMN_LIB_VARIANT"):
+    _N.LIB_PATH = _N.LIB_PATH.replace("libdmn_hip.so", f"libdmn_hip_{_os.environ['DMN_LIB_VARIANT']}.so")
+from diffusion_model_nemo_amd.modules import GaussianDiffusion, LearnedGaussianDiffusion, Unet  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--steps", type=int, default=300)
+ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--lv", action="store_true")
+ap.add_argument("--size", type=int, default=64)
+ap.add_argument("--batch", type=int, default=64)
+ap.add_argument("--tag", default="")
+a = ap.parse_args()
+dev = torch.device("cuda", 0)
+torch.manual_seed(1234)
+u = Unet(input_dim=a.size, dim=32, dim_mults=[1, 2, 4, 8], channels=3, resnet_block_groups=8, use_convnext=False, dropout=0.0,
+         learned_variance=a.lv, compute_dtype="bf16").to(dev).eval()
+gd = (LearnedGaussianDiffusion if a.lv else GaussianDiffusion)(timesteps=a.steps, schedule_name="cosine")
+ms = []
+for r in range(a.reps + 1):
+    x = gd.p_sample_loop(u, (a.batch, 3, a.size, a.size), device=dev, seed=3, keep="last", return_device_tensor=True)
+    torch.cuda.synchronize()
+    ms.append(N.loop_last_ms(u.native_handle()) / a.steps * 1e3)
+assert torch.isfinite(x).all()
+print(f"STEP_US {a.tag} min {min(ms[1:]):.1f} all {' '.join(f'{m:.1f}' for m in ms[1:])}", flush=True)
