@@ -123,25 +123,57 @@ static int carve(const DmnUnet* u, int B, int H, int W, void* ws, size_t ws_byte
     return DMN_OK;
 }
 
+// Chains a DDPM loop over B images runs as: two half batches when the handle allows it and the halves are big enough
+// to be worth a launch chain of their own.
+static int ddpm_chains(const DmnUnet* u, int B) { return (u->sample_chains == 2 && B >= 16 && B % 2 == 0) ? 2 : 1; }
+
+extern "C" int dmn_ddpm_loop_chains(const DmnUnet* u, int B) { return u ? ddpm_chains(u, B) : 0; }
+
+extern "C" int dmn_unet_set_sample_chains(DmnUnet* u, int chains, int skew_us) {
+    DMN_REQUIRE(u && (chains == 1 || chains == 2) && skew_us >= 0 && skew_us <= 5000, DMN_ERR_INVALID,
+                "dmn_unet_set_sample_chains: chains must be 1 or 2, skew 0..5000 us");
+    u->sample_chains = chains;
+    u->sample_skew_us = skew_us;
+    return DMN_OK;
+}
+
 extern "C" int dmn_sample_workspace_bytes(const DmnUnet* u, int B, int H, int W, size_t* bytes) {
     DMN_REQUIRE(u && bytes, DMN_ERR_INVALID, "dmn_sample_workspace_bytes: null argument");
     LoopBufs lb;
-    return carve(u, B, H, W, nullptr, 0, lb, bytes);
+    int rc = carve(u, B, H, W, nullptr, 0, lb, bytes);
+    if (rc) return rc;
+    if (ddpm_chains(u, B) == 2) {   // each chain has a control block, buffers and arena of its own
+        size_t half = 0;
+        if ((rc = carve(u, B / 2, H, W, nullptr, 0, lb, &half))) return rc;
+        if (2 * align256(half) > *bytes) *bytes = 2 * align256(half);
+    }
+    return DMN_OK;
 }
 
-// Runs `body` nsteps times; when allowed, captures it once into a graph (cached on the handle) and replays it.
+// Runs `body(chain, stream)` nsteps times per chain; when allowed, captures one step per chain into a graph (cached on
+// the handle) and replays it. Two chains run on the caller's stream and on a stream of the handle, forked and joined
+// with events, the second chain `sample_skew_us` behind the first.
 template <typename Body>
-static int run_loop_inner(DmnUnet* u, const SampleKey& key, int nsteps, hipStream_t s, int use_graph, Body body);
+static int run_loop_inner(DmnUnet* u, const SampleKey& key, int nsteps, hipStream_t s, int use_graph, int nchains, Body body);
+
+static int ensure_side_stream(DmnUnet* u) {
+    if (!u->side_stream) {
+        DMN_HIP_CHECK(hipStreamCreateWithFlags(&u->side_stream, hipStreamNonBlocking));
+        DMN_HIP_CHECK(hipEventCreateWithFlags(&u->ev_fork, hipEventDisableTiming));
+        DMN_HIP_CHECK(hipEventCreateWithFlags(&u->ev_join, hipEventDisableTiming));
+    }
+    return DMN_OK;
+}
 
 template <typename Body>
-static int run_loop(DmnUnet* u, const SampleKey& key, int nsteps, hipStream_t s, int use_graph, Body body) {
+static int run_loop(DmnUnet* u, const SampleKey& key, int nsteps, hipStream_t s, int use_graph, int nchains, Body body) {
     if (!u->ev_start) {
         DMN_HIP_CHECK(hipEventCreate(&u->ev_start));
         DMN_HIP_CHECK(hipEventCreate(&u->ev_stop));
     }
     u->ev_valid = false;
     DMN_HIP_CHECK(hipEventRecord(u->ev_start, s));
-    int rc = run_loop_inner(u, key, nsteps, s, use_graph, body);
+    int rc = run_loop_inner(u, key, nsteps, s, use_graph, nchains, body);
     if (rc) return rc;
     DMN_HIP_CHECK(hipEventRecord(u->ev_stop, s));
     u->ev_valid = true;
@@ -149,33 +181,50 @@ static int run_loop(DmnUnet* u, const SampleKey& key, int nsteps, hipStream_t s,
 }
 
 template <typename Body>
-static int run_loop_inner(DmnUnet* u, const SampleKey& key, int nsteps, hipStream_t s, int use_graph, Body body) {
-    if (!use_graph || s == nullptr) {
-        for (int i = 0; i < nsteps; ++i) {
-            int rc = body();
-            if (rc) return rc;
-        }
-        return DMN_OK;
+static int run_loop_inner(DmnUnet* u, const SampleKey& key, int nsteps, hipStream_t s, int use_graph, int nchains, Body body) {
+    int rc;
+    hipStream_t cs[2] = {s, s};
+    if (nchains == 2) {
+        if ((rc = ensure_side_stream(u))) return rc;
+        cs[1] = u->side_stream;
     }
-    if (!(u->graph_exec && u->graph_key == key)) {
-        if (u->graph_exec) {
-            (void)hipGraphExecDestroy(u->graph_exec);
-            u->graph_exec = nullptr;
+    const bool graph = use_graph && s != nullptr;
+    if (graph && !(u->graph_exec && u->graph_key == key)) {
+        hipGraphExec_t* slot[2] = {&u->graph_exec, &u->graph_exec2};
+        for (int c = 0; c < 2; ++c)
+            if (*slot[c]) {
+                (void)hipGraphExecDestroy(*slot[c]);
+                *slot[c] = nullptr;
+            }
+        for (int c = 0; c < nchains; ++c) {   // both steps are captured on the caller's stream; a graph runs on any stream
+            hipGraph_t g = nullptr;
+            DMN_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+            rc = body(c, s);
+            hipError_t e = hipStreamEndCapture(s, &g);
+            if (rc) {
+                if (g) (void)hipGraphDestroy(g);
+                return rc;
+            }
+            DMN_HIP_CHECK(e);
+            DMN_HIP_CHECK(hipGraphInstantiate(slot[c], g, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(g);
         }
-        hipGraph_t graph = nullptr;
-        DMN_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
-        int rc = body();
-        hipError_t e = hipStreamEndCapture(s, &graph);
-        if (rc) {
-            if (graph) (void)hipGraphDestroy(graph);
-            return rc;
-        }
-        DMN_HIP_CHECK(e);
-        DMN_HIP_CHECK(hipGraphInstantiate(&u->graph_exec, graph, nullptr, nullptr, 0));
-        (void)hipGraphDestroy(graph);
         u->graph_key = key;
     }
-    for (int i = 0; i < nsteps; ++i) DMN_HIP_CHECK(hipGraphLaunch(u->graph_exec, s));
+    if (nchains == 2) {   // the side stream starts behind everything queued on the caller's stream so far
+        DMN_HIP_CHECK(hipEventRecord(u->ev_fork, s));
+        DMN_HIP_CHECK(hipStreamWaitEvent(u->side_stream, u->ev_fork, 0));
+        if (u->sample_skew_us > 0 && (rc = launch_delay(u->sample_skew_us, u->side_stream))) return rc;
+    }
+    for (int i = 0; i < nsteps; ++i)
+        for (int c = 0; c < nchains; ++c) {
+            if (graph) DMN_HIP_CHECK(hipGraphLaunch(c ? u->graph_exec2 : u->graph_exec, cs[c]));
+            else if ((rc = body(c, cs[c]))) return rc;
+        }
+    if (nchains == 2) {
+        DMN_HIP_CHECK(hipEventRecord(u->ev_join, u->side_stream));
+        DMN_HIP_CHECK(hipStreamWaitEvent(s, u->ev_join, 0));
+    }
     return DMN_OK;
 }
 
@@ -187,31 +236,54 @@ extern "C" int dmn_ddpm_sample_loop(DmnUnet* u, const float* table, int nsteps, 
     DMN_REQUIRE(u->cfg.out_dim == u->cfg.channels * (learned_variance ? 2 : 1), DMN_ERR_INVALID,
                 "network emits %d channels, sampler expects %d", u->cfg.out_dim, u->cfg.channels * (learned_variance ? 2 : 1));
     hipStream_t s = (hipStream_t)stream;
-    LoopBufs lb;
-    int rc = carve(u, B, H, W, workspace, workspace_bytes, lb, nullptr);
-    if (rc) return rc;
     const int C = u->cfg.channels;
-    DMN_HIP_CHECK(hipMemsetAsync(lb.step_idx, 0, 256, s));
+    const int nchains = s ? ddpm_chains(u, B) : 1;   // the legacy default stream synchronises with every other stream
+    const int Bc = B / nchains;
+    LoopBufs lb[2];
+    int rc;
+    size_t per_chain = 0;
+    if (nchains == 2) {
+        if ((rc = carve(u, Bc, H, W, nullptr, 0, lb[0], &per_chain))) return rc;
+        per_chain = align256(per_chain);
+        DMN_REQUIRE(workspace_bytes >= 2 * per_chain, DMN_ERR_WORKSPACE, "sampling workspace too small: %zu < %zu",
+                    workspace_bytes, 2 * per_chain);
+    } else {
+        per_chain = workspace_bytes;
+    }
+    for (int c = 0; c < nchains; ++c) {
+        if ((rc = carve(u, Bc, H, W, (char*)workspace + c * per_chain, per_chain, lb[c], nullptr))) return rc;
+        DMN_HIP_CHECK(hipMemsetAsync(lb[c].step_idx, 0, 256, s));
+    }
     if (draw_prior && (rc = launch_prior(x, B, C * H * W, seed, (unsigned)nsteps, img_offset, 1.0f, s))) return rc;
-    SampleKey key = {x, table, workspace, keep, nullptr, 1, B, H, W, learned_variance | (pred_x0 << 1), nsteps, seed, img_offset, 0.f, u->labels};
-    auto body = [&]() -> int {
-        int r = unet_forward_impl(u, x, nullptr, 1, table, lb.step_idx, lb.net, B, H, W, lb.arena, lb.arena_bytes, s, false, nullptr);
+    SampleKey key = {x, table, workspace, keep, nullptr, 1 | (nchains << 8), B, H, W, learned_variance | (pred_x0 << 1), nsteps, seed,
+                     img_offset, 0.f, u->labels};
+    const size_t img = (size_t)C * H * W;
+    auto body = [&](int c, hipStream_t cs) -> int {
+        const int b0 = c * Bc;   // first image of the chain
+        float* xc = x + b0 * img;
+        u->label_offset = b0;
+        u->chain_id = c;
+        int r = unet_forward_impl(u, xc, nullptr, 1, table, lb[c].step_idx, lb[c].net, Bc, H, W, lb[c].arena, lb[c].arena_bytes, cs,
+                                  false, nullptr);
+        u->label_offset = 0;
+        u->chain_id = 0;
         if (r) return r;
         // The update reads the copy of the counter that the network's first kernel made and writes the next value
         // to the counter itself: no launch of its own for the increment.
         // (A network without time embedding has no kernel that makes the copy: separate increment then.)
         const bool handoff = u->cfg.with_time_emb != 0;
         DdpmStepArgs a;
-        a.c = step_common(table, handoff ? lb.step_idx + kStepCopyOffset : lb.step_idx, 0, x, lb.net, nullptr, x, B, C, H * W, seed,
-                          img_offset, keep);
-        a.step_next = handoff ? lb.step_idx : nullptr;
+        a.c = step_common(table, handoff ? lb[c].step_idx + kStepCopyOffset : lb[c].step_idx, 0, xc, lb[c].net, nullptr, xc, Bc, C,
+                          H * W, seed, img_offset + b0, keep ? keep + b0 * img : nullptr);
+        a.c.keep_stride = (long long)B * C * H * W;   // kept images of all chains share one [n_kept][B] buffer
+        a.step_next = handoff ? lb[c].step_idx : nullptr;
         a.learned_variance = learned_variance;
         a.pred_x0 = pred_x0 & 1;
         a.ddim = (pred_x0 >> 1) & 1;
-        if ((r = launch_ddpm_step(a, s))) return r;
-        return handoff ? DMN_OK : launch_advance(lb.step_idx, s);
+        if ((r = launch_ddpm_step(a, cs))) return r;
+        return handoff ? DMN_OK : launch_advance(lb[c].step_idx, cs);
     };
-    return run_loop(u, key, nsteps, s, use_graph, body);
+    return run_loop(u, key, nsteps, s, use_graph, nchains, body);
 }
 
 extern "C" int dmn_pc_sample_loop(DmnUnet* u, const float* table, int nsteps, float* x, int B, int H, int W, int predictor,
@@ -260,7 +332,7 @@ extern "C" int dmn_pc_sample_loop(DmnUnet* u, const float* table, int nsteps, fl
         }
         return launch_advance(lb.step_idx, s);
     };
-    return run_loop(u, key, nsteps, s, use_graph, body);
+    return run_loop(u, key, nsteps, s, use_graph, 1, [&](int, hipStream_t) { return body(); });
 }
 
 extern "C" int dmn_bpd_loop(DmnUnet* u, const float* table, int nsteps, const float* x0, int B, int H, int W,
@@ -296,7 +368,7 @@ extern "C" int dmn_bpd_loop(DmnUnet* u, const float* table, int nsteps, const fl
         if ((r = launch_bpd_term(a, s))) return r;
         return launch_advance(lb.step_idx, s);
     };
-    return run_loop(u, key, nsteps, s, use_graph, body);
+    return run_loop(u, key, nsteps, s, use_graph, 1, [&](int, hipStream_t) { return body(); });
 }
 
 extern "C" int dmn_loop_last_ms(DmnUnet* u, float* ms) {

@@ -716,7 +716,7 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
         DMN_REQUIRE(cpg >= c.bn ? cpg % c.bn == 0 : c.bn % cpg == 0, DMN_ERR_INVALID, "conv: group size %d vs tile %d", cpg, c.bn);
         a.epi.slots = conv_epi_slots(a);
     }
-    a.dbg = g_conv_dbg;
+    if (!a.dbg) a.dbg = g_conv_dbg;
     a.cg = pick_cg(a, c);
     const int upp = a.cg / (a.dtype == DMN_F32 ? 4 : 8);
     DMN_REQUIRE(upp <= 256 && (upp & (upp - 1)) == 0, DMN_ERR_INVALID,

@@ -426,7 +426,42 @@ __global__ void __launch_bounds__(256) lds_poison_kernel(unsigned pattern, unsig
     if (sink && w[threadIdx.x] != pattern) *sink = 1;   // keeps the stores alive
 }
 
+// span of one launch from the stamps its workgroups left ([wg][8]: slot 0 clock at start, slot 5 clock at end; unused
+// entries are zero): acc[0] += latest end - earliest start, acc[1] += 1; the stamps are cleared for the next launch.
+__global__ void __launch_bounds__(256) stamp_span_kernel(long long* stamps, int wgs, unsigned long long* acc) {
+    __shared__ long long sMin[256], sMax[256];
+    long long lo = 0x7fffffffffffffffll, hi = 0;
+    for (int i = threadIdx.x; i < wgs; i += 256) {
+        const long long b = stamps[(size_t)i * 8], e = stamps[(size_t)i * 8 + 5];
+        if (b && e) {
+            lo = b < lo ? b : lo;
+            hi = e > hi ? e : hi;
+        }
+        stamps[(size_t)i * 8] = 0;
+        stamps[(size_t)i * 8 + 5] = 0;
+    }
+    sMin[threadIdx.x] = lo;
+    sMax[threadIdx.x] = hi;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 256; ++i) {
+            lo = sMin[i] < lo ? sMin[i] : lo;
+            hi = sMax[i] > hi ? sMax[i] : hi;
+        }
+        if (hi > lo) {
+            acc[0] += (unsigned long long)(hi - lo);
+            acc[1] += 1;
+        }
+    }
+}
+
 }  // namespace
+
+int launch_stamp_span(long long* stamps, int wgs, unsigned long long* acc, hipStream_t s) {
+    hipLaunchKernelGGL(stamp_span_kernel, dim3(1), dim3(256), 0, s, stamps, wgs, acc);
+    DMN_HIP_CHECK(hipGetLastError());
+    return DMN_OK;
+}
 
 int launch_lds_poison(unsigned pattern, hipStream_t s) {
     static bool attr = false;

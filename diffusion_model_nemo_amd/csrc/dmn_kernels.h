@@ -179,3 +179,5 @@ int launch_attention(AttnArgs& a, hipStream_t s);
 int launch_checksum(const void* p, size_t bytes, unsigned long long* slot, hipStream_t s);
 // overwrites the LDS of every CU with `pattern` (diagnosis of reads of LDS a kernel did not write)
 int launch_lds_poison(unsigned pattern, hipStream_t s);
+// adds the span (latest end - earliest start) of the per-workgroup stamps of one launch to acc[0], 1 to acc[1]
+int launch_stamp_span(long long* stamps, int wgs, unsigned long long* acc, hipStream_t s);

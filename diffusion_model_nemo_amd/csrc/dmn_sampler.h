@@ -56,6 +56,7 @@ int langevin_slots(int per);
 int launch_prior(float* x, int B, int per, unsigned long long seed, unsigned pstep, long long img_offset, float scale,
                  hipStream_t s);
 int launch_advance(int* step_idx, hipStream_t s);
+int launch_delay(int us, hipStream_t s);   // holds the stream for `us` microseconds
 
 // Bits-per-dimension evaluation (models/abstract_diffusion_model.py:137-197), one timestep per table row.
 struct BpdArgs {

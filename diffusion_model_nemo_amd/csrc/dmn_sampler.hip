@@ -360,6 +360,20 @@ int launch_advance(int* step_idx, hipStream_t s) {
     return DMN_OK;
 }
 
+// One wave that holds its stream for `us` microseconds of the 100 MHz wall clock (at most 5 ms; the loop also ends after
+// a fixed number of sleeps, whatever the clock does).
+__global__ void delay_kernel(unsigned ticks) {
+    const unsigned long long t0 = wall_clock64();
+    for (int i = 0; i < 200000 && wall_clock64() - t0 < ticks; ++i) __builtin_amdgcn_s_sleep(32);
+}
+int launch_delay(int us, hipStream_t s) {
+    if (us <= 0) return DMN_OK;
+    if (us > 5000) us = 5000;
+    hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, s, (unsigned)us * 100u);
+    DMN_HIP_CHECK(hipGetLastError());
+    return DMN_OK;
+}
+
 // ---- Langevin corrector step for callers that cannot allocate -------------------------------------------------------
 // Same kernels as dmn_sde_corrector_step; the per-sample partial sums live in a device array of the library instead
 // of a caller's workspace. `scratch` is a host-side stand-in for the array: its device address is resolved once per

@@ -311,7 +311,8 @@ static Act do_conv(Fwd& f, const PackedConv& pc, const Act& in0, const Act* in1,
     if (f.ok() && !f.dry) {
         // measurement hook: events around the dominant launch as it runs inside the step (block2.proj of downs.0.0)
         DmnUnet* u = f.u;
-        bool probe = u->probe_on && &pc == &u->downs[0].rb[0].c2 && u->probe_n < kProbePairs;
+        const bool target = u->probe_on && &pc == &u->downs[0].rb[0].c2;
+        bool probe = target && u->probe_on == 1 && u->probe_n < kProbePairs;
         if (probe) {   // never inside a stream capture: a captured event record carries no time
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
             probe = hipStreamIsCapturing(f.s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
@@ -320,14 +321,25 @@ static Act do_conv(Fwd& f, const PackedConv& pc, const Act& in0, const Act* in1,
             (void)hipEventRecord(u->probe_ev[3 * u->probe_n], f.s);
             (void)hipEventRecord(u->probe_ev[3 * u->probe_n + 1], f.s);
         }
+        // device-clock form (also inside captured steps): every workgroup of this launch stamps its start and end
+        const bool clocked = target && u->probe_on == 2 && u->probe_stamps;
+        long long* stamps = clocked ? u->probe_stamps + (size_t)u->chain_id * kProbeMaxWgs * 8 : nullptr;   // per launch chain
+        if (clocked) a.dbg = stamps;
         char what[160];
         snprintf(what, sizeof(what), "conv kind %d %d->%d at %dx%d%s%s%s out@%zu stats@%zu", pc.kind, pc.Cin, pc.Cout, in0.H,
                  in0.W, pro ? (pro->silu ? " norm+silu" : " norm") : "", res ? " +res" : "", shortcut ? " +shortcut" : "",
                  (size_t)((char*)a.out - f.ar.base), out.stats ? (size_t)((char*)out.stats - f.ar.base) : (size_t)0);
         f.run(launch_conv(a, f.s), what);
+        if (clocked) {
+            const int tiles = ((a.Ho + 15) / 16) * ((a.Wo + 15) / 16);   // upper bound of the launch's workgroups (8x8 tiles: 4x)
+            int wgs = tiles * 4 * (a.Cout / 32) * f.B * a.nphase;
+            if (wgs > kProbeMaxWgs) wgs = kProbeMaxWgs;
+            f.run(launch_stamp_span(stamps, wgs, u->probe_acc + 2 * u->chain_id, f.s), "probe: span of the stamps");
+        }
+        if (probe || clocked)
+            u->probe_bytes = (double)f.B * in0.H * in0.W * (pc.Cin + pc.Cout) * f.esz() + (double)pc.Cin * pc.Cout * pc.ntaps * f.esz();
         if (probe) {
             (void)hipEventRecord(u->probe_ev[3 * u->probe_n + 2], f.s);
-            u->probe_bytes = (double)f.B * in0.H * in0.W * (pc.Cin + pc.Cout) * f.esz() + (double)pc.Cin * pc.Cout * pc.ntaps * f.esz();
             ++u->probe_n;
         }
     }
@@ -580,7 +592,7 @@ int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float,
         ia.B = B; ia.Cin = c.channels; ia.H = H; ia.W = W; ia.Cout = c.dim;
         if (c.num_classes > 0) {
             ia.class_embed = u->class_embed;
-            ia.labels = u->labels;
+            ia.labels = u->labels ? u->labels + u->label_offset : nullptr;
             ia.num_classes = c.num_classes;
         }
         if (f.ok() && !dry) {
@@ -762,18 +774,46 @@ extern "C" int dmn_bench_dominant_kernel(DmnUnet* u, int B, int H, int W, int it
 // directly around the kernel. Three markers per probed launch: the distance of the first two (nothing between them) is
 // what a marker packet itself costs, the distance of the last two is the kernel plus one marker.
 extern "C" int dmn_unet_probe_dominant(DmnUnet* u, int enable) {
-    DMN_REQUIRE(u, DMN_ERR_INVALID, "dmn_unet_probe_dominant: null handle");
-    if (enable && u->probe_ev.empty()) {
+    DMN_REQUIRE(u && enable >= 0 && enable <= 2, DMN_ERR_INVALID, "dmn_unet_probe_dominant: handle / mode");
+    if (enable == 1 && u->probe_ev.empty()) {
         u->probe_ev.resize(3 * kProbePairs, nullptr);
         for (auto& e : u->probe_ev) DMN_HIP_CHECK(hipEventCreate(&e));
     }
-    u->probe_on = enable != 0;
-    if (enable) u->probe_n = 0;
+    if (enable == 2) {
+        // Device-clock form: the workgroups of the probed launch stamp the constant 100 MHz clock when they start and
+        // when they end; a one-workgroup kernel behind the launch adds (latest end - earliest start) to a running sum.
+        // Works in captured steps too, so it times the launch where the timed chains run it.
+        if (!u->probe_stamps) {
+            DMN_HIP_CHECK(hipMalloc(&u->probe_stamps, (size_t)2 * kProbeMaxWgs * 8 * sizeof(long long)));
+            DMN_HIP_CHECK(hipMalloc(&u->probe_acc, 4 * sizeof(unsigned long long)));
+        }
+        DMN_HIP_CHECK(hipMemset(u->probe_stamps, 0, (size_t)2 * kProbeMaxWgs * 8 * sizeof(long long)));
+        DMN_HIP_CHECK(hipMemset(u->probe_acc, 0, 4 * sizeof(unsigned long long)));
+    }
+    if ((u->probe_on == 2) != (enable == 2) && u->graph_exec) {   // captured steps hold (or lack) the stamping launch
+        DMN_HIP_CHECK(hipDeviceSynchronize());
+        (void)hipGraphExecDestroy(u->graph_exec);
+        if (u->graph_exec2) (void)hipGraphExecDestroy(u->graph_exec2);
+        u->graph_exec = u->graph_exec2 = nullptr;
+    }
+    u->probe_on = enable;
+    if (enable == 1) u->probe_n = 0;
     return DMN_OK;
 }
 
 extern "C" int dmn_unet_probe_result(DmnUnet* u, float* avg_ms, float* marker_ms, int* launches, double* alg_bytes) {
     DMN_REQUIRE(u && avg_ms && marker_ms && launches, DMN_ERR_INVALID, "dmn_unet_probe_result: null argument");
+    if (u->probe_acc && u->probe_on != 1 && u->probe_n == 0) {   // device-clock form
+        unsigned long long acc[4];
+        DMN_HIP_CHECK(hipDeviceSynchronize());
+        DMN_HIP_CHECK(hipMemcpy(acc, u->probe_acc, sizeof(acc), hipMemcpyDeviceToHost));
+        DMN_REQUIRE(acc[1] + acc[3] > 0, DMN_ERR_INVALID, "dmn_unet_probe_result: no probed launch recorded");
+        *avg_ms = (float)((double)(acc[0] + acc[2]) / (double)(acc[1] + acc[3]) * 1e-5);   // ticks of 10 ns, both chains
+        *marker_ms = 0.f;
+        *launches = (int)(acc[1] + acc[3]);
+        if (alg_bytes) *alg_bytes = u->probe_bytes;
+        return DMN_OK;
+    }
     DMN_REQUIRE(u->probe_n > 0, DMN_ERR_INVALID, "dmn_unet_probe_result: no probed launch recorded");
     double sum = 0.0, empty = 0.0;
     for (int i = 0; i < u->probe_n; ++i) {
@@ -787,6 +827,7 @@ extern "C" int dmn_unet_probe_result(DmnUnet* u, float* avg_ms, float* marker_ms
     *avg_ms = (float)(sum / u->probe_n);
     *marker_ms = (float)(empty / u->probe_n);
     *launches = u->probe_n;
+    u->probe_n = 0;
     if (alg_bytes) *alg_bytes = u->probe_bytes;
     return DMN_OK;
 }
@@ -978,6 +1019,8 @@ extern "C" int dmn_unet_create(const DmnUnetCfg* cfg, DmnUnet** out) {
     DmnUnet* u = new DmnUnet();
     u->cfg = *cfg;
     if (const char* e = getenv("DMN_UNET_PATHS")) u->path_mask = atoi(e);
+    if (const char* e = getenv("DMN_SAMPLE_CHAINS")) u->sample_chains = atoi(e) == 1 ? 1 : 2;
+    if (const char* e = getenv("DMN_SAMPLE_SKEW_US")) u->sample_skew_us = atoi(e) < 0 ? 0 : (atoi(e) > 5000 ? 5000 : atoi(e));
     u->downs.resize(cfg->n_mults);
     u->ups.resize(cfg->n_mults - 1);
     *out = u;
@@ -1026,7 +1069,8 @@ extern "C" int dmn_unet_set_plan_batch(DmnUnet* u, int batch) {
     DMN_REQUIRE(u && batch >= 0, DMN_ERR_INVALID, "dmn_unet_set_plan_batch: bad argument");
     if (batch != u->plan_batch && u->graph_exec) {   // a captured step holds the old launch geometry
         (void)hipGraphExecDestroy(u->graph_exec);
-        u->graph_exec = nullptr;
+        if (u->graph_exec2) (void)hipGraphExecDestroy(u->graph_exec2);
+        u->graph_exec = u->graph_exec2 = nullptr;
     }
     u->plan_batch = batch;
     return DMN_OK;
@@ -1035,10 +1079,16 @@ extern "C" int dmn_unet_set_plan_batch(DmnUnet* u, int batch) {
 extern "C" void dmn_unet_destroy(DmnUnet* u) {
     if (!u) return;
     if (u->graph_exec) (void)hipGraphExecDestroy(u->graph_exec);
+    if (u->graph_exec2) (void)hipGraphExecDestroy(u->graph_exec2);
+    if (u->side_stream) (void)hipStreamDestroy(u->side_stream);
+    if (u->ev_fork) (void)hipEventDestroy(u->ev_fork);
+    if (u->ev_join) (void)hipEventDestroy(u->ev_join);
     if (u->ev_start) (void)hipEventDestroy(u->ev_start);
     if (u->ev_stop) (void)hipEventDestroy(u->ev_stop);
     for (auto e : u->probe_ev)
         if (e) (void)hipEventDestroy(e);
+    if (u->probe_stamps) (void)hipFree(u->probe_stamps);
+    if (u->probe_acc) (void)hipFree(u->probe_acc);
     free_weights(u);
     delete u;
 }
@@ -1049,7 +1099,8 @@ extern "C" int dmn_unet_load_weights(DmnUnet* u, const DmnTensorDesc* params, in
     free_weights(u);
     if (u->graph_exec) {
         (void)hipGraphExecDestroy(u->graph_exec);
-        u->graph_exec = nullptr;
+        if (u->graph_exec2) (void)hipGraphExecDestroy(u->graph_exec2);
+        u->graph_exec = u->graph_exec2 = nullptr;
     }
     ParamMap pm;
     for (int i = 0; i < n; ++i) pm.m[params[i].name] = &params[i];

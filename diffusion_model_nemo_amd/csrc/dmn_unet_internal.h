@@ -78,17 +78,31 @@ struct DmnUnet {
     std::vector<std::string> trace_names;
     // cached step graph of the sampling loops
     hipGraphExec_t graph_exec = nullptr;
+    hipGraphExec_t graph_exec2 = nullptr;   // second half-batch chain of a DDPM loop (see sample_chains)
     SampleKey graph_key = {};
+    // The DDPM loop runs a batch as `sample_chains` chains of half the images on two streams (the second one may be held
+    // back by `sample_skew_us`; on MI355X no skew measured best): a step is a chain of ~85 dependent launches, and a second chain fills the gaps at
+    // the launch boundaries and in the small bottleneck kernels. With the fixed planning batch every image gets the
+    // same bits as in one chain. Environment DMN_SAMPLE_CHAINS (1 or 2) / DMN_SAMPLE_SKEW_US at handle creation.
+    int sample_chains = 2;
+    int sample_skew_us = 0;
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int label_offset = 0;                   // first image of the chain that is being launched (class labels)
+    int chain_id = 0;                       // which chain is being launched (probe buffers)
     // HIP events bracketing the last sampling loop on its stream (device time of the loop)
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool ev_valid = false;
     // measurement hook: HIP event pairs around the launches of the step's dominant convolution (eager launches only)
     std::vector<hipEvent_t> probe_ev;    // 3 * kProbePairs events once enabled
     int probe_n = 0;                     // pairs recorded since the probe was switched on
-    bool probe_on = false;
+    int probe_on = 0;                    // 1: HIP events around eager launches, 2: device clock stamps (also in graphs)
+    long long* probe_stamps = nullptr;   // [2 chains][kProbeMaxWgs][8] per-workgroup stamps of the probed launch
+    unsigned long long* probe_acc = nullptr;   // per chain {sum of spans in 10 ns ticks, launches}
     double probe_bytes = 0.0;            // algorithmic bytes of one probed launch
 };
 constexpr int kProbePairs = 256;
+constexpr int kProbeMaxWgs = 16384;
 
 int pack_conv(PackedConv& pc, int dtype, const float* w, const float* bias, int Cout, int Cin, int kh, int kw, int stride,
               int pad, bool transposed);

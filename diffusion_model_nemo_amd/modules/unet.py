@@ -160,6 +160,20 @@ class Unet(nn.Module):
         self._workspace = None
         self._ws_key = None
         self._plan_batch = 64
+        self._sample_chains = None   # None: the library's default (two half-batch chains in the DDPM loop)
+
+    def set_sample_chains(self, chains: int, skew_us: int = 0):
+        """How the DDPM sampling loop runs a batch: 2 = two half-batch launch chains on two streams (default for
+        even batches of 16 images or more; per-image results are the same bits), 1 = one chain."""
+        if chains not in (1, 2):
+            raise ValueError("chains must be 1 or 2")
+        self._sample_chains = (int(chains), int(skew_us))
+        self._workspace = None
+        self._ws_key = None
+        if self._handle is not None:
+            with torch.cuda.device(self._handle_device):
+                N.check(N.lib().dmn_unet_set_sample_chains(self._handle, *self._sample_chains))
+        return self
 
     def set_plan_batch(self, batch: int):
         """Batch the launch heuristics plan for (default 64). With a fixed value the result for an image does not
@@ -231,6 +245,8 @@ class Unet(nn.Module):
                 cfg = self._cfg()
                 N.check(lib.dmn_unet_create(C.byref(cfg), C.byref(h)))
                 N.check(lib.dmn_unet_set_plan_batch(h, self._plan_batch))
+                if self._sample_chains is not None:
+                    N.check(lib.dmn_unet_set_sample_chains(h, *self._sample_chains))
                 self._handle = h
                 self._handle_device = dev
             ver = self._version()
@@ -269,7 +285,7 @@ class Unet(nn.Module):
             pass
 
     def workspace(self, B, H, W, device, sampling=False) -> torch.Tensor:
-        key = (B, H, W, str(device), sampling, self._plan_batch)
+        key = (B, H, W, str(device), sampling, self._plan_batch, self._sample_chains)
         if self._ws_key != key:
             lib = N.lib()
             n = C.c_size_t()

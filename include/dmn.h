@@ -128,6 +128,15 @@ int dmn_pc_sample_loop(DmnUnet* u, const float* table, int nsteps, float* x, int
                        int corrector, int n_corrector_steps, float snr, int denoise, int draw_prior, float prior_scale,
                        uint64_t seed, int64_t img_offset, float* keep, float* x_mean_out, void* workspace,
                        size_t workspace_bytes, void* stream, int use_graph);
+/* The DDPM loop runs a batch of B >= 16 (even) images as two half-batch launch chains on two streams (the caller's and
+ * one of the handle), which fills the gaps a single chain of ~85 dependent launches leaves; every image gets the bits
+ * it gets in one chain. No counterpart in the reference (gaussian_diffusion.py:171-189 is one Python loop).
+ * dmn_unet_set_sample_chains: chains 1 or 2 (default 2, environment DMN_SAMPLE_CHAINS), skew_us = head start of the
+ * first chain (default 0, DMN_SAMPLE_SKEW_US). dmn_ddpm_loop_chains: chains a loop over B images will use. Workspaces
+ * sized by dmn_sample_workspace_bytes hold either form. */
+int dmn_unet_set_sample_chains(DmnUnet* u, int chains, int skew_us);
+int dmn_ddpm_loop_chains(const DmnUnet* u, int B);
+
 /* AbstractDiffusionModel.calculate_bits_per_dimension (models/abstract_diffusion_model.py:137-197) for the
  * 'pred_noise' objective: for every row of `table` (BPD row layout, csrc/dmn_sampler.h; normally t = T-1 .. 0)
  * x_t = q_sample(x0, t) with generator stream 3, network evaluation, then the per-sample variational-bound term in

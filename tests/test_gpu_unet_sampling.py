@@ -567,6 +567,49 @@ def test_sampling_is_bit_identical_across_batch_splits_at_the_bench_shape(dtype,
         assert torch.equal(torch.cat(parts), full), (dtype, lv, per)
 
 
+@pytest.mark.parametrize("dtype,lv", [("bf16", False), ("bf16", True), ("fp32", False)])
+def test_two_launch_chains_give_the_bits_of_one_chain(dtype, lv):
+    """The DDPM loop runs an even batch of 16 images or more as two half-batch launch chains on two streams; final
+    images and the kept history must equal the single chain bit for bit (and the library must really be using two)."""
+    from diffusion_model_nemo_amd import _native as N
+    from diffusion_model_nemo_amd.modules import GaussianDiffusion, LearnedGaussianDiffusion
+    u = build_unet64(dtype, learned_variance=lv)
+    gd = (LearnedGaussianDiffusion if lv else GaussianDiffusion)(timesteps=10, schedule_name="cosine")
+    u.set_sample_chains(1)
+    one = gd.p_sample_loop(u, (32, 3, 64, 64), device="cuda", seed=9, keep="all", return_device_tensor=True).clone()
+    assert N.lib().dmn_ddpm_loop_chains(u.native_handle(), 32) == 1
+    u.set_sample_chains(2)
+    assert N.lib().dmn_ddpm_loop_chains(u.native_handle(), 32) == 2
+    assert N.lib().dmn_ddpm_loop_chains(u.native_handle(), 6) == 1      # too small to split
+    for rep in range(3):   # the chains overlap differently every time
+        two = gd.p_sample_loop(u, (32, 3, 64, 64), device="cuda", seed=9, keep="all", return_device_tensor=True)
+        assert two.shape == one.shape and torch.equal(two, one), (dtype, lv, rep)
+    eager = gd.p_sample_loop(u, (32, 3, 64, 64), device="cuda", seed=9, keep="all", return_device_tensor=True, use_graph=False)
+    assert torch.equal(eager, one)
+
+
+def test_two_launch_chains_keep_each_image_its_class_label():
+    """Class-conditional sampling with per-image labels: the second chain must read the labels of ITS images."""
+    import functools
+    from diffusion_model_nemo_amd.modules import GaussianDiffusion, Unet
+    sd = make_state_dict(unet_param_shapes(num_classes=10))
+    u = Unet(input_dim=32, dim=32, dim_mults=[1, 2, 4, 8], channels=3, use_convnext=False, dropout=0.0, num_classes=10,
+             compute_dtype="bf16")
+    u.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    u = u.cuda().eval()
+    labels = (torch.arange(16, device="cuda") * 7) % 10
+    gd = GaussianDiffusion(timesteps=8, schedule_name="linear")
+    fn = functools.partial(u.forward, classes=labels)
+    u.set_sample_chains(1)
+    one = gd.p_sample_loop(fn, (16, 3, 32, 32), device="cuda", seed=5, return_device_tensor=True).clone()
+    u.set_sample_chains(2)
+    two = gd.p_sample_loop(fn, (16, 3, 32, 32), device="cuda", seed=5, return_device_tensor=True)
+    assert torch.equal(one, two)
+    swapped = gd.p_sample_loop(functools.partial(u.forward, classes=labels.flip(0)), (16, 3, 32, 32), device="cuda", seed=5,
+                               return_device_tensor=True)
+    assert not torch.equal(one[8:], swapped[8:])
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "fp32"])
 def test_forward_is_bit_identical_beside_a_foreign_stream(dtype):
     """A network evaluation must not change when kernels of another stream share the CUs. (Built with packed-FP32

@@ -27,9 +27,14 @@ u = Unet(input_dim=a.size, dim=32, dim_mults=[1, 2, 4, 8], channels=3, resnet_bl
          learned_variance=a.lv, compute_dtype="bf16").to(dev).eval()
 gd = (LearnedGaussianDiffusion if a.lv else GaussianDiffusion)(timesteps=a.steps, schedule_name="cosine")
 ms = []
+host = []
 for r in range(a.reps + 1):
+    import time as _t
+    t0 = _t.perf_counter()
     x = gd.p_sample_loop(u, (a.batch, 3, a.size, a.size), device=dev, seed=3, keep="last", return_device_tensor=True)
+    host.append((_t.perf_counter() - t0) / a.steps * 1e6)
     torch.cuda.synchronize()
     ms.append(N.loop_last_ms(u.native_handle()) / a.steps * 1e3)
 assert torch.isfinite(x).all()
-print(f"STEP_US {a.tag} min {min(ms[1:]):.1f} all {' '.join(f'{m:.1f}' for m in ms[1:])}", flush=True)
+print(f"STEP_US {a.tag} min {min(ms[1:]):.1f} all {' '.join(f'{m:.1f}' for m in ms[1:])}; host time of the call per step "
+      f"{' '.join(f'{h:.0f}' for h in host[1:])} us", flush=True)
