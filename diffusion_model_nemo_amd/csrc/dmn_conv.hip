@@ -52,9 +52,11 @@ template <> struct KindTraits<DMN_K4X4S2> { static constexpr int NTAPS = 16, EXT
 template <> struct KindTraits<DMN_KT2X2> { static constexpr int NTAPS = 4, EXT = 2, S = 1, KW = 2, GK = 2; };
 
 // PRO: 0 = input used as is, 1 = GroupNorm affine, 2 = GroupNorm affine + SiLU (+ time bias) while staging,
-//      3 = the tail of the previous ResnetBlock, SiLU(GroupNorm(in0)) + pro_res (parts/convnext.py:85-86), applied
-//          while staging; the pixels of the tile proper are also written to pro_out, so the block output exists
-//          in memory for its other consumer (the next block's residual) without a launch of its own.
+//      3 = the tail of the producer applied while staging: SiLU(GroupNorm(in0)) + pro_res for a ResnetBlock
+//          (parts/convnext.py:85-86; pro.silu set) or GroupNorm(in0) + pro_res for a linear attention
+//          (parts/mha.py:41-42 + utils.py:73-74; pro.silu clear). When pro_out is given, the pixels of the tile proper
+//          are also written there, so the tensor exists in memory for its other consumers (the next block's residual,
+//          a skip connection) without a launch of its own.
 // RES: also apply a 1x1 convolution (w2, bias2 -> out2) to the same input tile -- the ResnetBlock shortcut
 // res_conv(x) beside block1.proj(x) (parts/convnext.py:76,79,86) -- sharing the staged tile; 3x3 kind only.
 template <typename T, int KIND, int TH, int TW, int BN, int WM, int WN, int PRO, bool RES>
@@ -178,6 +180,8 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
     const T* const in0p = static_cast<const T*>(a.in0);
     const T* const in1p = static_cast<const T*>(a.in1);
     const T* const resp3 = static_cast<const T*>(a.pro_res);
+    const bool pro_silu = a.pro.silu != 0;
+    const bool pro_store = PRO == 3 && a.pro_out != nullptr && blockIdx.y == 0 && ph == 0;
     auto stage_issue = [&](int cg0, int j0) {
         const int c = cg0 + part * PER;
         const bool first = c < inC0;
@@ -238,20 +242,22 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
                     for (int e = 0; e < PER; ++e) {
                         float y = v.get(e);
                         if constexpr (PRO >= 2 && sizeof(T) == 2) {
-                            y = silu_affine_fast(y, ca[e], cb[e], PRO == 2 ? ct[e] : r2.get(e));
+                            if (PRO == 2 || pro_silu) y = silu_affine_fast(y, ca[e], cb[e], PRO == 2 ? ct[e] : r2.get(e));
+                            else y = __builtin_fmaf(y, ca[e], cb[e]) + r2.get(e);
                         } else if (PRO) {
                             y = y * ca[e] + cb[e];
                             if (PRO == 2) y = silu_precise(y) + ct[e];
-                            if constexpr (PRO == 3) y = silu_precise(y) + r2.get(e);
+                            if constexpr (PRO == 3) y = (pro_silu ? silu_precise(y) : y) + r2.get(e);
                         }
                         v.set(e, y);
                     }
                     if (!in) v.v = V{};                  // padding is zero AFTER the prologue
                     if (pix < NPIX) *reinterpret_cast<V*>(sX + pix * rowB + part * 16) = v.v;
                     if constexpr (PRO == 3) {
-                        // the tile's own pixels (not the halo) of the first channel slice materialise the block output
+                        // the tile's own pixels (not the halo), staged by the first channel slice and phase, materialise
+                        // the tensor
                         const int ly = pix / IW, lx = pix - ly * IW;
-                        if (in && blockIdx.y == 0 && ly >= P.pad_y && ly < P.pad_y + TH && lx >= P.pad_x && lx < P.pad_x + TW) {
+                        if (in && pro_store && ly >= P.pad_y && ly < P.pad_y + TH * S && lx >= P.pad_x && lx < P.pad_x + TW * S) {
                             const unsigned off = (unsigned)((b * a.H + iy0 + ly) * a.W + ix0 + lx) * (unsigned)a.C0 + (unsigned)c;
                             store_stream(reinterpret_cast<V*>(static_cast<T*>(a.pro_out) + off), v.v);
                         }
@@ -602,10 +608,12 @@ template <typename T>
 int dispatch(const ConvArgs& a, const TileCfg& c, size_t lds, hipStream_t s) {
     const int pro = a.pro.stats ? (a.pro_res ? 3 : a.pro.silu ? 2 : 1) : 0;
     if (pro == 3) {
-        if (a.kind != DMN_K3X3 || a.w2 || a.C1 || !a.pro_out || !a.pro.silu || a.pro.tbias) {
-            dmn_set_error("conv: the fused block tail needs a plain single-source 3x3 convolution");
+        if (a.kind == DMN_K1X1 || a.w2 || a.C1 || a.pro.tbias) {
+            dmn_set_error("conv: the fused producer tail needs a plain single-source 3x3 or resampling convolution");
             return DMN_ERR_INVALID;
         }
+        if (a.kind == DMN_K4X4S2) return dispatch_tile<T, DMN_K4X4S2, 3>(a, c, lds, s);
+        if (a.kind == DMN_KT2X2) return dispatch_tile<T, DMN_KT2X2, 3>(a, c, lds, s);
         return dispatch_tile<T, DMN_K3X3, 3>(a, c, lds, s);
     }
     if (a.w2) {
@@ -670,6 +678,8 @@ int set_attr_all() {
     if ((rc = set_attr_kind<T, DMN_K1X1, 2>())) return rc;
     if ((rc = set_attr_kind<T, DMN_K4X4S2, 0>())) return rc;
     if ((rc = set_attr_kind<T, DMN_KT2X2, 0>())) return rc;
+    if ((rc = set_attr_kind<T, DMN_K4X4S2, 3>())) return rc;
+    if ((rc = set_attr_kind<T, DMN_KT2X2, 3>())) return rc;
     if ((rc = set_attr<T, DMN_K3X3, 16, 16, 32, 2, 2, 0, true>())) return rc;
     if ((rc = set_attr<T, DMN_K3X3, 8, 8, 32, 2, 2, 0, true>())) return rc;
     if ((rc = set_attr<T, DMN_K3X3, 8, 8, 64, 1, 4, 0, true>())) return rc;

@@ -52,8 +52,9 @@ struct ConvArgs {
     void* out;            // [B][out_H][out_W][Cout]
     int Cout;
     NormIn pro;           // normalise + activate the input while staging it (in0 only)
-    const void* pro_res;  // optional (3x3, single source): tensor added after the activation -- with `pro` this is the
-    void* pro_out;        //   previous ResnetBlock's tail; pro_out receives the resulting tensor (same shape as in0)
+    const void* pro_res;  // optional (3x3 / resampling kinds, single source): tensor added behind the normalisation [+ SiLU]
+                          //   of `pro` -- the tail of the ResnetBlock or linear attention that produced in0
+    void* pro_out;        // optional with pro_res: receives the resulting tensor (same shape as in0)
     const void* res;      // optional residual added in the epilogue, same shape as out
     NormOut epi;          // statistics of the output after bias (taken before the residual add)
     const void* w2;       // optional fused 1x1 convolution of the same input (3x3 kind, no input normalisation):

@@ -281,7 +281,8 @@ static NormIn norm_in(const Act& a, const float* gamma, const float* beta, int B
 
 // conv with optional: second source, input normalisation, residual, output statistics
 static Act do_conv(Fwd& f, const PackedConv& pc, const Act& in0, const Act* in1, const NormIn* pro, const Act* res, int epiG,
-                   const PackedConv* shortcut = nullptr, Act* shortcut_out = nullptr) {
+                   const PackedConv* shortcut = nullptr, Act* shortcut_out = nullptr, const void* pro_res = nullptr,
+                   void* pro_out = nullptr) {
     ConvArgs a;
     conv_args_from(pc, f.u->cfg.dtype, a, f.B, in0.H, in0.W);
     a.plan_B = f.planB();
@@ -292,6 +293,10 @@ static Act do_conv(Fwd& f, const PackedConv& pc, const Act& in0, const Act* in1,
         a.C1 = in1->C;
     }
     if (pro) a.pro = *pro;
+    if (pro_res) {   // the producer's tail (normalisation of `pro`, then + pro_res) is applied while staging
+        a.pro_res = pro_res;
+        a.pro_out = pro_out;
+    }
     Act out = f.new_act(pc.Cout, a.out_H, a.out_W);
     a.out = out.p;
     if (res) a.res = res->p;
@@ -428,7 +433,22 @@ static Act resblock(Fwd& f, const ResBlockW& w, Act& x, Act* x2, const float* tb
     return out;
 }
 
-static Act lin_attn_tail(Fwd& f, const AttnW& w, Act& x, Act& y) {
+// A linear attention whose closing `GroupNorm(y) + x` has not been applied: the resampling convolution that consumes it
+// applies it while staging its input (and stores the result when a skip connection needs the tensor).
+struct LazyAttn {
+    bool active = false;
+    Act y;                        // to_out output with GroupNorm(1) statistics
+    const float *og = nullptr, *ob = nullptr;
+};
+
+static Act lin_attn_tail(Fwd& f, const AttnW& w, Act& x, Act& y, LazyAttn* defer) {
+    if (defer) {
+        defer->active = true;
+        defer->y = y;
+        defer->og = w.og;
+        defer->ob = w.ob;
+        return Act();
+    }
     Act out = f.new_act(x.C, x.H, x.W);
     NormApplyArgs na;
     memset(&na, 0, sizeof(na));
@@ -447,7 +467,7 @@ static Act lin_attn_tail(Fwd& f, const AttnW& w, Act& x, Act& y) {
 }
 
 // Residual(PreNorm(dim, LinearAttention(dim))) (utils.py:68-93, parts/mha.py:44-59). x must carry GN(1) statistics.
-static Act lin_attn(Fwd& f, const AttnW& w, Act& x) {
+static Act lin_attn(Fwd& f, const AttnW& w, Act& x, LazyAttn* defer = nullptr) {
     const DmnUnetCfg& c = f.u->cfg;
     const int hidden = c.heads * c.dim_head;
     if (w.fq && !(f.u->path_mask & 2)) {
@@ -482,7 +502,7 @@ static Act lin_attn(Fwd& f, const AttnW& w, Act& x) {
         if (f.ok() && !f.dry) f.run(launch_linattn_fused(fa, f.s), what);
         f.ar.release(part);
         f.ar.release(ctxT);
-        return lin_attn_tail(f, w, x, y);
+        return lin_attn_tail(f, w, x, y, defer);
     }
     NormIn pn = norm_in(x, w.ng, w.nb, f.B, 0, nullptr, 0);
     Act qkv = do_conv(f, w.qkv, x, nullptr, &pn, nullptr, 0);
@@ -504,7 +524,7 @@ static Act lin_attn(Fwd& f, const AttnW& w, Act& x) {
     f.ar.release(part);
     Act y = do_conv(f, w.out, la, nullptr, nullptr, nullptr, 1);
     f.free_act(la);
-    return lin_attn_tail(f, w, x, y);
+    return lin_attn_tail(f, w, x, y, defer);
 }
 
 // Residual(PreNorm(dim, Attention(dim))) (parts/mha.py:16-30)
@@ -614,7 +634,24 @@ int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float,
         Act a2 = resblock(f, u->downs[i].rb[1], a1, nullptr, tb, tbs, 1, &lt, nullptr);
         f.free_act(cur);   // the block input stays alive as the deferred tail's residual
         f.free_act(a1);
-        Act a3 = lin_attn(f, u->downs[i].attn, a2);
+        // Opt-in (DMN_UNET_PATHS bit 4): below the last level the attention's tail (GroupNorm(y) + a2) is left to the
+        // downsampling convolution, and the tensor itself is only stored where a skip connection reads it. Same bits,
+        // 6 launches fewer per step, but measured SLOWER on MI355X (64x64, 2 x 32 images: 883 us per step against 863):
+        // the resampling kernels stage every input pixel 1.3x (halo) to 4x (sub-pixel phases) and now pay the tail's
+        // arithmetic and a second operand read each time, which costs more than the streaming pass it replaces.
+        const bool fold = (u->path_mask & 16) && !((u->path_mask & 64) && i > 0) && i < nlev - 1;
+        LazyAttn la;
+        Act a3 = lin_attn(f, u->downs[i].attn, a2, fold ? &la : nullptr);
+        if (fold) {
+            Act keep;
+            if (i > 0) keep = f.new_act(a2.C, a2.H, a2.W);
+            NormIn tn = norm_in(la.y, la.og, la.ob, f.B, 0, nullptr, 0);
+            cur = do_conv(f, u->downs[i].resample, la.y, nullptr, &tn, nullptr, 0, nullptr, nullptr, a2.p, i > 0 ? keep.p : nullptr);
+            f.free_act(la.y);
+            f.free_act(a2);
+            if (i > 0) skips.push_back(keep);
+            continue;
+        }
         f.free_act(a2);
         if (i < nlev - 1) {
             cur = do_conv(f, u->downs[i].resample, a3, nullptr, nullptr, nullptr, 0);
@@ -642,6 +679,15 @@ int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float,
         f.free_act(sk);
         Act a2 = resblock(f, u->ups[i].rb[1], a1, nullptr, tb, tbs, 1, &lt, nullptr);
         f.free_act(a1);
+        if ((u->path_mask & 16) && !(u->path_mask & 32)) {   // opt-in: the upsampling convolution applies the attention's tail
+            LazyAttn la;
+            lin_attn(f, u->ups[i].attn, a2, &la);
+            NormIn tn = norm_in(la.y, la.og, la.ob, f.B, 0, nullptr, 0);
+            cur = do_conv(f, u->ups[i].resample, la.y, nullptr, &tn, nullptr, 0, nullptr, nullptr, a2.p, nullptr);
+            f.free_act(la.y);
+            f.free_act(a2);
+            continue;
+        }
         Act a3 = lin_attn(f, u->ups[i].attn, a2);
         f.free_act(a2);
         cur = do_conv(f, u->ups[i].resample, a3, nullptr, nullptr, nullptr, 0);

@@ -69,7 +69,9 @@ struct DmnUnet {
     int plan_batch = 64;
     // Diagnosis switches (environment DMN_UNET_PATHS, read when the handle is created): bit 0 launches the ingest and
     // the time path separately, bit 1 uses the unfused linear attention, bit 2 closes every ResnetBlock with its own
-    // pass instead of leaving it to the next convolution, bit 3 keeps the bottleneck attention off the matrix cores.
+    // pass instead of leaving it to the next convolution, bit 3 keeps the bottleneck attention off the matrix cores,
+    // bit 4 leaves the tail of every linear attention to the resampling convolution behind it (fewer launches, slower;
+    // bit 5: only on the way down, bit 6: only at the top level).
     int path_mask = 0;
     // diagnosis: workspace checksums after every launch of a forward (dmn_test_unet_trace)
     unsigned long long* trace_slots = nullptr;

@@ -653,6 +653,28 @@ def test_forward_is_bit_identical_beside_a_foreign_stream(dtype):
     assert not bad, f"forwards {bad} differ from the forward run alone"
 
 
+def test_alternative_launch_paths_give_the_same_bits(monkeypatch):
+    """The diagnosis switches of the network (separate ingest / time launches, unfused linear attention, every block
+    tail in a pass of its own, attention tails folded into the resampling convolutions) only move work between launches:
+    bf16 outputs must be bit-identical except where a different kernel does the arithmetic (unfused attention, VALU
+    softmax, the block tail as a pass of its own: one more rounding than the fused multiply-add of the staging form), which
+    stays within bf16 noise."""
+    g = torch.Generator(device="cuda").manual_seed(4)
+    x = torch.randn(4, 3, 64, 64, device="cuda", generator=g)
+    t = torch.tensor([3, 500, 999, 40], device="cuda")
+    ref = build_unet64("bf16")(x, t)
+    for mask, exact in ((1, True), (16, True), (16 | 32, True), (4, False), (2, False), (8, False)):
+        monkeypatch.setenv("DMN_UNET_PATHS", str(mask))
+        y = build_unet64("bf16")(x, t)
+        monkeypatch.delenv("DMN_UNET_PATHS")
+        d = (y - ref).abs()
+        print(f"paths {mask}: max {float(d.max()):.3e} mean {float(d.mean()):.3e}")
+        if exact:
+            assert torch.equal(y, ref), (mask, float(d.max()))
+        else:
+            assert float(d.max()) < 0.15 and float(d.mean()) < 5e-3, (mask, float(d.max()), float(d.mean()))
+
+
 def test_plan_batch_zero_plans_for_the_call_and_still_matches_oracle():
     """set_plan_batch(0): launch geometry chosen for the batch of each call (the small-batch tile and slice choices);
     same parity bar as the default."""
