@@ -68,6 +68,7 @@ SIGNATURES = {
     "dmn_fill_normal": (_i, [_vp, _i, _i, _u64, C.c_uint32, _i64, _f, _vp]),
     "dmn_unet_set_sample_chains": (_i, [_vp, _i, _i]),
     "dmn_ddpm_loop_chains": (_i, [_vp, _i]),
+    "dmn_test_attn_train": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "dmn_test_attention": (_i, [_i, _vp, _vp, _i, _i, _i, _vp]),
     "dmn_test_unet_trace": (_i, [_vp, _vp, _i]),
     "dmn_test_unet_trace_count": (_i, [_vp]),

@@ -607,7 +607,7 @@ Ten* attn_core(Run& r, Ten* qkv, bool linear) {
         float* pmax = r.alloc((size_t)r.B * heads * linattn_train_splits(r.B, n, heads) * 32);
         RUN(r, launch_linattn_train_fwd(qkv->p, y->p, qkv->adt, ctx, st, pmax, r.B, n, heads, r.bf16, r.s));
     }
-    else RUN(r, launch_attn_train_fwd(qkv->p, y->p, qkv->adt, st, r.B, n, heads, r.s));
+    else RUN(r, launch_attn_train_fwd(qkv->p, y->p, qkv->adt, st, r.B, n, heads, r.bf16, r.s));
     Run* rp = &r;
     r.tape.push_back([rp, qkv, y, ctx, st, linear, n, heads]() {
         Run& r = *rp;
@@ -621,7 +621,7 @@ Ten* attn_core(Run& r, Ten* qkv, bool linear) {
             float* dctx = r.zalloc((size_t)r.B * heads * 1024);
             RUN(r, launch_linattn_train_bwd(qkv->p, y->g, qkv->adt, ctx, st, dctx, g, r.B, n, heads, r.bf16, r.s));
         }
-        else RUN(r, launch_attn_train_bwd(qkv->p, y->p, y->g, qkv->adt, st, g, r.B, n, heads, r.s));
+        else RUN(r, launch_attn_train_bwd(qkv->p, y->p, y->g, qkv->adt, st, g, r.B, n, heads, r.bf16, r.s));
     });
     return y;
 }
@@ -935,6 +935,17 @@ extern "C" int dmn_streams_share_queue(void* a, void* b, int* shared) {
     DMN_REQUIRE(shared, DMN_ERR_INVALID, "dmn_streams_share_queue: null argument");
     *shared = streams_share_queue((hipStream_t)a, (hipStream_t)b) ? 1 : 0;
     return DMN_OK;
+}
+
+// Softmax attention core of the training step on caller-provided tensors (unit parity tests): forward (out, lse) and
+// backward (dqkv) of out = softmax(q k^T / sqrt(32)) v for qkv [B][n][3*heads*32]. adt 0 = fp32 tensors, 1 = bf16;
+// bf16_operands selects the matrix-core kernels where they apply. lse: [2][B*heads][n] floats.
+extern "C" int dmn_test_attn_train(int adt, const void* qkv, const void* dout, void* out, void* dqkv, float* lse, int B, int n,
+                                   int heads, int bf16_operands, void* stream) {
+    DMN_REQUIRE(qkv && dout && out && dqkv && lse && B > 0 && n > 0 && heads > 0, DMN_ERR_INVALID, "dmn_test_attn_train: bad argument");
+    int rc = launch_attn_train_fwd(qkv, out, adt, lse, B, n, heads, bf16_operands, (hipStream_t)stream);
+    if (rc) return rc;
+    return launch_attn_train_bwd(qkv, out, dout, adt, lse, dqkv, B, n, heads, bf16_operands, (hipStream_t)stream);
 }
 
 extern "C" int dmn_train_create(const DmnUnetCfg* cfg, int loss_kind, DmnTrainer** out) {

@@ -113,10 +113,11 @@ int launch_linattn_train_fwd(const void* qkv, void* out, int adt, float* ctx, fl
                              int bf16, hipStream_t s);
 int launch_linattn_train_bwd(const void* qkv, const void* dout, int adt, const float* ctx, const float* kstat, float* dctx, void* dqkv,
                              int B, int n, int heads, int bf16, hipStream_t s);
-// Attention core (parts/mha.py:20-29): out [B][n][heads*32]; lse [B][heads][2][n] (log-sum-exp, then scratch).
-int launch_attn_train_fwd(const void* qkv, void* out, int adt, float* lse, int B, int n, int heads, hipStream_t s);
+// Attention core (parts/mha.py:20-29): out [B][n][heads*32]; lse [2][B*heads][n] (log-sum-exp, then scratch). With bf16
+// operands and 64 <= n <= 256 (n % 64 == 0) the three launches run on the matrix cores, else on the vector units.
+int launch_attn_train_fwd(const void* qkv, void* out, int adt, float* lse, int B, int n, int heads, int bf16, hipStream_t s);
 int launch_attn_train_bwd(const void* qkv, const void* out, const void* dout, int adt, const float* lse, void* dqkv, int B, int n,
-                          int heads, hipStream_t s);
+                          int heads, int bf16, hipStream_t s);
 
 // Layout changes between the reference's parameter layout and the GEMM layout, for all tensors in one launch.
 struct RepackDesc {

@@ -884,6 +884,214 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
     }
 }
 
+// ---- softmax attention core on the matrix cores (bf16 operands, fp32 accumulation), 64 <= n <= 256, n % 64 == 0 ----
+// Same orientation in all three kernels: a 16x16 product tile has one side of the score matrix on the lane (lane & 15)
+// and four entries of the other side in the registers of a lane group, so (a) the per-query / per-key row quantities
+// (log-sum-exp, sum_e dout*out) are one value per lane or per register, and (b) two stacked tiles, converted to bf16,
+// ARE the 32-deep operand of the product that contracts over that other side -- no lane movement. The operand that
+// pairs with them is the transpose of a [n][32] tensor, staged once per workgroup in LDS.
+// grid (heads, B, n / 64); a wave owns 16 queries (forward, dq) or 16 keys (dk/dv).
+constexpr int kAtMaxN = 256;
+constexpr int kAtPitch = kAtMaxN + 8;   // bf16 elements per transposed row (+16 bytes: rows start on different banks)
+
+// eight consecutive channels of a row as a bf16 operand fragment
+__device__ __forceinline__ bf16x8 at_frag(const float* p) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+    return bf16x8{(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3], (__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
+}
+__device__ __forceinline__ bf16x8 at_frag(const __bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+
+// transposes columns [coff, coff + 32) of rows [0, n) of `src` (row stride ld) into sT[32][kAtPitch] (bf16)
+template <typename T>
+__device__ __forceinline__ void at_stage_transposed(__bf16* sT, const T* src, int ld, int coff, int n, int tid) {
+    for (int u = tid; u < n * 4; u += 256) {
+        const int row = u >> 2, part = u & 3;
+        const bf16x8 v = at_frag(src + (size_t)row * ld + coff + part * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sT[(part * 8 + j) * kAtPitch + row] = v[j];
+    }
+}
+
+// transposed fragment for contraction step u (32 entries of the long side): positions {32u+4g..+3, 32u+16+4g..+3}
+__device__ __forceinline__ bf16x8 at_tfrag(const __bf16* sT, int row, int u, int lq) {
+    const __bf16* p = sT + row * kAtPitch + 32 * u + 4 * lq;
+    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(p), hi = *reinterpret_cast<const bf16x4*>(p + 16);
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+__device__ __forceinline__ bf16x8 at_stack(const f32x4& t0, const f32x4& t1) {
+    return bf16x8{(__bf16)t0[0], (__bf16)t0[1], (__bf16)t0[2], (__bf16)t0[3], (__bf16)t1[0], (__bf16)t1[1], (__bf16)t1[2], (__bf16)t1[3]};
+}
+
+#define AT_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const T* __restrict__ qkv, T* __restrict__ out, float* __restrict__ lse,
+                                                            int n, int heads) {
+    __shared__ __attribute__((aligned(16))) __bf16 sVt[32 * kAtPitch];
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int hid = heads * kD, ld = 3 * hid, bh = b * heads + h;
+    const T* base = qkv + (size_t)b * n * ld;
+    const int qi = (blockIdx.z * 4 + wave) * 16 + l15;
+    const bf16x8 qf = at_frag(base + (size_t)qi * ld + h * kD + lq * 8);
+    at_stage_transposed(sVt, base, ld, 2 * hid + h * kD, n, tid);
+    const int nt = n / 16;
+    f32x4 sreg[kAtMaxN / 16];
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < kAtMaxN / 16; ++t) {
+        if (t < nt) {
+            const bf16x8 kf = at_frag(base + (size_t)(t * 16 + l15) * ld + hid + h * kD + lq * 8);
+            f32x4 acc = AT_MFMA(kf, qf, (f32x4{0.f, 0.f, 0.f, 0.f}));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[r] *= kScale;
+                m = fmaxf(m, acc[r]);
+            }
+            sreg[t] = acc;
+        }
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int t = 0; t < kAtMaxN / 16; ++t) {
+        if (t < nt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = (float)(__bf16)__expf(sreg[t][r] - m);   // the denominator sums what the product multiplies
+                sreg[t][r] = e;
+                l += e;
+            }
+        }
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    __syncthreads();
+    f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int u = 0; u < kAtMaxN / 32; ++u) {
+        if (2 * u < nt) {
+            const bf16x8 pf = at_stack(sreg[2 * u], sreg[2 * u + 1]);
+#pragma unroll
+            for (int et = 0; et < 2; ++et) o[et] = AT_MFMA(at_tfrag(sVt, et * 16 + l15, u, lq), pf, o[et]);
+        }
+    }
+    const float inv = 1.0f / l;
+    T* orow = out + ((size_t)b * n + qi) * hid + h * kD;
+#pragma unroll
+    for (int et = 0; et < 2; ++et) {
+        f32x4 v = o[et];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= inv;
+        Io<T>::st4(orow + et * 16 + lq * 4, v);
+    }
+    if (lq == 0) lse[(size_t)bh * n + qi] = m + logf(l);
+}
+
+// dq (and the per-query sum_e dout*out, kept for the second launch): a wave owns 16 queries and sweeps the keys
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
+                                                               const T* __restrict__ dout, const float* __restrict__ lse,
+                                                               T* __restrict__ dqkv, float* __restrict__ dsum, int n, int heads) {
+    __shared__ __attribute__((aligned(16))) __bf16 sKt[32 * kAtPitch];
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int hid = heads * kD, ld = 3 * hid, bh = b * heads + h;
+    const T* base = qkv + (size_t)b * n * ld;
+    const int qi = (blockIdx.z * 4 + wave) * 16 + l15;
+    const bf16x8 qf = at_frag(base + (size_t)qi * ld + h * kD + lq * 8);
+    const T* dorow = dout + ((size_t)b * n + qi) * hid + h * kD + lq * 8;
+    const T* orow = out + ((size_t)b * n + qi) * hid + h * kD + lq * 8;
+    const bf16x8 dof = at_frag(dorow);
+    float Di = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) Di += Io<T>::ld(dorow + j) * Io<T>::ld(orow + j);
+    Di += __shfl_xor(Di, 16, 64);
+    Di += __shfl_xor(Di, 32, 64);
+    if (lq == 0) dsum[(size_t)bh * n + qi] = Di;
+    const float li = lse[(size_t)bh * n + qi];
+    at_stage_transposed(sKt, base, ld, hid + h * kD, n, tid);
+    __syncthreads();
+    f32x4 dq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    for (int u = 0; u < n / 32; ++u) {
+        f32x4 ds[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const T* krow = base + (size_t)((2 * u + i) * 16 + l15) * ld + h * kD + lq * 8;
+            const f32x4 sc = AT_MFMA(at_frag(krow + hid), qf, (f32x4{0.f, 0.f, 0.f, 0.f}));
+            const f32x4 dp = AT_MFMA(at_frag(krow + 2 * hid), dof, (f32x4{0.f, 0.f, 0.f, 0.f}));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ds[i][r] = __expf(sc[r] * kScale - li) * (dp[r] - Di);
+        }
+        const bf16x8 dsf = at_stack(ds[0], ds[1]);
+#pragma unroll
+        for (int et = 0; et < 2; ++et) dq[et] = AT_MFMA(at_tfrag(sKt, et * 16 + l15, u, lq), dsf, dq[et]);
+    }
+    T* drow = dqkv + ((size_t)b * n + qi) * ld + h * kD;
+#pragma unroll
+    for (int et = 0; et < 2; ++et) {
+        f32x4 v = dq[et];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= kScale;
+        Io<T>::st4(drow + et * 16 + lq * 4, v);
+    }
+}
+
+// dk and dv: a wave owns 16 keys and sweeps the queries
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
+                                                                const float* __restrict__ lse, const float* __restrict__ dsum,
+                                                                T* __restrict__ dqkv, int n, int heads) {
+    __shared__ __attribute__((aligned(16))) __bf16 sQt[32 * kAtPitch], sDt[32 * kAtPitch];
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int hid = heads * kD, ld = 3 * hid, bh = b * heads + h;
+    const T* base = qkv + (size_t)b * n * ld;
+    const T* dob = dout + (size_t)b * n * hid;
+    const int kj = (blockIdx.z * 4 + wave) * 16 + l15;
+    const bf16x8 kf = at_frag(base + (size_t)kj * ld + hid + h * kD + lq * 8);
+    const bf16x8 vf = at_frag(base + (size_t)kj * ld + 2 * hid + h * kD + lq * 8);
+    at_stage_transposed(sQt, base, ld, h * kD, n, tid);
+    at_stage_transposed(sDt, dob, hid, h * kD, n, tid);
+    __syncthreads();
+    f32x4 dk[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    f32x4 dv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    for (int u = 0; u < n / 32; ++u) {
+        f32x4 pp[2], ds[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q0 = (2 * u + i) * 16;
+            // rows = queries (registers: query q0 + 4 lq + r), column = this lane's key
+            const f32x4 sc = AT_MFMA(at_frag(base + (size_t)(q0 + l15) * ld + h * kD + lq * 8), kf, (f32x4{0.f, 0.f, 0.f, 0.f}));
+            const f32x4 dp = AT_MFMA(at_frag(dob + (size_t)(q0 + l15) * hid + h * kD + lq * 8), vf, (f32x4{0.f, 0.f, 0.f, 0.f}));
+            const f32x4 lr = *reinterpret_cast<const f32x4*>(lse + (size_t)bh * n + q0 + 4 * lq);
+            const f32x4 dr = *reinterpret_cast<const f32x4*>(dsum + (size_t)bh * n + q0 + 4 * lq);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pp[i][r] = __expf(sc[r] * kScale - lr[r]);
+                ds[i][r] = pp[i][r] * (dp[r] - dr[r]) * kScale;
+            }
+        }
+        const bf16x8 pf = at_stack(pp[0], pp[1]), dsf = at_stack(ds[0], ds[1]);
+#pragma unroll
+        for (int et = 0; et < 2; ++et) {
+            dv[et] = AT_MFMA(at_tfrag(sDt, et * 16 + l15, u, lq), pf, dv[et]);
+            dk[et] = AT_MFMA(at_tfrag(sQt, et * 16 + l15, u, lq), dsf, dk[et]);
+        }
+    }
+    T* drow = dqkv + ((size_t)b * n + kj) * ld + h * kD;
+#pragma unroll
+    for (int et = 0; et < 2; ++et) {
+        Io<T>::st4(drow + hid + et * 16 + lq * 4, dk[et]);
+        Io<T>::st4(drow + 2 * hid + et * 16 + lq * 4, dv[et]);
+    }
+}
+#undef AT_MFMA
+
+static bool attn_train_on_matrix_cores(int n, int bf16) { return bf16 && n >= 64 && n <= kAtMaxN && n % 64 == 0; }
+
 // ---- parameter layout changes -----------------------------------------------------------------------------------
 __device__ __forceinline__ void repack_index(const RepackDesc& d, long long idx, int& co, int& ci, int& tap) {
     tap = (int)(idx % d.taps);
@@ -1107,15 +1315,29 @@ int launch_linattn_train_bwd(const void* qkv, const void* dout, int adt, const f
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }
-int launch_attn_train_fwd(const void* qkv, void* out, int adt, float* lse, int B, int n, int heads, hipStream_t s) {
+int launch_attn_train_fwd(const void* qkv, void* out, int adt, float* lse, int B, int n, int heads, int bf16, hipStream_t s) {
+    if (attn_train_on_matrix_cores(n, bf16)) {
+        const dim3 grid(heads, B, n / 64);
+        DMN_DISPATCH_T(adt, attn_fwd_mfma_kernel<T><<<grid, 256, 0, s>>>((const T*)qkv, (T*)out, lse, n, heads));
+        DMN_LAUNCH_CHECK();
+        return DMN_OK;
+    }
     DMN_DISPATCH_T(adt, attn_fwd_kernel<T><<<B * heads, 256, 0, s>>>((const T*)qkv, (T*)out, lse, n, heads));
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }
 int launch_attn_train_bwd(const void* qkv, const void* out, const void* dout, int adt, const float* lse, void* dqkv, int B, int n,
-                          int heads, hipStream_t s) {
+                          int heads, int bf16, hipStream_t s) {
     // lse: [B*heads][2][n] -- the second half holds the per-query sums between the two launches
     float* dsum = const_cast<float*>(lse) + (size_t)B * heads * n;
+    if (attn_train_on_matrix_cores(n, bf16)) {
+        const dim3 grid(heads, B, n / 64);
+        DMN_DISPATCH_T(adt, attn_bwd_dq_mfma_kernel<T><<<grid, 256, 0, s>>>((const T*)qkv, (const T*)out, (const T*)dout, lse, (T*)dqkv, dsum, n, heads));
+        DMN_LAUNCH_CHECK();
+        DMN_DISPATCH_T(adt, attn_bwd_dkv_mfma_kernel<T><<<grid, 256, 0, s>>>((const T*)qkv, (const T*)dout, lse, dsum, (T*)dqkv, n, heads));
+        DMN_LAUNCH_CHECK();
+        return DMN_OK;
+    }
     const dim3 grid(B * heads, (n + 63) / 64);
     DMN_DISPATCH_T(adt, attn_bwd_dq_kernel<T><<<grid, 256, 0, s>>>((const T*)qkv, (const T*)out, (const T*)dout, lse, (T*)dqkv, dsum, n, heads));
     DMN_LAUNCH_CHECK();

@@ -241,6 +241,11 @@ int dmn_test_linattn(int dtype, const void* x, const float* x_stats, int B, int 
  * (channels q | k | v, each head-major) -> out [B][n][heads * 32], both in the internal dtype. 64 <= n <= 256 with
  * n % 64 == 0 runs on the matrix cores, other sizes on the vector units. */
 int dmn_test_attention(int dtype, const void* qkv, void* out, int B, int n, int heads, void* stream);
+/* Unit-test hook: forward and backward of the training step's softmax attention core (parts/mha.py:20-29) on
+ * caller tensors. adt 0 = fp32, 1 = bf16 tensors; lse = [2][B*heads][n] floats of scratch; bf16_operands != 0 and
+ * 64 <= n <= 256 (n % 64 == 0) runs on the matrix cores. */
+int dmn_test_attn_train(int adt, const void* qkv, const void* dout, void* out, void* dqkv, float* lse, int B, int n, int heads,
+                        int bf16_operands, void* stream);
 
 /* Diagnosis: after every launch of a forward, a checksum of the whole workspace goes to slot k of a device array. */
 int dmn_test_unet_trace(DmnUnet* u, unsigned long long* slots, int max_slots);

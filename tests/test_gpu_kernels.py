@@ -262,3 +262,35 @@ def test_softmax_attention_core_matches_torch(dtype, n):
     torch.cuda.synchronize()
     err = float((out.float().cpu() - ref).abs().max())
     assert err <= (5e-5 if dtype == 0 else 3e-2), (dtype, n, err)   # outputs reach |7|: 1e-5 relative in f32
+
+
+@pytest.mark.parametrize("n,adt,bf16", [(256, 0, 1), (64, 0, 1), (128, 1, 1), (256, 0, 0), (48, 0, 1)])
+def test_training_attention_core_forward_and_backward_match_autograd(n, adt, bf16):
+    """parts/mha.py:20-29 as the training step runs it: out and d(qkv) against torch autograd in float64. bf16 operands
+    on the matrix cores (64 <= n <= 256, n % 64 == 0): 2e-2 of each tensor's largest entry; the vector-unit kernels
+    (fp32 operands, or a size the matrix-core kernels do not take): 2e-5."""
+    from diffusion_model_nemo_amd import _native as N
+    B, heads, d = 3, 4, 32
+    g = torch.Generator().manual_seed(n + adt)
+    qkv = torch.randn(B, n, 3 * heads * d, generator=g) * 1.5
+    dout = torch.randn(B, n, heads * d, generator=g)
+    ref_in = qkv.double().requires_grad_(True)
+    q, k, v = [t.reshape(B, n, heads, d).permute(0, 2, 1, 3) for t in ref_in.chunk(3, dim=-1)]
+    attn = torch.softmax(torch.einsum("bhid,bhjd->bhij", q * d ** -0.5, k), dim=-1)
+    ref = torch.einsum("bhij,bhjd->bhid", attn, v).permute(0, 2, 1, 3).reshape(B, n, heads * d)
+    ref.backward(dout.double())
+    dt = torch.bfloat16 if adt else torch.float32
+    dq = qkv.cuda().to(dt).contiguous()
+    do = dout.cuda().to(dt).contiguous()
+    out = torch.full((B, n, heads * d), float("nan"), device="cuda", dtype=dt)
+    dqkv = torch.full((B, n, 3 * heads * d), float("nan"), device="cuda", dtype=dt)
+    lse = torch.zeros(2 * B * heads * n, device="cuda")
+    N.check(N.lib().dmn_test_attn_train(adt, dq.data_ptr(), do.data_ptr(), out.data_ptr(), dqkv.data_ptr(), lse.data_ptr(), B, n,
+                                        heads, bf16, None))
+    torch.cuda.synchronize()
+    exact = not bf16 and not adt
+    tol = 2e-5 if (exact or (not adt and n == 48)) else (2e-2 if not adt else 4e-2)
+    for name, got, want in (("out", out, ref.detach()), ("dqkv", dqkv, ref_in.grad)):
+        err = float((got.double().cpu() - want).abs().max())
+        scale = float(want.abs().max())
+        assert err <= tol * scale, (name, n, adt, bf16, err, scale)
