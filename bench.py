@@ -235,6 +235,16 @@ def main():
     gdp.p_sample_loop(unet, shape, device=dev, seed=7, keep="last", return_device_tensor=True, use_graph=not a.no_graph)
     clk_ms, clk_n = C.c_float(), C.c_int()
     N.check(N.lib().dmn_unet_probe_result(h, C.byref(clk_ms), C.byref(mark_ms), C.byref(clk_n), C.byref(k_bytes)))
+    # (a') the same with ONE launch chain (64 images per launch, nothing else in flight): the kernel by itself in its
+    #      place in the step, comparable with earlier rounds and with a profiler's per-kernel average
+    one_ms, one_n, one_bytes = C.c_float(), C.c_int(), C.c_double()
+    chains_default = N.lib().dmn_ddpm_loop_chains(h, B)
+    if chains_default > 1:
+        unet.set_sample_chains(1)
+        N.check(N.lib().dmn_unet_probe_dominant(unet.native_handle(), 2))
+        gdp.p_sample_loop(unet, shape, device=dev, seed=7, keep="last", return_device_tensor=True, use_graph=not a.no_graph)
+        N.check(N.lib().dmn_unet_probe_result(h, C.byref(one_ms), C.byref(mark_ms), C.byref(one_n), C.byref(one_bytes)))
+        unet.set_sample_chains(2)
     # (b) HIP events around the launch inside an eager replay of the same steps (markers cannot be timed inside a graph)
     N.check(N.lib().dmn_unet_probe_dominant(h, 1))
     gdp.p_sample_loop(unet, shape, device=dev, seed=7, keep="last", return_device_tensor=True, use_graph=False)
@@ -293,6 +303,13 @@ def main():
                          "launch_us_measured": f"device clock (100 MHz) stamps of the launch's workgroups, earliest start to latest "
                                                f"end, {clk_n.value} launches inside graph-replayed denoising steps with "
                                                f"{chains} launch chain{'s' if chains > 1 else ''} in flight",
+                         "note": "with two launch chains in flight a launch shares the machine with the other chain's kernels: its own "
+                                 "bytes over its own duration understate what the machine moves meanwhile; single_chain is the same "
+                                 "kernel timed the same way with one chain (all images in one launch, nothing else in flight)",
+                         "single_chain": None if chains_default == 1 else {
+                             "launch_us": one_ms.value * 1e3, "algorithmic_bytes": one_bytes.value, "launches": one_n.value,
+                             "achieved": one_bytes.value / (one_ms.value / 1e3) / 1e9,
+                             "frac": one_bytes.value / (one_ms.value / 1e3) / 1e9 / HBM_PEAK_GBS},
                          "launch_us_hip_events_eager": p_ms.value * 1e3,
                          "launch_us_hip_events_eager_measured": f"HIP events around {p_n.value} launches inside eager denoising steps: marker-to-"
                                                f"marker {pair_ms.value * 1e3:.2f} us minus {mark_ms.value * 1e3:.2f} us for a marker by itself",

@@ -18,7 +18,7 @@ find $o/${tag}_prof_bench -name "*_kernel_trace.csv" -size +20M -delete
 DMN_SAMPLE_CHAINS=1 timeout -k 10 600 python bench.py --no-train --no-cpu-baseline > $o/${tag}_bench_single_chain.log 2>&1 || { tail -5 $o/${tag}_bench_single_chain.log; exit 1; }
 grep -v "^[WE]2026" $o/${tag}_bench_single_chain.log | tail -1 > $o/${tag}_bench_single_chain.json
 DMN_SAMPLE_CHAINS=1 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_prof_single -- python bench.py --steps 1 --warmup 1 --no-train --no-cpu-baseline > $o/${tag}_single_chain_under_rocprof.log 2>&1 || { tail -5 $o/${tag}_single_chain_under_rocprof.log; exit 1; }
-for t in $(find $o/${tag}_prof_single -name "*_kernel_trace.csv"); do python tools/trace_by_grid.py $t > $o/${tag}_single_chain_kernel_by_grid.csv; done
+for t in $(find $o/${tag}_prof_single -name "*_kernel_trace.csv"); do python tools/trace_by_grid.py $t > $o/${tag}_single_chain_kernel_by_grid.csv; python tools/step_timeline.py $t > $o/${tag}_step_timeline.txt; done
 find $o/${tag}_prof_single -name "*_kernel_trace.csv" -size +20M -delete
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -s KILL 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $o/${tag}_pmc_$c -- python bench.py --steps 1 --warmup 0 --timesteps 10 --probe-steps 10 --no-cpu-baseline --no-train > $o/${tag}_pmc_$c.log 2>&1 || { tail -5 $o/${tag}_pmc_$c.log; exit 1; }
