@@ -82,6 +82,45 @@ template <typename T> __global__ __launch_bounds__(256) void gn_apply_kernel(con
     const float inv_cnt = 1.0f / ((float)Cg * (float)a.HW);
     const size_t img = (size_t)b * a.HW * a.C;
     float s1 = 0.f, s2 = 0.f;
+    if (256 % c4n == 0) {
+        // A thread keeps its four channels (the stride of the walk is a multiple of the channel vectors per pixel): the
+        // group's mean / rstd and the channel parameters are fetched once, and four pixels' loads are in flight together.
+        const int c = 4 * (threadIdx.x % c4n), ppb = 256 / c4n;
+        float mean, rstd;
+        gn_mean_rstd(a.stats, b * a.G + c / Cg, inv_cnt, mean, rstd);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(a.gamma + c), be = *reinterpret_cast<const f32x4*>(a.beta + c);
+        f32x4 tbv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.tb) tbv = *reinterpret_cast<const f32x4*>(a.tb + (size_t)b * a.tb_ld + c);
+        const T* xp = x + img + c;
+        const T* rp = res ? res + img + c : nullptr;
+        T* yp = y + img + c;
+        auto one = [&](const f32x4& v, const f32x4& rv, int p) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float z = (v[e] - mean) * rstd * ga[e] + be[e];
+                if (a.act) z = z * sigmoid_f(z);
+                o[e] = z + tbv[e] + rv[e];
+            }
+            Io<T>::st4(yp + (size_t)p * a.C, o);
+            s1 += (o[0] + o[1]) + (o[2] + o[3]);
+            s2 += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+        };
+        const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+        int p = blockIdx.x * ppb + threadIdx.x / c4n;
+        const int st = gridDim.x * ppb;
+        for (; p + 3 * st < a.HW; p += 4 * st) {
+            f32x4 v[4], rv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[u] = Io<T>::ld4(xp + (size_t)(p + u * st) * a.C);
+                rv[u] = rp ? Io<T>::ld4(rp + (size_t)(p + u * st) * a.C) : zero;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) one(v[u], rv[u], p + u * st);
+        }
+        for (; p < a.HW; p += st) one(Io<T>::ld4(xp + (size_t)p * a.C), rp ? Io<T>::ld4(rp + (size_t)p * a.C) : zero, p);
+    } else
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const long long pix = i / c4n;
         const int c = 4 * (int)(i - pix * c4n);
@@ -203,6 +242,43 @@ template <typename T> __global__ __launch_bounds__(256) void gn_bwd_apply_kernel
     const float inv_cnt = 1.0f / ((float)Cg * (float)a.HW);
     const size_t img = (size_t)b * a.HW * a.C;
     const long long total = (long long)a.HW * c4n;
+    if (256 % c4n == 0) {   // fixed channels per thread, as in the forward kernel
+        const int c = 4 * (tid % c4n), g = c / Cg, ppb = 256 / c4n;
+        float mean, rstd;
+        gn_mean_rstd(a.stats, b * a.G + g, inv_cnt, mean, rstd);
+        const float m1 = S1[g] * inv_cnt, m2 = S2[g] * inv_cnt;
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(a.gamma + c), be = *reinterpret_cast<const f32x4*>(a.beta + c);
+        const T* xp = x + img + c;
+        const T* dp = dy + img + c;
+        T* op = dx + img + c;
+        const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto one = [&](const f32x4& v, const f32x4& d, f32x4 o, int p) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (v[e] - mean) * rstd;
+                float dz = d[e];
+                if (a.act) dz *= silu_grad(xh * ga[e] + be[e]);
+                o[e] += rstd * (dz * ga[e] - m1 - xh * m2);
+            }
+            Io<T>::st4(op + (size_t)p * a.C, o);
+        };
+        int p = blockIdx.x * ppb + tid / c4n;
+        const int st = gridDim.x * ppb;
+        for (; p + 3 * st < a.HW; p += 4 * st) {
+            f32x4 v[4], d[4], o[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[u] = Io<T>::ld4(xp + (size_t)(p + u * st) * a.C);
+                d[u] = Io<T>::ld4(dp + (size_t)(p + u * st) * a.C);
+                o[u] = a.accumulate ? Io<T>::ld4(op + (size_t)(p + u * st) * a.C) : zero;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) one(v[u], d[u], o[u], p + u * st);
+        }
+        for (; p < a.HW; p += st)
+            one(Io<T>::ld4(xp + (size_t)p * a.C), Io<T>::ld4(dp + (size_t)p * a.C), a.accumulate ? Io<T>::ld4(op + (size_t)p * a.C) : zero, p);
+        return;
+    }
     for (long long i = (long long)blockIdx.x * 256 + tid; i < total; i += (long long)gridDim.x * 256) {
         const long long p = i / c4n;
         const int c = 4 * (int)(i - p * c4n), g = c / Cg;
