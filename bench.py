@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the extra training-step measurement")
     ap.add_argument("--learned-variance", action="store_true",
-                    help="improved DDPM: 6-channel network + LearnedGaussianDiffusion (BASELINE configuration 3 per GPU)")
+                    help="improved DDPM: 6-channel network + LearnedGaussianDiffusion (benchmark configuration 3 per GPU)")
     ap.add_argument("--probe-steps", type=int, default=100, help="eager steps for the in-loop timing of the dominant kernel")
     return ap.parse_args()
 
@@ -89,7 +89,7 @@ def cpu_chain(B, image_size, timesteps, budget_s, learned_variance=False, min_st
 
 def cpu_baseline(batch, image_size, timesteps, budget_s, learned_variance=False):
     """The CPU oracle timed on this host's cores: (1) the timed workload itself (same batch, image size and step count)
-    for a bounded number of steps, extrapolated to the whole chain; (2) BASELINE configuration 1 (32x32, batch 4, the
+    for a bounded number of steps, extrapolated to the whole chain; (2) benchmark configuration 1 (32x32, batch 4, the
     reference's own CPU-runnable case) for up to 1000 steps."""
     cores = min(16, os.cpu_count() or 1)   # the box's CPU share for one GPU is 16 threads, whatever the machine has
     torch.set_num_threads(cores)
@@ -107,7 +107,7 @@ def cpu_baseline(batch, image_size, timesteps, budget_s, learned_variance=False)
 
 
 def train_step_extra(dev, rank, world, dist):
-    """Extra, reported beside the headline: the DDPM training step of BASELINE configuration 5 (128x128, 32 images per
+    """Extra, reported beside the headline: the DDPM training step of benchmark configuration 5 (128x128, 32 images per
     GPU: q_sample + forward + L_simple + backward, ONE all-reduce of the flat gradient buffer over RCCL when N > 1,
     global-norm clip + AdamW), bf16 matrix-core operands, fp32 activations. Every rank first runs one step without any
     collective and the ranks agree that all succeeded before the timed loop with the all-reduce starts, so a failure

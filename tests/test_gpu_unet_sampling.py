@@ -69,7 +69,7 @@ def test_unet_forward_fp32_64x64_and_oracle_batch():
 
 @pytest.mark.parametrize("B,H,W", [(1, 128, 128), (64, 64, 64), (5, 8, 8)])
 def test_unet_forward_other_sizes_match_oracle(B, H, W):
-    """Sizes of the other BASELINE configurations (128x128 inputs, the batch-64 64x64 bench shape whose tile and
+    """Sizes of the other benchmark configurations (128x128 inputs, the batch-64 64x64 bench shape whose tile and
     slice heuristics differ from the small-batch ones) and the smallest legal image, HIP fp32 vs the oracle."""
     u = build_unet("fp32")
     p = R.to_torch(make_state_dict(unet_param_shapes()))
@@ -202,7 +202,7 @@ def test_p_sample_single_steps_match_reference_golden():
 
 
 def test_ddpm_chain_1000_steps_fp32_matches_reference_golden():
-    """BASELINE config 1 shape (32x32, 1000 steps; B=2) through the graph-replayed device loop."""
+    """benchmark configuration 1 shape (32x32, 1000 steps; B=2) through the graph-replayed device loop."""
     from diffusion_model_nemo_amd.modules import GaussianDiffusion
     g = load_golden("chain_ddpm_T1000_B2_32")
     u = build_unet("fp32")
@@ -315,7 +315,7 @@ def test_stream_queue_probe():
     ("vp_rd_langevin2", "vp", "reverse_diffusion", "langevin", 2),
     ("ve_anc_ald", "ve", "ancestral_sampling", "ald", 1)])
 def test_pc_sampler_chains_match_reference_golden(tag, kind, pred, corr, n_steps):
-    """BASELINE config 4 path (VE/VP predictor-corrector, 32x32) on N=20 chains; VE states reach |x| ~ 1e3,
+    """benchmark configuration 4 path (VE/VP predictor-corrector, 32x32) on N=20 chains; VE states reach |x| ~ 1e3,
     so the tolerance is relative to the golden's absolute maximum."""
     from diffusion_model_nemo_amd.modules import VESDE, VPSDE, PredictorCorrectorSampler
     g = load_golden("chain_sde_N20_B2_32")
@@ -521,7 +521,7 @@ def build_unet64(compute_dtype, learned_variance=False):
 
 
 def test_learned_variance_forward_at_the_bench_shape_matches_oracle():
-    """BASELINE configuration 3 per GPU: the 6-channel network on [64, 3, 64, 64]; images 0 and 63 against the oracle."""
+    """benchmark configuration 3 per GPU: the 6-channel network on [64, 3, 64, 64]; images 0 and 63 against the oracle."""
     u = build_unet64("fp32", learned_variance=True)
     p = R.to_torch(make_state_dict(unet_param_shapes(learned_variance=True)))
     B = 64

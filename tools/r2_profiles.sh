@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/r2_profiles.sh <tag>: the profile set of a round for the sampling path.
+# usage: tools/r2_profiles.sh <tag>: the profile set of the sampling path.
 #  1. the default bench command, plain;  2. the same command under rocprofv3 --kernel-trace --stats (per-kernel and
 #  per-(kernel, grid) summaries; the big per-dispatch trace is deleted);  3. FETCH_SIZE and WRITE_SIZE passes (one per
 #  run) over a short chain;  4. one matrix-core counter pass.

@@ -1,4 +1,4 @@
-"""Times the DDPM training step (q_sample + U-Net forward + L_simple + backward + clip + AdamW) of BASELINE
+"""Times the DDPM training step (q_sample + U-Net forward + L_simple + backward + clip + AdamW) of the benchmark
 configuration 5: 128x128 images, 32 per GPU, shipped network widths. `python tools/train_bench.py [--batch 32]
 [--size 128] [--steps 20] [--warmup 5]`; under torch.distributed.run every rank takes `--batch` images and the flat
 gradient buffer is all-reduced over RCCL. Prints one JSON line (rank 0)."""
