@@ -1,11 +1,13 @@
-"""Improved-DDPM sampler with a learned, per-pixel interpolated variance.
+"""Improved-DDPM sampler: the network predicts, per pixel, where between the two analytic extremes the reverse
+variance lies (diffusion_model_nemo/modules/learned_gaussian_diffusion.py:14-53).
 
-Mirror of diffusion_model_nemo/modules/learned_gaussian_diffusion.py:14-53. The network emits 2*C channels
-(eps | v); log sigma^2 = f log beta_t + (1 - f) log beta~_t with f = (v + 1) / 2. The sampling loop is inherited
-and runs the same fused device kernel with ``learned_variance`` set. As in the reference, ``objective`` does not
-change the parameterisation here: the first half of the output is always treated as predicted noise.
+The network emits 2*C channels: the noise estimate and a raw interpolation value v in [-1, 1]. With w = (v + 1) / 2,
+log sigma^2 = w * log beta_t + (1 - w) * log beta~_t (Nichol & Dhariwal, eq. 15). The sampling loop is the inherited
+device loop with the `learned_variance` switch of the update kernel; this module only has to provide the host-side
+`p_mean_variance` that the step-by-step API and the variational-bound terms use. As in the reference, `objective`
+does not change the parameterisation: the first half of the output is always read as predicted noise.
 """
-from typing import Optional
+from typing import Optional, Tuple
 
 import torch
 
@@ -22,17 +24,19 @@ class LearnedGaussianDiffusion(GaussianDiffusion):
         self._declared_objective = objective
         self.objective = "pred_noise"
 
+    def interpolated_variance(self, v: torch.Tensor, t: torch.Tensor, shape) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(sigma^2, log sigma^2) for the raw interpolation values `v` at steps `t`
+        (learned_gaussian_diffusion.py:38-43): the bounds are log beta~_t (clipped posterior) and log beta_t."""
+        lower, upper = (self.extract(table, t, shape) for table in (self.posterior_log_variance_clipped, self.betas.log()))
+        w = (v + 1) * 0.5
+        log_variance = w * upper + (1 - w) * lower
+        return log_variance.exp(), log_variance
+
     def p_mean_variance(self, model, x, t, model_output=None, return_pred_x_start=False):
-        if model_output is None:
-            model_output = model(x, t)
-        pred_noise, frac_raw = model_output.chunk(2, dim=1)
-        min_log = self.extract(self.posterior_log_variance_clipped, t, x.shape)
-        max_log = self.extract(torch.log(self.betas), t, x.shape)
-        frac = (frac_raw + 1) * 0.5
-        model_log_variance = frac * max_log + (1 - frac) * min_log
-        model_variance = model_log_variance.exp()
-        x_start = self.predict_start_from_noise(x_t=x, t=t, noise=pred_noise).clamp(-1.0, 1.0)
-        model_mean, _ = self.q_posterior(x_start, x, t)
-        if return_pred_x_start:
-            return model_mean, model_variance, model_log_variance, x_start
-        return model_mean, model_variance, model_log_variance
+        out = model(x, t) if model_output is None else model_output
+        eps, v = torch.split(out, out.shape[1] // 2, dim=1)
+        variance, log_variance = self.interpolated_variance(v, t, x.shape)
+        x0 = self.predict_start_from_noise(x_t=x, t=t, noise=eps).clamp(-1.0, 1.0)
+        mean = self.q_posterior(x0, x, t)[0]
+        result = (mean, variance, log_variance)
+        return result + (x0,) if return_pred_x_start else result
