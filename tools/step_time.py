@@ -20,11 +20,14 @@ ap.add_argument("--lv", action="store_true")
 ap.add_argument("--size", type=int, default=64)
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--tag", default="")
+ap.add_argument("--plan", type=int, default=None, help="planning batch of the launch heuristics")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 torch.manual_seed(1234)
 u = Unet(input_dim=a.size, dim=32, dim_mults=[1, 2, 4, 8], channels=3, resnet_block_groups=8, use_convnext=False, dropout=0.0,
          learned_variance=a.lv, compute_dtype="bf16").to(dev).eval()
+if a.plan is not None:
+    u.set_plan_batch(a.plan)
 gd = (LearnedGaussianDiffusion if a.lv else GaussianDiffusion)(timesteps=a.steps, schedule_name="cosine")
 ms = []
 host = []
