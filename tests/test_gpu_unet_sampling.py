@@ -588,6 +588,28 @@ def test_two_launch_chains_give_the_bits_of_one_chain(dtype, lv):
     assert torch.equal(eager, one)
 
 
+@pytest.mark.parametrize("B", [15, 16, 18, 34])
+def test_two_launch_chains_at_ragged_batches(B):
+    """Batches around the split rule (even and >= 16: two chains of B/2, else one) on a 32x32 network, DDIM steps with a
+    given x_T included: always the bits of one chain."""
+    from diffusion_model_nemo_amd import _native as N
+    from diffusion_model_nemo_amd.modules import GaussianDiffusion, GeneralizedGaussianDiffusion
+    u = build_unet("bf16")
+    assert N.lib().dmn_ddpm_loop_chains(u.native_handle(), B) == (2 if B % 2 == 0 and B >= 16 else 1)
+    g = torch.Generator(device="cuda").manual_seed(B)
+    x_T = torch.randn(B, 3, 32, 32, device="cuda", generator=g)
+    samplers = ((GaussianDiffusion(timesteps=9, schedule_name="linear"), "x_T"),
+                (GeneralizedGaussianDiffusion(timesteps=50, schedule_name="linear", eta=0.5, ddim_timesteps=10), "img"))
+    for gd, start in samplers:
+        u.set_sample_chains(1)
+        one = gd.p_sample_loop(u, (B, 3, 32, 32), device="cuda", seed=3, return_device_tensor=True, **{start: x_T.clone()}).clone()
+        u.set_sample_chains(2)
+        two = gd.p_sample_loop(u, (B, 3, 32, 32), device="cuda", seed=3, return_device_tensor=True, **{start: x_T.clone()})
+        assert torch.equal(one, two), (B, type(gd).__name__)
+    with pytest.raises(ValueError):
+        u.set_sample_chains(3)
+
+
 def test_two_launch_chains_keep_each_image_its_class_label():
     """Class-conditional sampling with per-image labels: the second chain must read the labels of ITS images."""
     import functools
