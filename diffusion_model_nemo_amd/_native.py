@@ -37,6 +37,7 @@ SIGNATURES = {
     "dmn_unet_load_weights": (_i, [_vp, C.POINTER(DmnTensorDesc), _i]),
     "dmn_unet_set_class_labels": (_i, [_vp, _vp]),
     "dmn_unet_set_plan_batch": (_i, [_vp, _i]),
+    "dmn_unet_handoff_giveups": (_i, [_vp, C.POINTER(C.c_uint)]),
     "dmn_unet_workspace_bytes": (_i, [_vp, _i, _i, _i, C.POINTER(_sz)]),
     "dmn_unet_forward": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "dmn_ddpm_step": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _u64, _i64, _vp]),
@@ -77,6 +78,8 @@ SIGNATURES = {
     "dmn_test_unet_trace_name": (C.c_char_p, [_vp, _i]),
     "dmn_test_set_conv_debug": (_i, [_vp]),
     "dmn_test_linattn": (_i, [_i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i), _vp, _sz, _vp]),
+    "dmn_test_conv_block_tail": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp,
+                                      _i, C.POINTER(_i), _i, _i, _i, _i, C.POINTER(C.c_uint), _vp]),
     "dmn_test_conv2d": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp,
                              _vp, _vp, _i, _i, _i, _vp, _i, C.POINTER(_i), _i, _i, _vp]),
 }

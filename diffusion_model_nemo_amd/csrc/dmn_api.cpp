@@ -434,6 +434,122 @@ extern "C" int dmn_test_conv2d(int dtype, const void* in0, const void* in1, int 
     return rc;
 }
 
+// block2.proj of a ResnetBlock together with the block's closing SiLU(GroupNorm(h)) + res on caller-provided tensors
+// (unit parity tests, tuning): fused = 1 runs the one-launch form with the in-launch statistics hand-off, fused = 0 the
+// convolution followed by the stand-alone closing pass (h2 [B][H][W][Cout] is its intermediate). out_stats_dev receives
+// [B][out_G][slots][2] partial statistics of `out` (slots returned in out_slots). The launch may stamp phase times
+// into the buffer set by dmn_test_set_conv_debug.
+extern "C" int dmn_test_conv_block_tail(int dtype, const void* in, int Cin, int B, int H, int W, const float* w_host,
+                                        const float* bias_host, int Cout, const float* pro_gamma_host,
+                                        const float* pro_beta_host, const float* pro_stats_dev, int pro_G, int pro_slots,
+                                        const float* tail_gamma_host, const float* tail_beta_host, int G, const void* res,
+                                        void* h2, void* out, float* out_stats_dev, int out_G, int* out_slots, int fused,
+                                        int plan_B, int cfg_tile, int cfg_bn, unsigned* giveups, void* stream) {
+    DMN_REQUIRE(in && w_host && pro_stats_dev && tail_gamma_host && tail_beta_host && res && out && (fused || h2), DMN_ERR_INVALID,
+                "dmn_test_conv_block_tail: null argument");
+    int rc = conv_init_attributes();
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    PackedConv pc;
+    if ((rc = pack_conv(pc, dtype, w_host, bias_host, Cout, Cin, 3, 3, 1, 1, false))) return rc;
+    float *dpg = nullptr, *dpb = nullptr, *dtg = nullptr, *dtb = nullptr, *h2_stats = nullptr;
+    void* area = nullptr;
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(s);
+        free_conv(pc);
+        for (void* p : {(void*)dpg, (void*)dpb, (void*)dtg, (void*)dtb, (void*)h2_stats, area})
+            if (p) (void)hipFree(p);
+    };
+    auto up = [&](const float* h, int n, float** d) {
+        return hipMalloc((void**)d, n * 4) == hipSuccess && hipMemcpy(*d, h, n * 4, hipMemcpyHostToDevice) == hipSuccess;
+    };
+    if (!up(pro_gamma_host, Cin, &dpg) || !up(pro_beta_host, Cin, &dpb) || !up(tail_gamma_host, Cout, &dtg) ||
+        !up(tail_beta_host, Cout, &dtb)) {
+        cleanup();
+        dmn_set_error("dmn_test_conv_block_tail: device allocation failed");
+        return DMN_ERR_HIP;
+    }
+    ConvArgs a;
+    conv_args_from(pc, dtype, a, B, H, W);
+    a.in0 = in;
+    a.C0 = Cin;
+    a.plan_B = plan_B;
+    a.cfg_tile = cfg_tile;
+    a.cfg_bn = cfg_bn;
+    a.pro.stats = pro_stats_dev;
+    a.pro.G = pro_G;
+    a.pro.slots = pro_slots;
+    a.pro.inv_count = 1.0f / ((float)(Cin / pro_G) * H * W);
+    a.pro.gamma = dpg;
+    a.pro.beta = dpb;
+    a.pro.silu = 1;
+    a.epi.G = G;
+    const float inv_count = 1.0f / ((float)(Cout / G) * H * W);
+    if (giveups) *giveups = 0;
+    if (fused) {
+        const size_t bytes = kHandoffHeaderBytes + (size_t)B * G * conv_epi_slots(a) * 16;
+        unsigned hdr[2] = {1u, 0u};   // epoch 1 over a zeroed area
+        if (!conv_tail_fits(a) || hipMalloc(&area, bytes) != hipSuccess || hipMemset(area, 0, bytes) != hipSuccess ||
+            hipMemcpy(area, hdr, sizeof(hdr), hipMemcpyHostToDevice) != hipSuccess) {
+            cleanup();
+            dmn_set_error("dmn_test_conv_block_tail: shape outside the hand-off's limits, or allocation failed");
+            return DMN_ERR_LIMIT;
+        }
+        a.out = out;
+        a.res = res;
+        a.tail.gran = reinterpret_cast<unsigned long long*>((char*)area + kHandoffHeaderBytes);
+        a.tail.epoch = reinterpret_cast<const unsigned*>(area);
+        a.tail.giveups = reinterpret_cast<unsigned*>(area) + 1;
+        a.tail_gamma = dtg;
+        a.tail_beta = dtb;
+        a.tail_inv_count = inv_count;
+        if (out_stats_dev) {
+            a.tail_stats.stats = out_stats_dev;
+            a.tail_stats.G = out_G;
+        }
+        rc = launch_conv(a, s);
+        if (out_slots) *out_slots = a.tail_stats.slots;
+        (void)hipStreamSynchronize(s);
+        if (giveups) (void)hipMemcpy(giveups, (char*)area + 4, 4, hipMemcpyDeviceToHost);
+    } else {
+        const int slots = conv_epi_slots(a);
+        if (hipMalloc((void**)&h2_stats, (size_t)B * G * slots * 8) != hipSuccess) {
+            cleanup();
+            return DMN_ERR_HIP;
+        }
+        a.out = h2;
+        a.epi.stats = h2_stats;
+        rc = launch_conv(a, s);
+        if (rc == DMN_OK) {
+            NormApplyArgs na;
+            memset(&na, 0, sizeof(na));
+            na.dtype = dtype;
+            na.in = h2;
+            na.out = out;
+            na.res = res;
+            na.B = B;
+            na.HW = H * W;
+            na.C = Cout;
+            na.norm.stats = h2_stats;
+            na.norm.G = G;
+            na.norm.slots = a.epi.slots;
+            na.norm.inv_count = inv_count;
+            na.norm.gamma = dtg;
+            na.norm.beta = dtb;
+            na.norm.silu = 1;
+            na.plan_B = plan_B;
+            if (out_stats_dev) {
+                na.epi.stats = out_stats_dev;
+                na.epi.G = out_G;
+            }
+            rc = launch_norm_apply(na, s);
+            if (out_slots) *out_slots = na.epi.slots;
+        }
+    }
+    cleanup();
+    return rc;
+}
+
 // Softmax attention core on caller-provided tensors (unit parity tests).
 extern "C" int dmn_test_attention(int dtype, const void* qkv, void* out, int B, int n, int heads, void* stream) {
     DMN_REQUIRE(qkv && out && B > 0 && n > 0 && heads > 0, DMN_ERR_INVALID, "dmn_test_attention: bad argument");

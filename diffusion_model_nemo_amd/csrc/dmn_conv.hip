@@ -29,6 +29,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
+#include "dmn_handoff.h"
 #include "dmn_kernels.h"
 #include "dmn_norm.h"
 
@@ -59,9 +62,14 @@ template <> struct KindTraits<DMN_KT2X2> { static constexpr int NTAPS = 4, EXT =
 //          a skip connection) without a launch of its own.
 // RES: also apply a 1x1 convolution (w2, bias2 -> out2) to the same input tile -- the ResnetBlock shortcut
 // res_conv(x) beside block1.proj(x) (parts/convnext.py:76,79,86) -- sharing the staged tile; 3x3 kind only.
-template <typename T, int KIND, int TH, int TW, int BN, int WM, int WN, int PRO, bool RES>
+// TAIL: the launch is block2.proj of a ResnetBlock and also closes the block (parts/convnext.py:85-86): the
+// accumulators stay in registers while the image's workgroups exchange their GroupNorm partial sums (dmn_handoff.h),
+// then out = SiLU(GroupNorm(conv + bias)) + res is stored, with partial statistics of THAT tensor for the next
+// consumer. The convolution's own output never reaches memory and the block needs no closing pass.
+template <typename T, int KIND, int TH, int TW, int BN, int WM, int WN, int PRO, bool RES, bool TAIL = false>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
     static_assert(!RES || KIND == DMN_K3X3, "the fused 1x1 shortcut rides on the 3x3 kernel");
+    static_assert(!TAIL || (KIND == DMN_K3X3 && !RES), "the fused block tail rides on the plain 3x3 kernel");
     using KT = KindTraits<KIND>;
     static_assert(WM * WN == 4, "four waves per workgroup");
     constexpr int NTAPS = KT::NTAPS, S = KT::S, GK = KT::GK, KW = KT::KW;
@@ -382,10 +390,6 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
     {
         DMN_STAMP(3)
         // ---- epilogue: bias, residual, statistics, NHWC store ---------------------------------------------
-        const bool want_stats = a.epi.stats != nullptr;
-        float ssum[NT], ssq[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) ssum[nt] = ssq[nt] = 0.f;
         T* outp = static_cast<T*>(a.out);
         const T* resp = static_cast<const T*>(a.res);
         // Output offsets in 32 bits (the launcher bounds the tensor), linear in mt: pixel tile mt of the wave lies
@@ -397,6 +401,157 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
                                 (unsigned)a.Cout;
         const unsigned ostep = (unsigned)(ROWS * a.out_sy * a.out_W) * (unsigned)a.Cout;
         const bool col_ok = oxt < a.Wo;
+        // Per-lane sums of 4-channel quads -> one {sum, sum of squares} per (group, workgroup), handed to emit(g, slot,
+        // s, ss) by the first threads. Contains one barrier, which every wave reaches behind its MFMA loop.
+        auto wg_partials = [&](float (&ps)[NT], float (&pq)[NT], int G, auto emit) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                // reduce over the 16 pixel lanes; lane (lane&15)==0 of each quarter holds the sums of a 4-channel quad
+                ps[nt] = row16_sum(ps[nt]);
+                pq[nt] = row16_sum(pq[nt]);
+                if (l15 == 0) {
+                    const int quad = (wn * NT + nt) * 4 + lq;  // local quad index in [0, BN/4)
+                    sRed[(wm * (BN / 4) + quad) * 2] = ps[nt];
+                    sRed[(wm * (BN / 4) + quad) * 2 + 1] = pq[nt];
+                }
+            }
+            __syncthreads();
+            const int cpg = a.Cout / G;
+            const int ngl = cpg >= BN ? 1 : BN / cpg;      // groups this workgroup touches
+            const int qpg = (cpg >= BN ? BN : cpg) / 4;    // quads per touched group inside this workgroup
+            const int sub = cpg > BN ? cpg / BN : 1;       // workgroups (along N) sharing one group
+            if (tid < ngl) {
+                float s = 0.f, ss = 0.f;
+                for (int w_ = 0; w_ < WM; ++w_)
+                    for (int q = 0; q < qpg; ++q) {
+                        s += sRed[(w_ * (BN / 4) + tid * qpg + q) * 2];
+                        ss += sRed[(w_ * (BN / 4) + tid * qpg + q) * 2 + 1];
+                    }
+                emit(n0 / cpg + tid, blockIdx.x * sub + (cpg > BN ? (n0 % cpg) / BN : 0), s, ss);
+            }
+        };
+        float ssum[NT], ssq[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) ssum[nt] = ssq[nt] = 0.f;
+        if constexpr (TAIL) {
+            // (0) requests whose answers are only needed behind the wait: the residual operand of every output
+            //     fragment, this thread's channel of the closing GroupNorm
+            using RV = typename std::conditional<sizeof(T) == 4, f32x4, bf16x4>::type;
+            RV rv[MT][NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const bool valid = col_ok && oyt0 + mt * ROWS < a.Ho;
+                const unsigned obase = valid ? obase0 + (unsigned)mt * ostep : 0u;   // outside the image: any mapped address
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    rv[mt][nt] = *reinterpret_cast<const RV*>(resp + obase + n0 + (wn * NT + nt) * 16 + lq * 4);
+            }
+            const unsigned epoch = *a.tail.epoch;
+            const int G = a.epi.G;
+            const int cpg = a.Cout / G;
+            float pgam = 0.f, pbet = 0.f;
+            if (tid < BN) {
+                pgam = a.tail_gamma[n0 + tid];
+                pbet = a.tail_beta[n0 + tid];
+            }
+            // (1) statistics of conv + bias over this workgroup's pixels, published as granules -- unless this workgroup
+            //     holds every pixel and channel of its groups (one slot per group: nothing to exchange)
+            const bool exchange = a.epi.slots > 1;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if (col_ok && oyt0 + mt * ROWS < a.Ho) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float v = acc[mt][nt][r] + bias[nt][r];
+                            ssum[nt] += v;
+                            ssq[nt] += v * v;
+                        }
+                }
+            }
+            // the halo tile is dead behind the barrier inside wg_partials: its LDS holds mean / rstd of this
+            // workgroup's groups and then the per-channel coefficients
+            float* sMR = reinterpret_cast<float*>(smem);
+            float* sC = sMR + 2 * kHandoffMaxGroups;
+            const int ng = cpg >= BN ? 1 : BN / cpg;
+            wg_partials(ssum, ssq, G, [&](int g, int slot, float s, float ss) {
+                if (exchange) {
+                    unsigned long long* dst = a.tail.gran + ((size_t)(b * G + g) * a.epi.slots + slot) * 2;
+                    granule_store(dst, epoch, s);
+                    granule_store(dst + 1, epoch, ss);
+                } else {   // the arithmetic of the exchange with one slot
+                    const float mean = s * a.tail_inv_count;
+                    float var = ss * a.tail_inv_count - mean * mean;
+                    var = var > 0.f ? var : 0.f;
+                    sMR[2 * (g - n0 / cpg)] = mean;
+                    sMR[2 * (g - n0 / cpg) + 1] = __builtin_amdgcn_rsqf(var + 1e-5f);
+                }
+            });
+            // (2) wait for the image's other workgroups
+            if (exchange) handoff_group_stats(a.tail, epoch, b, G, a.epi.slots, n0 / cpg, ng, a.tail_inv_count, sMR);
+            __syncthreads();
+            if (a.dbg && tid == 0) a.dbg[wgid * 8 + 6] = clock64();
+            if (tid < BN) {
+                const int gl = cpg >= BN ? 0 : tid / cpg;
+                const float aa = sMR[2 * gl + 1] * pgam;
+                sC[tid] = aa;
+                sC[BN + tid] = pbet - sMR[2 * gl] * aa;
+            }
+            __syncthreads();
+            // (3) out = SiLU(GroupNorm(conv + bias)) + res, in the arithmetic of the stand-alone closing pass (which
+            //     reads the convolution's output rounded to the activation type)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) ssum[nt] = ssq[nt] = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const bool valid = col_ok && oyt0 + mt * ROWS < a.Ho;
+                const unsigned obase = obase0 + (unsigned)mt * ostep;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int cl = (wn * NT + nt) * 16 + lq * 4;
+                    const int n = n0 + cl;
+                    const f32x4 ca = *reinterpret_cast<const f32x4*>(sC + cl);
+                    const f32x4 cb = *reinterpret_cast<const f32x4*>(sC + BN + cl);
+                    if (valid) {
+                        float y[4];
+                        if constexpr (sizeof(T) == 4) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                float t = (acc[mt][nt][r] + bias[nt][r]) * ca[r] + cb[r];
+                                t = silu_precise(t);
+                                t += 0.f;
+                                y[r] = t + rv[mt][nt][r];
+                                ssum[nt] += y[r];
+                                ssq[nt] += y[r] * y[r];
+                            }
+                            store_stream(reinterpret_cast<f32x4*>(outp + obase + n), f32x4{y[0], y[1], y[2], y[3]});
+                        } else {
+                            bf16x4 o;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float x = (float)(__bf16)(acc[mt][nt][r] + bias[nt][r]);
+                                o[r] = (__bf16)(silu_affine_fast(x, ca[r], cb[r], 0.f) + (float)rv[mt][nt][r]);
+                                const float yr = (float)o[r];   // statistics of the value the consumer will read
+                                ssum[nt] += yr;
+                                ssq[nt] += yr * yr;
+                            }
+                            store_stream(reinterpret_cast<bf16x4*>(outp + obase + n), o);
+                        }
+                    }
+                }
+            }
+            // (4) partial statistics of the block's output
+            if (a.tail_stats.stats) {
+                const int Go = a.tail_stats.G;
+                wg_partials(ssum, ssq, Go, [&](int g, int slot, float s, float ss) {
+                    float* dst = a.tail_stats.stats + ((size_t)(b * Go + g) * a.tail_stats.slots + slot) * 2;
+                    dst[0] = s;
+                    dst[1] = ss;
+                });
+            }
+        } else {
+        const bool want_stats = a.epi.stats != nullptr;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const bool valid = col_ok && oyt0 + mt * ROWS < a.Ho;
@@ -467,36 +622,13 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
             }
         }
         if (want_stats) {
-            // reduce over the 16 pixel lanes; lane (lane&15)==0 of each quarter holds the sums of a 4-channel quad
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                ssum[nt] = row16_sum(ssum[nt]);
-                ssq[nt] = row16_sum(ssq[nt]);
-                if (l15 == 0) {
-                    const int quad = (wn * NT + nt) * 4 + lq;  // local quad index in [0, BN/4)
-                    sRed[(wm * (BN / 4) + quad) * 2] = ssum[nt];
-                    sRed[(wm * (BN / 4) + quad) * 2 + 1] = ssq[nt];
-                }
-            }
-            __syncthreads();
             const int G = a.epi.G;
-            const int cpg = a.Cout / G;
-            const int ngl = cpg >= BN ? 1 : BN / cpg;      // groups this workgroup touches
-            const int qpg = (cpg >= BN ? BN : cpg) / 4;    // quads per touched group inside this workgroup
-            const int sub = cpg > BN ? cpg / BN : 1;       // workgroups (along N) sharing one group
-            if (tid < ngl) {
-                float s = 0.f, ss = 0.f;
-                for (int w_ = 0; w_ < WM; ++w_)
-                    for (int q = 0; q < qpg; ++q) {
-                        s += sRed[(w_ * (BN / 4) + tid * qpg + q) * 2];
-                        ss += sRed[(w_ * (BN / 4) + tid * qpg + q) * 2 + 1];
-                    }
-                const int g = n0 / cpg + tid;
-                const int slot = blockIdx.x * sub + (cpg > BN ? (n0 % cpg) / BN : 0);
+            wg_partials(ssum, ssq, G, [&](int g, int slot, float s, float ss) {
                 float* dst = a.epi.stats + ((size_t)(b * G + g) * a.epi.slots + slot) * 2;
                 dst[0] = s;
                 dst[1] = ss;
-            }
+            });
+        }
         }
     }
     DMN_STAMP(4)
@@ -507,11 +639,11 @@ struct TileCfg {
     int th, tw, bn;
 };
 
-template <typename T, int KIND, int TH, int TW, int BN, int WM, int WN, int PRO, bool RES = false>
+template <typename T, int KIND, int TH, int TW, int BN, int WM, int WN, int PRO, bool RES = false, bool TAIL = false>
 int launch_cfg(const ConvArgs& a, size_t lds, hipStream_t s) {
     const int tiles = ((a.Ho + TH - 1) / TH) * ((a.Wo + TW - 1) / TW);
     dim3 grid(tiles, a.Cout / BN, a.B * a.nphase);
-    hipLaunchKernelGGL((conv_igemm_kernel<T, KIND, TH, TW, BN, WM, WN, PRO, RES>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, KIND, TH, TW, BN, WM, WN, PRO, RES, TAIL>), grid, dim3(256), lds, s, a);
     DMN_HIP_CHECK(hipGetLastError());
     return DMN_OK;
 }
@@ -604,9 +736,27 @@ int dispatch_fused_shortcut(const ConvArgs& a, const TileCfg& c, size_t lds, hip
     return DMN_ERR_INVALID;
 }
 
+// block2.proj that also closes its ResnetBlock (TAIL): 3x3, GroupNorm + SiLU prologue
+template <typename T>
+int dispatch_fused_tail(const ConvArgs& a, const TileCfg& c, size_t lds, hipStream_t s) {
+    if (c.th == 16 && c.bn == 32) return launch_cfg<T, DMN_K3X3, 16, 16, 32, 2, 2, 2, false, true>(a, lds, s);
+    if (c.th == 16 && c.bn == 64) return launch_cfg<T, DMN_K3X3, 16, 16, 64, 2, 2, 2, false, true>(a, lds, s);
+    if (c.th == 8 && c.bn == 32) return launch_cfg<T, DMN_K3X3, 8, 8, 32, 2, 2, 2, false, true>(a, lds, s);
+    if (c.th == 8 && c.bn == 64) return launch_cfg<T, DMN_K3X3, 8, 8, 64, 1, 4, 2, false, true>(a, lds, s);
+    dmn_set_error("conv: no fused-tail kernel for tile %dx%d / %d", c.th, c.tw, c.bn);
+    return DMN_ERR_INVALID;
+}
+
 template <typename T>
 int dispatch(const ConvArgs& a, const TileCfg& c, size_t lds, hipStream_t s) {
     const int pro = a.pro.stats ? (a.pro_res ? 3 : a.pro.silu ? 2 : 1) : 0;
+    if (a.tail.gran) {
+        if (a.kind != DMN_K3X3 || pro != 2 || a.w2 || a.C1) {
+            dmn_set_error("conv: the fused block tail needs a single-source 3x3 convolution with the GroupNorm + SiLU prologue");
+            return DMN_ERR_INVALID;
+        }
+        return dispatch_fused_tail<T>(a, c, lds, s);
+    }
     if (pro == 3) {
         if (a.kind == DMN_K1X1 || a.w2 || a.C1 || a.pro.tbias) {
             dmn_set_error("conv: the fused producer tail needs a plain single-source 3x3 or resampling convolution");
@@ -646,10 +796,10 @@ int dispatch(const ConvArgs& a, const TileCfg& c, size_t lds, hipStream_t s) {
     return DMN_ERR_INVALID;
 }
 
-template <typename T, int KIND, int TH, int TW, int BN, int WM, int WN, int PRO, bool RES = false>
+template <typename T, int KIND, int TH, int TW, int BN, int WM, int WN, int PRO, bool RES = false, bool TAIL = false>
 int set_attr() {
     // opt in to more than 64 KiB of dynamic LDS (done once at handle creation, never inside a stream capture)
-    DMN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, KIND, TH, TW, BN, WM, WN, PRO, RES>),
+    DMN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, KIND, TH, TW, BN, WM, WN, PRO, RES, TAIL>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return DMN_OK;
 }
@@ -683,6 +833,10 @@ int set_attr_all() {
     if ((rc = set_attr<T, DMN_K3X3, 16, 16, 32, 2, 2, 0, true>())) return rc;
     if ((rc = set_attr<T, DMN_K3X3, 8, 8, 32, 2, 2, 0, true>())) return rc;
     if ((rc = set_attr<T, DMN_K3X3, 8, 8, 64, 1, 4, 0, true>())) return rc;
+    if ((rc = set_attr<T, DMN_K3X3, 16, 16, 32, 2, 2, 2, false, true>())) return rc;
+    if ((rc = set_attr<T, DMN_K3X3, 16, 16, 64, 2, 2, 2, false, true>())) return rc;
+    if ((rc = set_attr<T, DMN_K3X3, 8, 8, 32, 2, 2, 2, false, true>())) return rc;
+    if ((rc = set_attr<T, DMN_K3X3, 8, 8, 64, 1, 4, 2, false, true>())) return rc;
     return DMN_OK;
 }
 
@@ -702,11 +856,16 @@ int conv_init_attributes() {
     return DMN_OK;
 }
 
-int conv_epi_slots(const ConvArgs& a) {
+static int slots_for_groups(const ConvArgs& a, int G) {
     const TileCfg c = pick_cfg(a);
     const int tiles = ((a.Ho + c.th - 1) / c.th) * ((a.Wo + c.tw - 1) / c.tw);
-    const int cpg = a.Cout / a.epi.G;
+    const int cpg = a.Cout / G;
     return tiles * (cpg > c.bn ? cpg / c.bn : 1);
+}
+int conv_epi_slots(const ConvArgs& a) { return slots_for_groups(a, a.epi.G); }
+int conv_tail_slots(const ConvArgs& a) { return slots_for_groups(a, a.tail_stats.G); }
+bool conv_tail_fits(const ConvArgs& a) {
+    return a.epi.G >= 1 && a.epi.G <= kHandoffMaxGroups && conv_epi_slots(a) <= kHandoffMaxSlots;
 }
 
 int launch_conv(ConvArgs& a, hipStream_t s) {
@@ -719,12 +878,25 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
     DMN_REQUIRE(!(a.pro.stats && a.C1), DMN_ERR_INVALID, "conv: input normalisation needs a single source");
     const TileCfg c = pick_cfg(a);
     if (a.pro.stats) DMN_REQUIRE(Cin % a.pro.G == 0, DMN_ERR_INVALID, "conv: Cin %% groups != 0");
-    if (a.epi.stats) {
+    if (a.tail.gran) {
+        DMN_REQUIRE(!a.epi.stats && a.epi.G >= 1 && a.tail.epoch && a.tail.giveups && a.tail_gamma && a.tail_beta && a.res,
+                    DMN_ERR_INVALID, "conv: fused block tail needs groups, epoch, parameters and the residual tensor");
+        DMN_REQUIRE(conv_tail_fits(a), DMN_ERR_LIMIT, "conv: fused block tail limited to %d groups of %d partial sums",
+                    kHandoffMaxGroups, kHandoffMaxSlots);
+    }
+    if (a.epi.stats || a.tail.gran) {
         DMN_REQUIRE(a.nphase == 1 && a.Cout % a.epi.G == 0 && (a.Cout / a.epi.G) % 4 == 0, DMN_ERR_INVALID,
                     "conv: output statistics need one phase and >= 4 channels per group");
         const int cpg = a.Cout / a.epi.G;
         DMN_REQUIRE(cpg >= c.bn ? cpg % c.bn == 0 : c.bn % cpg == 0, DMN_ERR_INVALID, "conv: group size %d vs tile %d", cpg, c.bn);
         a.epi.slots = conv_epi_slots(a);
+    }
+    if (a.tail.gran && a.tail_stats.stats) {
+        DMN_REQUIRE(a.tail_stats.G >= 1 && a.Cout % a.tail_stats.G == 0 && (a.Cout / a.tail_stats.G) % 4 == 0, DMN_ERR_INVALID,
+                    "conv: statistics of the block output need >= 4 channels per group");
+        const int cpg = a.Cout / a.tail_stats.G;
+        DMN_REQUIRE(cpg >= c.bn ? cpg % c.bn == 0 : c.bn % cpg == 0, DMN_ERR_INVALID, "conv: group size %d vs tile %d", cpg, c.bn);
+        a.tail_stats.slots = conv_tail_slots(a);
     }
     if (!a.dbg) a.dbg = g_conv_dbg;
     a.cg = pick_cg(a, c);

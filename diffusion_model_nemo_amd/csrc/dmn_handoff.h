@@ -1,0 +1,96 @@
+// Hand-off of GroupNorm partial sums between the workgroups of ONE launch (gfx950: eight XCDs with private L2s,
+// per-CU L1s that other CUs' stores never refresh).
+//
+// A kernel whose epilogue needs statistics of its own output (the closing SiLU(GroupNorm(h)) + res of a ResnetBlock,
+// parts/convnext.py:85-86, or the GroupNorm(1) + residual behind a linear attention, parts/mha.py:41-42) would
+// otherwise end at a kernel boundary and hand its tile to a second pass. Here every workgroup of an image publishes its
+// partial {sum, sum of squares} as 8-byte GRANULES {tag = epoch, value = float bits}, each written by one agent-scope
+// relaxed atomic store (a write-through store that every XCD observes) and read by agent-scope relaxed atomic loads
+// (which bypass the reader's L1): the data is its own flag, so no fence, no counter and no ordering between granules
+// is needed. A reader polls its granules until all carry the current epoch.
+//
+// Epoch: one device word per launch chain, incremented by the first kernel of every network evaluation. The granule
+// area belongs to the handle (never to the caller's workspace), is zeroed when allocated and only ever written with
+// epochs that grow, so a tag equal to the current epoch can only have been written by the current evaluation; every
+// fused launch of an evaluation owns a distinct range of the area.
+//
+// Progress: the workgroups of an image are consecutive in launch order (blockIdx.z = image), each publishes BEFORE it
+// waits, and a waiting workgroup only needs workgroups of its own image, of which there are at most a few dozen; the
+// spins are bounded all the same (kHandoffSpinTicks of the 100 MHz clock), a give-up is counted in the area's
+// header and surfaces as an error at the next host check, never as a hang.
+#pragma once
+#include "dmn_common.h"
+
+typedef __attribute__((address_space(1))) unsigned long long dmn_gu64;
+
+constexpr int kHandoffHeaderBytes = 256;           // word 0: epoch, word 1: spins given up
+constexpr long long kHandoffSpinTicks = 50000000;  // 0.5 s of the 100 MHz wall clock
+constexpr int kHandoffMaxSlots = 64;               // partial sums per (image, group): one per lane of a wave
+constexpr int kHandoffMaxGroups = 32;
+
+// Host view of a fused tail's statistics hand-off (kernel argument).
+struct HandoffArgs {
+    unsigned long long* gran;   // [B][G][slots][2] granules; nullptr: the launch has no fused tail
+    const unsigned* epoch;      // current epoch of the chain
+    unsigned* giveups;          // incremented when a bounded spin runs out
+};
+
+__device__ __forceinline__ void granule_store(unsigned long long* g, unsigned epoch, float v) {
+    __hip_atomic_store((dmn_gu64*)g, ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long granule_load(const unsigned long long* g) {
+    return __hip_atomic_load((const dmn_gu64*)g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Mean / rstd of `ng` consecutive groups (first group g_first) of image `b` from the granules of all its workgroups;
+// result pairs in sMR[2 * local group]. Called by every wave of a 256-thread workgroup; no barrier inside. The slots
+// of a group are summed exactly as norm_coefs_to_lds sums the slots of a stats buffer (one slot per lane of a 16-, 32-
+// or 64-lane segment, then a fixed butterfly), so the coefficients equal those of the two-launch form bit for bit.
+__device__ __forceinline__ void handoff_group_stats(const HandoffArgs& h, unsigned epoch, int b, int G, int slots, int g_first,
+                                                    int ng, float inv_count, float* sMR) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nwaves = blockDim.x >> 6;
+    const int seg = slots <= 16 ? 16 : slots <= 32 ? 32 : 64;
+    const int gpw = 64 / seg;
+    const int sl = lane & (seg - 1);
+    for (int g0 = wave * gpw; g0 < ng; g0 += nwaves * gpw) {
+        const int gl = g0 + lane / seg;
+        const bool mine = gl < ng && sl < slots;
+        const unsigned long long* p = h.gran + (((size_t)b * G + g_first + (mine ? gl : 0)) * slots + (mine ? sl : 0)) * 2;
+        unsigned long long va = 0, vb = 0;
+        const long long t0 = wall_clock64();
+        for (;;) {
+            bool ok = true;
+            if (mine) {
+                va = granule_load(p);
+                vb = granule_load(p + 1);
+                ok = (unsigned)(va >> 32) == epoch && (unsigned)(vb >> 32) == epoch;
+            }
+            if (__all(ok)) break;
+            if (wall_clock64() - t0 > kHandoffSpinTicks) {   // wave-uniform: every lane reads the same clock region
+                if (lane == 0) atomicAdd(h.giveups, 1u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        float s = mine ? __uint_as_float((unsigned)va) : 0.f;
+        float ss = mine ? __uint_as_float((unsigned)vb) : 0.f;
+        s = row16_sum(s);
+        ss = row16_sum(ss);
+        if (seg >= 32) {
+            s += __shfl_xor(s, 16, 64);
+            ss += __shfl_xor(ss, 16, 64);
+        }
+        if (seg == 64) {
+            s += __shfl_xor(s, 32, 64);
+            ss += __shfl_xor(ss, 32, 64);
+        }
+        if (sl == 0 && gl < ng) {
+            const float mean = s * inv_count;
+            float var = ss * inv_count - mean * mean;
+            var = var > 0.f ? var : 0.f;
+            sMR[2 * gl] = mean;
+            sMR[2 * gl + 1] = __builtin_amdgcn_rsqf(var + 1e-5f);
+        }
+    }
+}

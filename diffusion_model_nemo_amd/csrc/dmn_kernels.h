@@ -2,6 +2,7 @@
 // All activations are NHWC, element type T = float or __bf16 selected by `dtype`.
 #pragma once
 #include "dmn_common.h"
+#include "dmn_handoff.h"
 
 enum { DMN_F32 = 0, DMN_BF16 = 1 };
 // convolution shapes the implicit-GEMM kernel is specialised for
@@ -60,6 +61,14 @@ struct ConvArgs {
     const void* w2;       // optional fused 1x1 convolution of the same input (3x3 kind, no input normalisation):
     const float* bias2;   //   weights packed like `w` with one tap, bias [Cout],
     void* out2;           //   output [B][out_H][out_W][Cout]
+    // Fused ResnetBlock tail (3x3 kind with the GroupNorm + SiLU prologue, single source; tail.gran != nullptr):
+    // out = SiLU(GroupNorm_{epi.G}(conv + bias)) + res with the image's partial sums exchanged inside the launch
+    // (epi.stats stays nullptr; epi.G gives the groups), and partial statistics of `out` into tail_stats.
+    HandoffArgs tail;
+    const float* tail_gamma;   // [Cout] affine parameters of the closing GroupNorm
+    const float* tail_beta;
+    float tail_inv_count;      // 1 / elements per (image, group) of that GroupNorm
+    NormOut tail_stats;        // optional statistics of `out`
     int cg, lg_upp;       // channels staged per group and log2 of its 16-byte units per pixel; set by the launcher
     long long* dbg;       // optional [workgroups][8] phase timestamps (tuning aid; nullptr in production)
     int cfg_tile, cfg_bn; // 0 = choose automatically; otherwise force the pixel tile (8 or 16) / channel tile (32 or 64)
@@ -68,6 +77,8 @@ struct ConvArgs {
 };
 int launch_conv(ConvArgs& a, hipStream_t s);
 int conv_epi_slots(const ConvArgs& a);   // slots per (image, group) launch_conv will write
+int conv_tail_slots(const ConvArgs& a);  // same for tail_stats
+bool conv_tail_fits(const ConvArgs& a);  // epi.G groups / their partial sums within the hand-off's limits
 int conv_init_attributes();
 void conv_set_debug_buffer(long long* dev);
 long long* kernel_debug_buffer();   // timestamps of every later launch_conv go here (nullptr: off)
@@ -116,6 +127,7 @@ struct IngestArgs {
     const float* class_embed;   // optional [num_classes + 1][Cout]: row labels[b] is added to every pixel of image b
     const long long* labels;    // [B] or nullptr (every image takes row num_classes)
     int num_classes;
+    unsigned* epoch;            // optional: the hand-off epoch of the chain, incremented by one thread (dmn_handoff.h)
 };
 int launch_ingest(IngestArgs& a, hipStream_t s);
 bool ingest_time_fusable(const IngestArgs& a, const TimeArgs& t);

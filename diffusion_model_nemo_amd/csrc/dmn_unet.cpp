@@ -248,6 +248,25 @@ struct Fwd {
     }
     int planB() const { return u->plan_batch > 0 ? u->plan_batch : B; }
     bool ok() const { return rc == DMN_OK; }
+    // granule area of this chain (dmn_handoff.h): every fused launch takes the next range. The dry run only adds up;
+    // a real run returns nullptr when the area is missing or too small and the caller takes the two-launch form.
+    char* ho_base = nullptr;
+    size_t ho_cap = 0, ho_off = kHandoffHeaderBytes;
+    bool ho_enabled = false;
+    unsigned long long* handoff_take(size_t bytes) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        const size_t at = ho_off;
+        ho_off += bytes;
+        if (dry || !ho_base || at + bytes > ho_cap) return nullptr;
+        return reinterpret_cast<unsigned long long*>(ho_base + at);
+    }
+    HandoffArgs handoff_args(unsigned long long* gran) const {
+        HandoffArgs h;
+        h.gran = gran;
+        h.epoch = reinterpret_cast<const unsigned*>(ho_base);
+        h.giveups = reinterpret_cast<unsigned*>(ho_base) + 1;
+        return h;
+    }
     // every launch of the forward reports here; with a trace buffer attached, a checksum of the whole workspace is
     // taken behind it (slot k = state after launch k), which locates the first launch whose result differs between runs
     void run(int r, const char* what) {
@@ -396,6 +415,46 @@ static Act resblock(Fwd& f, const ResBlockW& w, Act& x, Act* x2, const float* tb
         h1 = do_conv(f, w.c1, x, x2, nullptr, nullptr, G, w.has_res ? &w.res : nullptr, w.has_res ? &r : nullptr);
     }
     NormIn n1 = norm_in(h1, w.g1, w.b1, f.B, 1, w.tb_off >= 0 ? tb + w.tb_off : nullptr, tb_stride);
+    if (!defer && f.ho_enabled && w.c2.kind == DMN_K3X3) {
+        // block2.proj closes the block itself: the image's workgroups exchange their GroupNorm partial sums inside
+        // the launch, so neither the convolution's output nor a closing pass over it exists
+        ConvArgs a;
+        conv_args_from(w.c2, f.u->cfg.dtype, a, f.B, h1.H, h1.W);
+        a.plan_B = f.planB();
+        a.in0 = h1.p;
+        a.C0 = h1.C;
+        a.pro = n1;
+        a.epi.G = G;
+        if (conv_tail_fits(a)) {
+            unsigned long long* gran = f.handoff_take((size_t)f.B * G * conv_epi_slots(a) * 2 * sizeof(unsigned long long));
+            if (gran || f.dry) {
+                Act out = f.new_act(w.c2.Cout, a.out_H, a.out_W);
+                if (f.dry) {   // plan for the two-launch form as well (its peak is the larger one)
+                    Act h2 = f.new_act(w.c2.Cout, a.out_H, a.out_W);
+                    float* st = f.new_stats(G, conv_epi_slots(a));
+                    f.ar.release(st);
+                    f.free_act(h2);
+                }
+                a.out = out.p;
+                a.res = resp->p;
+                a.tail = f.handoff_args(gran);
+                a.tail_gamma = w.g2;
+                a.tail_beta = w.b2;
+                a.tail_inv_count = 1.0f / ((float)(w.c2.Cout / G) * a.out_H * a.out_W);
+                if (statsG > 0) {
+                    a.tail_stats.G = statsG;
+                    out.sG = statsG;
+                    out.sSlots = conv_tail_slots(a);
+                    out.stats = f.new_stats(statsG, out.sSlots);
+                    a.tail_stats.stats = out.stats;
+                }
+                if (f.ok() && !f.dry) f.run(launch_conv(a, f.s), "conv2 + block tail (in-launch statistics)");
+                f.free_act(h1);
+                if (w.has_res) f.free_act(r);
+                return out;
+            }
+        }
+    }
     Act h2 = do_conv(f, w.c2, h1, nullptr, &n1, nullptr, G);
     f.free_act(h1);
     Act out = f.new_act(h2.C, h2.H, h2.W);
@@ -552,8 +611,34 @@ static Act full_attn(Fwd& f, const AttnW& w, Act& x) {
 }
 
 // The whole forward. `t`/`t_is_float` or (`table`, `step_idx`) provide the time label.
+int unet_reserve_handoff(DmnUnet* u, size_t bytes) {
+    if (bytes <= u->handoff_bytes && u->handoff_mem[0] && u->handoff_mem[1]) return DMN_OK;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;   // a capture on the legacy stream forbids allocation
+    if (hipStreamIsCapturing(nullptr, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return DMN_OK;
+    const size_t want = bytes < ((size_t)1 << 20) ? ((size_t)1 << 20) : bytes + bytes / 2;
+    DMN_HIP_CHECK(hipDeviceSynchronize());   // evaluations in flight still poll the old areas
+    if (u->graph_exec) {                     // captured steps hold the old addresses
+        (void)hipGraphExecDestroy(u->graph_exec);
+        if (u->graph_exec2) (void)hipGraphExecDestroy(u->graph_exec2);
+        u->graph_exec = u->graph_exec2 = nullptr;
+    }
+    for (int c = 0; c < 2; ++c) {
+        if (u->handoff_mem[c]) (void)hipFree(u->handoff_mem[c]);
+        u->handoff_mem[c] = nullptr;
+    }
+    u->handoff_bytes = 0;
+    for (int c = 0; c < 2; ++c) {
+        DMN_HIP_CHECK(hipMalloc(&u->handoff_mem[c], want));
+        DMN_HIP_CHECK(hipMemset(u->handoff_mem[c], 0, want));   // epoch 0, no granule carries a tag
+    }
+    DMN_HIP_CHECK(hipDeviceSynchronize());
+    u->handoff_bytes = want;
+    return DMN_OK;
+}
+
 int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float, const float* table, int* step_idx,
-                      float* out, int B, int H, int W, void* ws, size_t ws_bytes, hipStream_t s, bool dry, size_t* high) {
+                      float* out, int B, int H, int W, void* ws, size_t ws_bytes, hipStream_t s, bool dry, size_t* high,
+                      size_t* handoff_need) {
     const DmnUnetCfg& c = u->cfg;
     DMN_REQUIRE(u->loaded || dry, DMN_ERR_WEIGHTS, "dmn_unet_forward: weights not loaded");
     const int nlev = c.n_mults;
@@ -566,6 +651,12 @@ int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float,
     f.B = B;
     f.dry = dry;
     f.ar.reset(ws, ws_bytes, dry);
+    f.ho_enabled = !(u->path_mask & 128);
+    if (!dry && f.ho_enabled) {
+        f.ho_base = static_cast<char*>(u->handoff_mem[u->chain_id & 1]);
+        f.ho_cap = u->handoff_bytes;
+        if (!f.ho_base) f.ho_enabled = false;
+    }
     if (!dry) {
         u->trace_n = 0;
         if (u->trace_slots && u->trace_poison) (void)launch_lds_poison(u->trace_poison, s);
@@ -615,6 +706,7 @@ int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float,
             ia.labels = u->labels ? u->labels + u->label_offset : nullptr;
             ia.num_classes = c.num_classes;
         }
+        if (f.ho_enabled && !dry) ia.epoch = reinterpret_cast<unsigned*>(f.ho_base);
         if (f.ok() && !dry) {
             if (c.with_time_emb && !(u->path_mask & 1) && ingest_time_fusable(ia, ta)) {
                 f.run(launch_ingest_time(ia, ta, s), "ingest + time");   // the two independent openers of the network in one launch
@@ -709,6 +801,7 @@ int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float,
         f.free_act(fin);
     }
     if (high) *high = f.ar.high;
+    if (handoff_need) *handoff_need = f.ho_off;
     return f.rc == kTraceStop ? DMN_OK : f.rc;
 }
 
@@ -1135,6 +1228,8 @@ extern "C" void dmn_unet_destroy(DmnUnet* u) {
         if (e) (void)hipEventDestroy(e);
     if (u->probe_stamps) (void)hipFree(u->probe_stamps);
     if (u->probe_acc) (void)hipFree(u->probe_acc);
+    for (int c = 0; c < 2; ++c)
+        if (u->handoff_mem[c]) (void)hipFree(u->handoff_mem[c]);
     free_weights(u);
     delete u;
 }
@@ -1272,10 +1367,27 @@ extern "C" int dmn_unet_workspace_bytes(const DmnUnet* u, int B, int H, int W, s
         for (int i = 0; i < u->cfg.n_mults - 1; ++i) total += 2 * dims[u->cfg.n_mults - 1 - i];
         uu->tb_total = total;
     }
-    int rc = unet_forward_impl(uu, nullptr, nullptr, 0, nullptr, nullptr, nullptr, B, H, W, nullptr, 0, nullptr, true, &high);
+    size_t handoff = 0;
+    int rc = unet_forward_impl(uu, nullptr, nullptr, 0, nullptr, nullptr, nullptr, B, H, W, nullptr, 0, nullptr, true, &high, &handoff);
     uu->tb_total = saved_total;
     if (rc) return rc;
     *bytes = high + 4096;
+    // the granule areas of the in-launch hand-offs belong to the handle and grow with the largest shape asked about
+    if (!(u->path_mask & 128) && (rc = unet_reserve_handoff(uu, handoff))) return rc;
+    return DMN_OK;
+}
+
+// Spins of the in-launch hand-offs that ran into their time limit since the handle was created (both chains; waits for
+// the device). Non-zero means an evaluation used incomplete GroupNorm statistics: its results are invalid.
+extern "C" int dmn_unet_handoff_giveups(DmnUnet* u, unsigned* count) {
+    DMN_REQUIRE(u && count, DMN_ERR_INVALID, "dmn_unet_handoff_giveups: null argument");
+    *count = 0;
+    for (int c = 0; c < 2; ++c)
+        if (u->handoff_mem[c]) {
+            unsigned hdr[2] = {0, 0};
+            DMN_HIP_CHECK(hipMemcpy(hdr, u->handoff_mem[c], sizeof(hdr), hipMemcpyDeviceToHost));
+            *count += hdr[1];
+        }
     return DMN_OK;
 }
 

@@ -71,7 +71,8 @@ struct DmnUnet {
     // the time path separately, bit 1 uses the unfused linear attention, bit 2 closes every ResnetBlock with its own
     // pass instead of leaving it to the next convolution, bit 3 keeps the bottleneck attention off the matrix cores,
     // bit 4 leaves the tail of every linear attention to the resampling convolution behind it (fewer launches, slower;
-    // bit 5: only on the way down, bit 6: only at the top level).
+    // bit 5: only on the way down, bit 6: only at the top level), bit 7 closes the ResnetBlocks in front of an attention
+    // with a pass of their own instead of inside block2.proj (no in-launch hand-off anywhere).
     int path_mask = 0;
     // diagnosis: workspace checksums after every launch of a forward (dmn_test_unet_trace)
     unsigned long long* trace_slots = nullptr;
@@ -102,6 +103,12 @@ struct DmnUnet {
     long long* probe_stamps = nullptr;   // [2 chains][kProbeMaxWgs][8] per-workgroup stamps of the probed launch
     unsigned long long* probe_acc = nullptr;   // per chain {sum of spans in 10 ns ticks, launches}
     double probe_bytes = 0.0;            // algorithmic bytes of one probed launch
+    // Granule areas of the in-launch statistics hand-off (dmn_handoff.h), one per launch chain, owned by the handle:
+    // [256 B header: epoch, give-ups][granules of every fused launch of an evaluation, in launch order]. Sized by
+    // dmn_unet_workspace_bytes for the largest shape asked about; an evaluation whose fused launches do not fit
+    // falls back to the separate closing passes.
+    void* handoff_mem[2] = {nullptr, nullptr};
+    size_t handoff_bytes = 0;
 };
 constexpr int kProbePairs = 256;
 constexpr int kProbeMaxWgs = 16384;
@@ -114,4 +121,7 @@ void conv_args_from(const PackedConv& pc, int dtype, ConvArgs& a, int B, int H, 
 // step_idx[kStepCopyOffset]; step_idx must then address at least kStepCopyOffset + 1 ints.
 constexpr int kStepCopyOffset = 16;
 int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float, const float* table, int* step_idx,
-                      float* out, int B, int H, int W, void* ws, size_t ws_bytes, hipStream_t s, bool dry, size_t* high);
+                      float* out, int B, int H, int W, void* ws, size_t ws_bytes, hipStream_t s, bool dry, size_t* high,
+                      size_t* handoff_need = nullptr);
+// Makes both chains' granule areas at least `bytes` large (never inside a stream capture: it allocates).
+int unet_reserve_handoff(DmnUnet* u, size_t bytes);

@@ -273,10 +273,11 @@ class GaussianDiffusion(AbstractDiffusionProcess):
         hist = self._run_chain(model, x, 0, self.timesteps, x_T is None, keep, seed, image_offset, use_graph=use_graph)
         if return_device_tensor:
             return x
-        if keep == "last":
-            return [((x + 1) * 0.5).cpu()]
-        imgs = ((hist + 1) * 0.5).cpu()
-        return list(imgs.unbind(0))
+        imgs = [((x + 1) * 0.5).cpu()] if keep == "last" else list(((hist + 1) * 0.5).cpu().unbind(0))
+        net = _unwrap_conditional(model)[0]
+        if isinstance(net, Unet):
+            net.check_handoffs()   # the copies above have waited for the chain
+        return imgs
 
     @torch.no_grad()
     def sample(self, model, shape, device=None, **kwargs):

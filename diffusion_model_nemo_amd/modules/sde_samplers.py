@@ -189,6 +189,8 @@ class PredictorCorrectorSampler(torch.nn.Module):
             out = [((final + 1.0) * 0.5).cpu()] * (1 if keep == "last" else sde.N)
         else:
             out = list(((hist + 1.0) * 0.5).cpu().unbind(0))
+        if not return_device_tensor and hasattr(model, "check_handoffs"):
+            model.check_handoffs()   # the copies above have waited for the chain
         return (out, nfe) if return_nfe else out
 
     def sample(self, model, shape, device=None, return_nfe: bool = False, **kwargs):

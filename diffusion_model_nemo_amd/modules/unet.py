@@ -188,6 +188,21 @@ class Unet(nn.Module):
                 N.check(N.lib().dmn_unet_set_plan_batch(self._handle, self._plan_batch))
         return self
 
+    def handoff_giveups(self) -> int:
+        """Bounded waits of the in-launch GroupNorm hand-offs that ran out since the handle was created (synchronises
+        the device). Anything but 0 means an evaluation used incomplete statistics."""
+        if self._handle is None:
+            return 0
+        n = C.c_uint()
+        with torch.cuda.device(self._handle_device):
+            N.check(N.lib().dmn_unet_handoff_giveups(self._handle, C.byref(n)))
+        return int(n.value)
+
+    def check_handoffs(self):
+        n = self.handoff_giveups()
+        if n:
+            raise RuntimeError(f"{n} in-launch GroupNorm hand-offs timed out: the last results are invalid")
+
     def _device(self) -> torch.device:
         dev = self.init_conv.weight.device
         if dev.type != "cuda":

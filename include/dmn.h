@@ -71,6 +71,14 @@ int dmn_unet_set_class_labels(DmnUnet* u, const int64_t* labels);
  * Workspace sizes depend on it: set it before dmn_unet_workspace_bytes. No counterpart in the reference. */
 int dmn_unet_set_plan_batch(DmnUnet* u, int batch);
 
+/* A ResnetBlock's closing SiLU(GroupNorm(h)) + res (parts/convnext.py:85-86) is computed by the block's second
+ * convolution itself: the workgroups of an image exchange their GroupNorm partial sums inside the launch through a
+ * device area the handle owns (allocated by dmn_unet_workspace_bytes / dmn_sample_workspace_bytes for the largest shape
+ * asked about; a shape never asked about runs the separate closing passes instead). The waits are bounded (0.5 s); one
+ * that runs out is counted and the evaluation's result is invalid. Returns the count since the handle was created;
+ * waits for the device. No counterpart in the reference. */
+int dmn_unet_handoff_giveups(DmnUnet* u, unsigned* count);
+
 /* eps = Unet(x, t).  t: [B] int64 (t_is_float = 0) or float32 (1), device memory. out: [B][out_dim][H][W]. */
 int dmn_unet_forward(DmnUnet* u, const float* x, const void* t, int t_is_float, float* out, int B, int H, int W,
                      void* workspace, size_t workspace_bytes, void* stream);
@@ -262,6 +270,15 @@ int dmn_test_conv2d(int dtype, const void* in0, const void* in1, int C0, int C1,
                     const void* res, const float* pro_gamma_host, const float* pro_beta_host, const float* pro_tbias_dev,
                     const float* pro_stats_dev, int pro_G, int pro_slots, int pro_silu, float* epi_stats_dev, int epi_G,
                     int* epi_slots_out, int cfg_tile, int cfg_bn, void* stream);
+/* block2.proj of a ResnetBlock with the block's closing SiLU(GroupNorm(h)) + res (parts/convnext.py:81-86) on
+ * caller-provided device tensors: fused = 1 in one launch (partial sums exchanged inside it), fused = 0 as the
+ * convolution followed by the separate closing pass (h2: its intermediate). Both forms give the same bits in `out`. */
+int dmn_test_conv_block_tail(int dtype, const void* in, int Cin, int B, int H, int W, const float* w_host,
+                             const float* bias_host, int Cout, const float* pro_gamma_host, const float* pro_beta_host,
+                             const float* pro_stats_dev, int pro_G, int pro_slots, const float* tail_gamma_host,
+                             const float* tail_beta_host, int G, const void* res, void* h2, void* out, float* out_stats_dev,
+                             int out_G, int* out_slots, int fused, int plan_B, int cfg_tile, int cfg_bn, unsigned* giveups,
+                             void* stream);
 
 #ifdef __cplusplus
 }

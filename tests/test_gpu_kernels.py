@@ -294,3 +294,59 @@ def test_training_attention_core_forward_and_backward_match_autograd(n, adt, bf1
         err = float((got.double().cpu() - want).abs().max())
         scale = float(want.abs().max())
         assert err <= tol * scale, (name, n, adt, bf16, err, scale)
+
+
+def _block_tail(dtype, B, H, W, C_, G, out_G, fused, plan_B=64, tile=0, bn=0, seed=3):
+    """block2.proj + closing SiLU(GroupNorm(h)) + res through the C-ABI hook; returns (out NCHW fp32, statistics of out
+    summed over the partial slots [B][out_G][2], give-ups of the hand-off)."""
+    N = _N()
+    lib = N.lib()
+    tdt = torch.bfloat16 if dtype == 1 else torch.float32
+    x, res = rnd((B, C_, H, W), seed), rnd((B, C_, H, W), seed + 1)
+    w = rnd((C_, C_, 3, 3), seed + 2, (1.0 / (9 * C_)) ** 0.5).numpy().astype(np.float32)
+    bias = rnd((C_,), seed + 3).numpy().astype(np.float32)
+    pg, pb = (1.0 + 0.1 * rnd((C_,), seed + 4)).numpy().astype(np.float32), (0.1 * rnd((C_,), seed + 5)).numpy().astype(np.float32)
+    tg, tb = (1.0 + 0.1 * rnd((C_,), seed + 6)).numpy().astype(np.float32), (0.1 * rnd((C_,), seed + 7)).numpy().astype(np.float32)
+    dx, dres = to_dev_nhwc(x, dtype), to_dev_nhwc(res, dtype)
+    xs = dx.float().view(B, H * W, G, C_ // G)
+    pst = torch.stack([xs.sum((1, 3)), (xs * xs).sum((1, 3))], -1).view(B, G, 1, 2).contiguous()   # statistics of the input, one slot
+    out = torch.zeros((B, H, W, C_), device="cuda", dtype=tdt)
+    h2 = torch.zeros_like(out)
+    ost = torch.zeros((B * out_G * 4096 * 2,), device="cuda")
+    slots, give = C.c_int(0), C.c_uint(0)
+    N.check(lib.dmn_test_conv_block_tail(
+        dtype, dx.data_ptr(), C_, B, H, W, w.ctypes.data, bias.ctypes.data, C_, pg.ctypes.data, pb.ctypes.data, pst.data_ptr(), G, 1,
+        tg.ctypes.data, tb.ctypes.data, G, dres.data_ptr(), h2.data_ptr(), out.data_ptr(), ost.data_ptr(), out_G, C.byref(slots),
+        fused, plan_B, tile, bn, C.byref(give), None))
+    torch.cuda.synchronize()
+    n = slots.value
+    return out, ost[:B * out_G * n * 2].view(B, out_G, n, 2).sum(2).cpu(), give.value
+
+
+@pytest.mark.parametrize("dtype", [1, 0])
+@pytest.mark.parametrize("B,H,W,C_,G,out_G,tile,bn", [
+    (5, 64, 64, 32, 8, 1, 0, 0),      # full resolution: 16 workgroups per image exchange 8 groups
+    (3, 64, 64, 32, 8, 8, 0, 0),      # the last block of the network: statistics of the output in 8 groups
+    (6, 32, 32, 64, 8, 1, 0, 0),      # 16x16 tiles, 64 channels per workgroup
+    (6, 32, 32, 64, 4, 1, 8, 32),     # forced 8x8 tiles / 32 channels: a group spread over tiles and channel slices
+    (7, 16, 16, 128, 8, 1, 0, 0),
+    (9, 8, 8, 256, 8, 1, 0, 0),       # one workgroup holds whole groups: no exchange
+    (9, 8, 8, 256, 4, 1, 0, 0),       # groups of 64 channels = the channel tile
+    (4, 8, 8, 256, 2, 1, 0, 0),       # groups of 128 channels: two workgroups per group
+    (3, 24, 40, 64, 8, 1, 0, 0),      # ragged tiles
+    (2, 128, 128, 32, 8, 1, 0, 0),    # 64 partial sums per group: the hand-off's maximum
+])
+def test_block_tail_inside_the_convolution_equals_the_two_launch_form(dtype, B, H, W, C_, G, out_G, tile, bn):
+    """The ResnetBlock tail computed by block2.proj itself (GroupNorm partial sums exchanged between the workgroups of
+    the launch) gives the bits of the convolution followed by the separate closing pass, and statistics of the output
+    that agree to summation order; repeated launches agree with themselves (no stale partial sum is ever read)."""
+    a, sa, give = _block_tail(dtype, B, H, W, C_, G, out_G, 1, tile=tile, bn=bn)
+    b, sb, _ = _block_tail(dtype, B, H, W, C_, G, out_G, 0, tile=tile, bn=bn)
+    assert give == 0
+    assert torch.equal(a, b), float((a.float() - b.float()).abs().max())
+    assert float((sa - sb).abs().max()) <= 1e-5 * float(sb.abs().max())
+    want = torch.stack([a.float().sum((1, 2)).view(B, out_G, -1).sum(2), (a.float() ** 2).sum((1, 2)).view(B, out_G, -1).sum(2)], -1).cpu()
+    assert float((sa - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    for _ in range(5):
+        again, _, give = _block_tail(dtype, B, H, W, C_, G, out_G, 1, tile=tile, bn=bn)
+        assert give == 0 and torch.equal(again, a)
