@@ -173,6 +173,13 @@ struct LinAttnFusedArgs {
     int slice1, splits;   // pass 1: workgroup slice in pixels (multiple of 32)
     int tpw, slices;      // pass 2: workgroup slice = 64*tpw pixels
     long long* dbg;       // optional phase timestamps [2][workgroups][8] (tuning aid; nullptr in production)
+    // Fused closing (tail.gran != nullptr): out = GroupNorm(1)(y) * gamma + beta + x with the image's partial sums
+    // exchanged inside the second launch; y and y_stats are then unused.
+    HandoffArgs tail;
+    const float* tail_gamma;   // [C]
+    const float* tail_beta;
+    float tail_inv_count;      // 1 / (n * C)
+    void* out;                 // [B][n][C]
 };
 bool linattn_fused_supported(int C, int heads, int dim_head);
 void linattn_fused_plan(int n, int B, int C, int dtype, int* slice1, int* splits, int* tpw, int* slices);

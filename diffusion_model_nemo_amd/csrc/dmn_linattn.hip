@@ -15,6 +15,7 @@
 // (bf16) or one tile (f32) form the 16-byte operand fragment of the next MFMA whose k dimension is the tile's
 // row index, in the k order  pos -> 4*(pos>>3) + (pos&3) + 16*((pos>>2)&1)  (bf16; identity for f32). The
 // other operand of that MFMA (ctx^T rows, Wout columns) is stored in the same order.
+#include "dmn_handoff.h"
 #include "dmn_kernels.h"
 #include "dmn_norm.h"
 
@@ -368,7 +369,10 @@ __global__ void __launch_bounds__(256) la_merge_kernel(const LinAttnFusedArgs a)
 //   phase A  wave h = head h:  Q_h = Wq_h x  ->  softmax over d  ->  out_h = ctx_h^T q_h  ->  LDS (k-major rows)
 //   phase B  waves split the output-channel tiles:  y = Wout out + bias  ->  store + statistics
 // ------------------------------------------------------------------------------------------------------------
-template <typename T, int C>
+// TAIL: the launch also closes the attention -- out = GroupNorm(1)(y) + x (parts/mha.py:41-42, utils.py:73-74). y stays
+//   in the workgroup's LDS (in the rows of the staged pixels it was computed from) while the image's workgroups exchange
+//   their partial sums inside the launch (dmn_handoff.h); neither y nor a closing pass over it exists.
+template <typename T, int C, bool TAIL>
 __global__ void __launch_bounds__(256) la_fused_out_kernel(const LinAttnFusedArgs a) {
     constexpr int PER = ElemTraits<T>::kPer16B;
     constexpr int KCH = ElemTraits<T>::kChunk;
@@ -574,13 +578,19 @@ __global__ void __launch_bounds__(256) la_fused_out_kernel(const LinAttnFusedArg
                         ssum += v[r];
                         ssq += v[r] * v[r];
                     }
+                    // TAIL: y replaces the staged pixel it came from (every wave is done with the group's rows of sX
+                    // since the barrier between the phases)
+                    char* yl = sX + (size_t)(g * 64 + (ptb + pt) * 16 + l15) * row_bytes + c * sizeof(T);
                     if constexpr (sizeof(T) == 4) {
-                        store_stream(reinterpret_cast<f32x4*>(yout + (size_t)px * C + c), f32x4{v[0], v[1], v[2], v[3]});
+                        const f32x4 ov = f32x4{v[0], v[1], v[2], v[3]};
+                        if constexpr (TAIL) *reinterpret_cast<f32x4*>(yl) = ov;
+                        else store_stream(reinterpret_cast<f32x4*>(yout + (size_t)px * C + c), ov);
                     } else {
                         bf16x4 ov;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) ov[r] = (__bf16)v[r];
-                        store_stream(reinterpret_cast<bf16x4*>(yout + (size_t)px * C + c), ov);
+                        if constexpr (TAIL) *reinterpret_cast<bf16x4*>(yl) = ov;
+                        else store_stream(reinterpret_cast<bf16x4*>(yout + (size_t)px * C + c), ov);
                     }
                 }
             }
@@ -596,15 +606,99 @@ __global__ void __launch_bounds__(256) la_fused_out_kernel(const LinAttnFusedArg
         sRed[2 * wave + 1] = ssq;
     }
     __syncthreads();
-    if (tid == 0) {
-        float s = 0.f, ss = 0.f;
-        for (int w = 0; w < 4; ++w) {
-            s += sRed[2 * w];
-            ss += sRed[2 * w + 1];
+    if constexpr (!TAIL) {
+        if (tid == 0) {
+            float s = 0.f, ss = 0.f;
+            for (int w = 0; w < 4; ++w) {
+                s += sRed[2 * w];
+                ss += sRed[2 * w + 1];
+            }
+            float* dst = a.y_stats + ((size_t)b * gridDim.x + blockIdx.x) * 2;
+            dst[0] = s;
+            dst[1] = ss;
         }
-        float* dst = a.y_stats + ((size_t)b * gridDim.x + blockIdx.x) * 2;
-        dst[0] = s;
-        dst[1] = ss;
+    } else {
+        // ---- closing GroupNorm(1) + residual ------------------------------------------------------------------------
+        constexpr int PARTS = C / PER;                 // 16-byte units per pixel
+        constexpr int XB = 4;                          // residual units requested ahead of the wait
+        const unsigned epoch = *a.tail.epoch;
+        const int slots = gridDim.x;
+        float* sMR = sCoef + 3 * C;
+        const T* xres = static_cast<const T*>(a.x) + (size_t)b * a.n * C;
+        T* outp = static_cast<T*>(a.out) + (size_t)b * a.n * C;
+        const int rows = min(slice, a.n - p0);         // pixels of this workgroup inside the image
+        const int units = rows * PARTS;
+        V xr[XB];
+        auto x_issue = [&](int j0) {
+#pragma unroll
+            for (int j = 0; j < XB; ++j) {
+                const int u = tid + 256 * (j0 + j);
+                xr[j] = *reinterpret_cast<const V*>(xres + (size_t)(p0 + (u < units ? u / PARTS : 0)) * C + (u % PARTS) * PER);
+            }
+        };
+        x_issue(0);
+        float pgam = 0.f, pbet = 0.f;
+        if (tid < C) {
+            pgam = a.tail_gamma[tid];
+            pbet = a.tail_beta[tid];
+        }
+        if (tid == 0) {
+            float s = 0.f, ss = 0.f;
+            for (int w = 0; w < 4; ++w) {
+                s += sRed[2 * w];
+                ss += sRed[2 * w + 1];
+            }
+            if (slots > 1) {
+                unsigned long long* dst = a.tail.gran + ((size_t)b * slots + blockIdx.x) * 2;
+                granule_store(dst, epoch, s);
+                granule_store(dst + 1, epoch, ss);
+            } else {   // the arithmetic of the exchange with one slot
+                const float mean = s * a.tail_inv_count;
+                float var = ss * a.tail_inv_count - mean * mean;
+                var = var > 0.f ? var : 0.f;
+                sMR[0] = mean;
+                sMR[1] = __builtin_amdgcn_rsqf(var + 1e-5f);
+            }
+        }
+        if (slots > 1) handoff_group_stats(a.tail, epoch, b, 1, slots, 0, 1, a.tail_inv_count, sMR);
+        __syncthreads();
+        for (int c = tid; c < C; c += 256) {           // C <= 256: one channel per thread
+            const float aa = sMR[1] * pgam;
+            sCoef[c] = aa;
+            sCoef[C + c] = pbet - sMR[0] * aa;
+        }
+        __syncthreads();
+        const int part = tid % PARTS;                  // 256 % PARTS == 0: a thread keeps its channel offset
+        float ca[PER], cb[PER];
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            ca[e] = sCoef[part * PER + e];
+            cb[e] = sCoef[C + part * PER + e];
+        }
+        for (int j0 = 0; j0 * 256 < units; j0 += XB) {
+            if (j0) x_issue(j0);
+#pragma unroll
+            for (int j = 0; j < XB; ++j) {
+                const int u = tid + 256 * (j0 + j);
+                if (u < units) {
+                    const int row = u / PARTS;
+                    Vec16<T> v, r;
+                    v.v = *reinterpret_cast<const V*>(sX + (size_t)row * row_bytes + part * 16);
+                    r.v = xr[j];
+#pragma unroll
+                    for (int e = 0; e < PER; ++e) {
+                        float y;
+                        if constexpr (sizeof(T) == 2) y = __builtin_fmaf(v.get(e), ca[e], cb[e]) + 0.f;
+                        else {
+                            y = v.get(e) * ca[e] + cb[e];
+                            y += 0.f;
+                        }
+                        v.set(e, y + r.get(e));
+                    }
+                    store_stream(reinterpret_cast<V*>(outp + (size_t)(p0 + row) * C + part * PER), v.v);
+                }
+            }
+        }
     }
     LA_STAMP(dbg2, 4)
 }
@@ -625,7 +719,9 @@ int launch_pair(const LinAttnFusedArgs& a, hipStream_t s) {
     if (!attr) {
         DMN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&la_fused_ctx_kernel<T, C>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        DMN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&la_fused_out_kernel<T, C>),
+        DMN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&la_fused_out_kernel<T, C, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DMN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&la_fused_out_kernel<T, C, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
@@ -635,7 +731,8 @@ int launch_pair(const LinAttnFusedArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(la_merge_kernel<T>, dim3(a.B), dim3(256), ldsm, s, a);
         DMN_HIP_CHECK(hipGetLastError());
     }
-    hipLaunchKernelGGL((la_fused_out_kernel<T, C>), dim3(a.slices, a.B), dim3(256), lds2, s, a);
+    if (a.tail.gran) hipLaunchKernelGGL((la_fused_out_kernel<T, C, true>), dim3(a.slices, a.B), dim3(256), lds2, s, a);
+    else hipLaunchKernelGGL((la_fused_out_kernel<T, C, false>), dim3(a.slices, a.B), dim3(256), lds2, s, a);
     DMN_HIP_CHECK(hipGetLastError());
     return DMN_OK;
 }
@@ -691,6 +788,11 @@ int launch_linattn_fused(LinAttnFusedArgs& a, hipStream_t s) {
     DMN_REQUIRE(a.norm.stats && a.norm.G == 1, DMN_ERR_INVALID, "fused linear attention: GroupNorm(1) statistics of x required");
     DMN_REQUIRE(a.ctxT, DMN_ERR_INVALID, "fused linear attention: needs the merged-context buffer");
     DMN_REQUIRE(a.slices <= 65535 && a.splits <= 65535, DMN_ERR_LIMIT, "fused linear attention: image too large");
+    if (a.tail.gran)
+        DMN_REQUIRE(a.slices <= kHandoffMaxSlots && a.out && a.tail.epoch && a.tail.giveups && a.tail_gamma && a.tail_beta,
+                    DMN_ERR_INVALID, "fused linear attention: closing GroupNorm needs <= %d pixel slices, parameters and an output",
+                    kHandoffMaxSlots);
+    else DMN_REQUIRE(a.y && a.y_stats, DMN_ERR_INVALID, "fused linear attention: needs y and its statistics buffer");
     a.dbg = kernel_debug_buffer();
     if (a.dtype == DMN_F32) return launch_both<float>(a, s);
     return launch_both<__bf16>(a, s);

@@ -544,6 +544,32 @@ static Act lin_attn(Fwd& f, const AttnW& w, Act& x, LazyAttn* defer = nullptr) {
         fa.n = x.H * x.W;
         fa.C = x.C;
         linattn_fused_plan(fa.n, f.planB(), fa.C, c.dtype, &fa.slice1, &fa.splits, &fa.tpw, &fa.slices);
+        if (!defer && f.ho_enabled && !(f.u->path_mask & 256) && fa.slices <= kHandoffMaxSlots) {
+            // the second launch closes the attention itself (GroupNorm(1)(y) + x, partial sums exchanged inside the launch)
+            unsigned long long* gran = f.handoff_take((size_t)f.B * fa.slices * 2 * sizeof(unsigned long long));
+            if (gran || f.dry) {
+                Act out = f.new_act(x.C, x.H, x.W);
+                float* part = (float*)f.alloc((size_t)f.B * 4 * fa.splits * (32 * 32 + 64) * 4);
+                void* ctxT = f.alloc((size_t)f.B * 4 * 32 * 32 * f.esz());
+                if (f.dry) {   // plan for the three-launch form as well (its peak is the larger one)
+                    Act y = f.new_act(x.C, x.H, x.W);
+                    float* st = f.new_stats(1, fa.slices);
+                    f.ar.release(st);
+                    f.free_act(y);
+                }
+                fa.ctxT = ctxT;
+                fa.ctx_part = part;
+                fa.out = out.p;
+                fa.tail = f.handoff_args(gran);
+                fa.tail_gamma = w.og;
+                fa.tail_beta = w.ob;
+                fa.tail_inv_count = 1.0f / ((float)x.C * x.H * x.W);
+                if (f.ok() && !f.dry) f.run(launch_linattn_fused(fa, f.s), "fused linear attention + closing GroupNorm (in-launch statistics)");
+                f.ar.release(part);
+                f.ar.release(ctxT);
+                return out;
+            }
+        }
         Act y = f.new_act(x.C, x.H, x.W);
         y.sG = 1;
         y.sSlots = fa.slices;
@@ -808,22 +834,30 @@ int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float,
 static int pack_fragments(int dtype, const float* W, int rows, int K, bool acc_order, void** dev);
 
 // Fused linear attention on caller-provided tensors (unit parity tests, tuning). Packs + uploads the weights per call.
-extern "C" int dmn_test_linattn(int dtype, const void* x, const float* x_stats, int B, int n, int C, const float* gamma_host,
-                                const float* beta_host, const float* wqkv_host, const float* wout_host,
-                                const float* bout_host, void* y, float* y_stats, int* slices_out, void* scratch,
-                                size_t scratch_bytes, void* stream) {
-    DMN_REQUIRE(x && x_stats && y && y_stats && scratch, DMN_ERR_INVALID, "dmn_test_linattn: null argument");
-    DMN_REQUIRE(linattn_fused_supported(C, 4, 32), DMN_ERR_INVALID, "dmn_test_linattn: C=%d unsupported", C);
+// closing: 0 = stop at y = to_out(...) + bias with its statistics; 1 = out = GroupNorm(1)(y) + x computed by the second
+// launch itself (in-launch statistics hand-off); 2 = the same tensor from a separate closing pass over y.
+static int test_linattn_impl(int dtype, const void* x, const float* x_stats, int B, int n, int C, const float* gamma_host,
+                             const float* beta_host, const float* wqkv_host, const float* wout_host, const float* bout_host,
+                             void* y, float* y_stats, int* slices_out, void* scratch, size_t scratch_bytes, int closing,
+                             const float* og_host, const float* ob_host, void* out, unsigned* giveups, hipStream_t stream) {
     LinAttnFusedArgs fa;
     memset(&fa, 0, sizeof(fa));
-    void *fq = nullptr, *fk = nullptr, *fv = nullptr, *fo = nullptr;
-    float *g = nullptr, *bt = nullptr, *bo = nullptr;
+    void *fq = nullptr, *fk = nullptr, *fv = nullptr, *fo = nullptr, *ctxT = nullptr, *area = nullptr;
+    float *g = nullptr, *bt = nullptr, *bo = nullptr, *og = nullptr, *ob = nullptr;
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(stream);
+        void* fr[] = {fq, fk, fv, fo, g, bt, bo, og, ob, ctxT, area};
+        for (void* q : fr)
+            if (q) (void)hipFree(q);
+    };
     int rc;
-    if ((rc = pack_fragments(dtype, wqkv_host, 128, C, false, &fq))) return rc;
-    if ((rc = pack_fragments(dtype, wqkv_host + (size_t)128 * C, 128, C, false, &fk))) return rc;
-    if ((rc = pack_fragments(dtype, wqkv_host + (size_t)256 * C, 128, C, false, &fv))) return rc;
-    if ((rc = pack_fragments(dtype, wout_host, C, 128, false, &fo))) return rc;
-    if ((rc = upload_f32(gamma_host, C, &g)) || (rc = upload_f32(beta_host, C, &bt)) || (rc = upload_f32(bout_host, C, &bo))) return rc;
+    if ((rc = pack_fragments(dtype, wqkv_host, 128, C, false, &fq)) || (rc = pack_fragments(dtype, wqkv_host + (size_t)128 * C, 128, C, false, &fk)) ||
+        (rc = pack_fragments(dtype, wqkv_host + (size_t)256 * C, 128, C, false, &fv)) || (rc = pack_fragments(dtype, wout_host, C, 128, false, &fo)) ||
+        (rc = upload_f32(gamma_host, C, &g)) || (rc = upload_f32(beta_host, C, &bt)) || (rc = upload_f32(bout_host, C, &bo)) ||
+        (closing && ((rc = upload_f32(og_host, C, &og)) || (rc = upload_f32(ob_host, C, &ob))))) {
+        cleanup();
+        return rc;
+    }
     fa.dtype = dtype;
     fa.x = x;
     fa.y = y;
@@ -838,18 +872,79 @@ extern "C" int dmn_test_linattn(int dtype, const void* x, const float* x_stats, 
     fa.B = B; fa.n = n; fa.C = C;
     linattn_fused_plan(n, B, C, dtype, &fa.slice1, &fa.splits, &fa.tpw, &fa.slices);
     const size_t need = (size_t)B * 4 * fa.splits * (32 * 32 + 64) * 4;
-    DMN_REQUIRE(scratch_bytes >= need, DMN_ERR_WORKSPACE, "dmn_test_linattn: scratch %zu < %zu", scratch_bytes, need);
+    if (scratch_bytes < need || hipMalloc(&ctxT, (size_t)B * 4 * 32 * 32 * 4) != hipSuccess) {
+        cleanup();
+        dmn_set_error("dmn_test_linattn: scratch %zu < %zu, or allocation failed", scratch_bytes, need);
+        return DMN_ERR_WORKSPACE;
+    }
     fa.ctx_part = (float*)scratch;
     fa.y_stats = y_stats;
     if (slices_out) *slices_out = fa.slices;
-    void* ctxT = nullptr;
-    DMN_HIP_CHECK(hipMalloc(&ctxT, (size_t)B * 4 * 32 * 32 * 4));
     fa.ctxT = ctxT;
-    rc = launch_linattn_fused(fa, (hipStream_t)stream);
-    (void)hipStreamSynchronize((hipStream_t)stream);
-    void* fr[] = {fq, fk, fv, fo, g, bt, bo, ctxT};
-    for (void* q : fr) (void)hipFree(q);
+    if (giveups) *giveups = 0;
+    if (closing == 1) {
+        const size_t bytes = kHandoffHeaderBytes + (size_t)B * fa.slices * 16;
+        unsigned hdr[2] = {1u, 0u};   // epoch 1 over a zeroed area
+        if (hipMalloc(&area, bytes) != hipSuccess || hipMemset(area, 0, bytes) != hipSuccess ||
+            hipMemcpy(area, hdr, sizeof(hdr), hipMemcpyHostToDevice) != hipSuccess) {
+            cleanup();
+            return DMN_ERR_HIP;
+        }
+        fa.tail.gran = reinterpret_cast<unsigned long long*>((char*)area + kHandoffHeaderBytes);
+        fa.tail.epoch = reinterpret_cast<const unsigned*>(area);
+        fa.tail.giveups = reinterpret_cast<unsigned*>(area) + 1;
+        fa.tail_gamma = og;
+        fa.tail_beta = ob;
+        fa.tail_inv_count = 1.0f / ((float)C * n);
+        fa.out = out;
+    }
+    rc = launch_linattn_fused(fa, stream);
+    if (rc == DMN_OK && closing == 2) {
+        NormApplyArgs na;
+        memset(&na, 0, sizeof(na));
+        na.dtype = dtype;
+        na.in = y;
+        na.out = out;
+        na.res = x;
+        na.B = B;
+        na.HW = n;
+        na.C = C;
+        na.norm.stats = y_stats;
+        na.norm.G = 1;
+        na.norm.slots = fa.slices;
+        na.norm.inv_count = 1.0f / ((float)C * n);
+        na.norm.gamma = og;
+        na.norm.beta = ob;
+        rc = launch_norm_apply(na, stream);
+    }
+    (void)hipStreamSynchronize(stream);
+    if (giveups && area) (void)hipMemcpy(giveups, (char*)area + 4, 4, hipMemcpyDeviceToHost);
+    cleanup();
     return rc;
+}
+
+extern "C" int dmn_test_linattn(int dtype, const void* x, const float* x_stats, int B, int n, int C, const float* gamma_host,
+                                const float* beta_host, const float* wqkv_host, const float* wout_host,
+                                const float* bout_host, void* y, float* y_stats, int* slices_out, void* scratch,
+                                size_t scratch_bytes, void* stream) {
+    DMN_REQUIRE(x && x_stats && y && y_stats && scratch, DMN_ERR_INVALID, "dmn_test_linattn: null argument");
+    DMN_REQUIRE(linattn_fused_supported(C, 4, 32), DMN_ERR_INVALID, "dmn_test_linattn: C=%d unsupported", C);
+    return test_linattn_impl(dtype, x, x_stats, B, n, C, gamma_host, beta_host, wqkv_host, wout_host, bout_host, y, y_stats,
+                             slices_out, scratch, scratch_bytes, 0, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream);
+}
+
+// The whole Residual(PreNorm(LinearAttention)) block (utils.py:68-93, parts/mha.py:44-59): out = GroupNorm(1)(y) + x behind
+// the fused attention, fused = 1 inside its second launch, fused = 0 as a separate closing pass over y (same bits).
+extern "C" int dmn_test_linattn_block(int dtype, const void* x, const float* x_stats, int B, int n, int C, const float* gamma_host,
+                                      const float* beta_host, const float* wqkv_host, const float* wout_host,
+                                      const float* bout_host, const float* out_gamma_host, const float* out_beta_host, void* y,
+                                      float* y_stats, void* out, void* scratch, size_t scratch_bytes, int fused,
+                                      unsigned* giveups, void* stream) {
+    DMN_REQUIRE(x && x_stats && y && y_stats && out && scratch && out_gamma_host && out_beta_host, DMN_ERR_INVALID,
+                "dmn_test_linattn_block: null argument");
+    DMN_REQUIRE(linattn_fused_supported(C, 4, 32), DMN_ERR_INVALID, "dmn_test_linattn_block: C=%d unsupported", C);
+    return test_linattn_impl(dtype, x, x_stats, B, n, C, gamma_host, beta_host, wqkv_host, wout_host, bout_host, y, y_stats, nullptr,
+                             scratch, scratch_bytes, fused ? 1 : 2, out_gamma_host, out_beta_host, out, giveups, (hipStream_t)stream);
 }
 
 // Times the kernel that dominates a denoising step -- the level-0 3x3 convolution with the fused GroupNorm +

@@ -245,6 +245,13 @@ int dmn_fill_normal(float* x, int B, int per, uint64_t seed, uint32_t step, int6
 int dmn_test_linattn(int dtype, const void* x, const float* x_stats, int B, int n, int C, const float* gamma_host,
                      const float* beta_host, const float* wqkv_host, const float* wout_host, const float* bout_host,
                      void* y, float* y_stats, int* slices_out, void* scratch, size_t scratch_bytes, void* stream);
+/* The whole Residual(PreNorm(LinearAttention)) block (utils.py:68-93, parts/mha.py:44-59): out = GroupNorm(1)(y) + x
+ * behind the fused attention; fused = 1 inside the attention's second launch (partial sums exchanged within it),
+ * fused = 0 as a separate pass over y. Both forms give the same bits in `out`. */
+int dmn_test_linattn_block(int dtype, const void* x, const float* x_stats, int B, int n, int C, const float* gamma_host,
+                           const float* beta_host, const float* wqkv_host, const float* wout_host, const float* bout_host,
+                           const float* out_gamma_host, const float* out_beta_host, void* y, float* y_stats, void* out,
+                           void* scratch, size_t scratch_bytes, int fused, unsigned* giveups, void* stream);
 /* Softmax attention core (parts/mha.py:21-28: scale, q k^T, row maximum, softmax, attn v) on qkv [B][n][3 * heads * 32]
  * (channels q | k | v, each head-major) -> out [B][n][heads * 32], both in the internal dtype. 64 <= n <= 256 with
  * n % 64 == 0 runs on the matrix cores, other sizes on the vector units. */

@@ -350,3 +350,48 @@ def test_block_tail_inside_the_convolution_equals_the_two_launch_form(dtype, B, 
     for _ in range(5):
         again, _, give = _block_tail(dtype, B, H, W, C_, G, out_G, 1, tile=tile, bn=bn)
         assert give == 0 and torch.equal(again, a)
+
+
+@pytest.mark.parametrize("dtype", [1, 0])
+@pytest.mark.parametrize("B,side_h,side_w,cch", [
+    (5, 64, 64, 32),     # 16 pixel slices per image exchange their sums
+    (6, 32, 32, 64), (7, 16, 16, 128),
+    (9, 8, 8, 256),      # one workgroup per image: no exchange
+    (3, 24, 40, 64),     # last slice ragged
+    (2, 64, 64, 32),     # a small batch is cut into 64 slices per image: the hand-off's maximum
+])
+def test_linear_attention_closed_inside_its_second_launch_equals_the_separate_pass(dtype, B, side_h, side_w, cch):
+    """Residual(PreNorm(LinearAttention)) with the closing GroupNorm(1)(y) + x computed by the attention's second launch
+    (partial sums exchanged between the workgroups of the launch) gives the bits of the separate closing pass over y;
+    repeated launches agree with themselves."""
+    N = _N()
+    lib = N.lib()
+    n = side_h * side_w
+    x = rnd((B, cch, side_h, side_w), 21)
+    arr = lambda t: np.ascontiguousarray(t.numpy(), dtype=np.float32)   # noqa: E731
+    gamma, beta = arr(1.0 + 0.1 * rnd((cch,), 22)), arr(0.1 * rnd((cch,), 23))
+    og, ob = arr(1.0 + 0.1 * rnd((cch,), 24)), arr(0.1 * rnd((cch,), 25))
+    wqkv, wout, bout = arr(rnd((384, cch), 26, cch ** -0.5) * 2.0), arr(rnd((cch, 128), 27, 128 ** -0.5)), arr(0.1 * rnd((cch,), 28))
+    xd = to_dev_nhwc(x, dtype)
+    xq = xd.float()
+    xs = torch.stack([xq.sum((1, 2, 3)), (xq * xq).sum((1, 2, 3))], 1).contiguous()
+    scratch = torch.zeros((B * 4 * ((n + 31) // 32) * 1088,), device="cuda")
+
+    def run(fused):
+        y = torch.zeros_like(xd)
+        out = torch.zeros_like(xd)
+        ystats = torch.zeros((B * 1024 * 2,), device="cuda")
+        give = C.c_uint(0)
+        N.check(lib.dmn_test_linattn_block(dtype, xd.data_ptr(), xs.data_ptr(), B, n, cch, gamma.ctypes.data, beta.ctypes.data,
+                                           wqkv.ctypes.data, wout.ctypes.data, bout.ctypes.data, og.ctypes.data, ob.ctypes.data,
+                                           y.data_ptr(), ystats.data_ptr(), out.data_ptr(), scratch.data_ptr(), scratch.numel() * 4,
+                                           fused, C.byref(give), None))
+        torch.cuda.synchronize()
+        assert give.value == 0
+        return out
+
+    a, b = run(1), run(0)
+    assert torch.isfinite(a.float()).all() and float(a.float().abs().max()) > 0.5
+    assert torch.equal(a, b), float((a.float() - b.float()).abs().max())
+    for _ in range(5):
+        assert torch.equal(run(1), a)
