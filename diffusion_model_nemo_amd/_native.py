@@ -77,7 +77,7 @@ SIGNATURES = {
     "dmn_test_unet_trace_poison": (_i, [_vp, C.c_uint32]),
     "dmn_test_unet_trace_name": (C.c_char_p, [_vp, _i]),
     "dmn_test_set_conv_debug": (_i, [_vp]),
-    "dmn_test_linattn_block": (_i, [_i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i,
+    "dmn_test_linattn_block": (_i, [_i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i,
                                     C.POINTER(C.c_uint), _vp]),
     "dmn_test_linattn": (_i, [_i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i), _vp, _sz, _vp]),
     "dmn_test_conv_block_tail": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp,

@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
     const int tiles_x = (a.Wo + TW - 1) / TW;
     const int tile_y = blockIdx.x / tiles_x, tile_x = blockIdx.x % tiles_x;
     const int n0 = blockIdx.y * BN;
-    const int b = blockIdx.z / a.nphase, ph = blockIdx.z % a.nphase;
+    const int b = a.b_first + blockIdx.z / a.nphase, ph = blockIdx.z % a.nphase;
     const ConvPhase P = a.phase[ph];
     const int iy0 = tile_y * TH * S - P.pad_y, ix0 = tile_x * TW * S - P.pad_x;
     const int Cin = a.C0 + a.C1;
@@ -642,7 +642,7 @@ struct TileCfg {
 template <typename T, int KIND, int TH, int TW, int BN, int WM, int WN, int PRO, bool RES = false, bool TAIL = false>
 int launch_cfg(const ConvArgs& a, size_t lds, hipStream_t s) {
     const int tiles = ((a.Ho + TH - 1) / TH) * ((a.Wo + TW - 1) / TW);
-    dim3 grid(tiles, a.Cout / BN, a.B * a.nphase);
+    dim3 grid(tiles, a.Cout / BN, a.b_count * a.nphase);
     hipLaunchKernelGGL((conv_igemm_kernel<T, KIND, TH, TW, BN, WM, WN, PRO, RES, TAIL>), grid, dim3(256), lds, s, a);
     DMN_HIP_CHECK(hipGetLastError());
     return DMN_OK;
@@ -864,8 +864,20 @@ static int slots_for_groups(const ConvArgs& a, int G) {
 }
 int conv_epi_slots(const ConvArgs& a) { return slots_for_groups(a, a.epi.G); }
 int conv_tail_slots(const ConvArgs& a) { return slots_for_groups(a, a.tail_stats.G); }
+// workgroups of one image in the launch
+static int wgs_per_image(const ConvArgs& a) {
+    const TileCfg c = pick_cfg(a);
+    return ((a.Ho + c.th - 1) / c.th) * ((a.Wo + c.tw - 1) / c.tw) * (a.Cout / c.bn) * a.nphase;
+}
 bool conv_tail_fits(const ConvArgs& a) {
-    return a.epi.G >= 1 && a.epi.G <= kHandoffMaxGroups && conv_epi_slots(a) <= kHandoffMaxSlots;
+    if (a.epi.G < 1 || a.epi.G > kHandoffMaxGroups) return false;
+    const int slots = conv_epi_slots(a);
+    if (slots == 1) return true;   // every group lies inside one workgroup: nothing is exchanged, nothing waits
+    ConvArgs t = a;
+    t.pro.stats = t.pro.stats ? t.pro.stats : reinterpret_cast<const float*>(1);   // the tail rides on the prologue kernel
+    const TileCfg c = pick_cfg(t);
+    return slots <= kHandoffMaxSlots && wgs_per_image(a) <= kHandoffMaxWgsPerImage &&
+           lds_bytes(t, c, pick_cg(t, c)) <= (size_t)kHandoffMaxLdsBytes;
 }
 
 int launch_conv(ConvArgs& a, hipStream_t s) {
@@ -912,6 +924,17 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
     if (a.pro.stats) DMN_REQUIRE(Cin <= 1024, DMN_ERR_LIMIT, "conv: input normalisation limited to 1024 channels");
     const size_t lds = lds_bytes(a, c, a.cg);
     DMN_REQUIRE(lds <= 160 * 1024, DMN_ERR_INVALID, "conv: LDS request %zu too large", lds);
-    if (a.dtype == DMN_F32) return dispatch<float>(a, c, lds, s);
-    return dispatch<__bf16>(a, c, lds, s);
+    // a launch whose workgroups wait for each other stays small enough to be resident as a whole (dmn_handoff.h)
+    int per_launch = a.B;
+    if (a.tail.gran && a.epi.slots > 1) {
+        per_launch = kHandoffMaxWgsPerLaunch / wgs_per_image(a);
+        if (per_launch < 1) per_launch = 1;
+    }
+    for (int b0 = 0; b0 < a.B; b0 += per_launch) {
+        a.b_first = b0;
+        a.b_count = a.B - b0 < per_launch ? a.B - b0 : per_launch;
+        const int rc = a.dtype == DMN_F32 ? dispatch<float>(a, c, lds, s) : dispatch<__bf16>(a, c, lds, s);
+        if (rc) return rc;
+    }
+    return DMN_OK;
 }

@@ -14,10 +14,17 @@
 // epochs that grow, so a tag equal to the current epoch can only have been written by the current evaluation; every
 // fused launch of an evaluation owns a distinct range of the area.
 //
-// Progress: the workgroups of an image are consecutive in launch order (blockIdx.z = image), each publishes BEFORE it
-// waits, and a waiting workgroup only needs workgroups of its own image, of which there are at most a few dozen; the
-// spins are bounded all the same (kHandoffSpinTicks of the 100 MHz clock), a give-up is counted in the area's
-// header and surfaces as an error at the next host check, never as a hang.
+// Progress: a waiting workgroup keeps its place on the CU, so a wait can only end if the workgroups it waits for get a
+// place too. One launch alone is safe (the workgroups of an image are consecutive in launch order and publish BEFORE
+// they wait), but two such launches on two streams can starve each other once waiters of both fill the machine
+// (measured: about one stalled step in 3000 with two 512-workgroup launches in flight). Therefore every launch that
+// exchanges is small enough for ALL its workgroups to be resident beside all those of a second such launch: at most
+// kHandoffMaxWgsPerLaunch workgroups, each needing at most half a CU (80 KiB of LDS; 256 threads never need more than
+// half the registers). Hosts split the batch over several launches to stay below that, and leave shapes with more than
+// kHandoffMaxWgsPerImage workgroups per image to the multi-launch forms. More than two exchanging launches at once
+// (several handles sampling concurrently on one GPU) are outside this guarantee; the spins are bounded all the same
+// (kHandoffSpinTicks of the 100 MHz clock), a give-up is counted in the area's header and surfaces as an error at the
+// next host check, never as a hang.
 #pragma once
 #include "dmn_common.h"
 
@@ -27,6 +34,9 @@ constexpr int kHandoffHeaderBytes = 256;           // word 0: epoch, word 1: spi
 constexpr long long kHandoffSpinTicks = 50000000;  // 0.5 s of the 100 MHz wall clock
 constexpr int kHandoffMaxSlots = 64;               // partial sums per (image, group): one per lane of a wave
 constexpr int kHandoffMaxGroups = 32;
+constexpr int kHandoffMaxWgsPerLaunch = 256;       // one per CU: two such launches are resident together
+constexpr int kHandoffMaxWgsPerImage = 8;          // 32 images (half of the planning batch) per launch
+constexpr int kHandoffMaxLdsBytes = 80 * 1024;     // half a CU
 
 // Host view of a fused tail's statistics hand-off (kernel argument).
 struct HandoffArgs {
@@ -69,6 +79,20 @@ __device__ __forceinline__ void handoff_group_stats(const HandoffArgs& h, unsign
             if (__all(ok)) break;
             if (wall_clock64() - t0 > kHandoffSpinTicks) {   // wave-uniform: every lane reads the same clock region
                 if (lane == 0) atomicAdd(h.giveups, 1u);
+                // diagnosis: the first lane that still misses a granule describes it in words 2..9 of the header
+                if (!ok && atomicCAS(h.giveups + 1, 0u, 1u) == 0u) {
+                    unsigned* d = h.giveups + 2;
+                    d[0] = epoch;
+                    d[1] = (unsigned)(va >> 32);
+                    d[2] = (unsigned)(vb >> 32);
+                    d[3] = (unsigned)b;
+                    d[4] = (unsigned)(g_first + gl);
+                    d[5] = (unsigned)sl;
+                    d[6] = (unsigned)slots;
+                    d[7] = (blockIdx.x << 16) | (blockIdx.y << 8) | (blockIdx.z & 255);
+                    d[8] = *h.epoch;
+                    d[9] = (unsigned)G;
+                }
                 break;
             }
             __builtin_amdgcn_s_sleep(4);

@@ -69,6 +69,7 @@ struct ConvArgs {
     const float* tail_beta;
     float tail_inv_count;      // 1 / elements per (image, group) of that GroupNorm
     NormOut tail_stats;        // optional statistics of `out`
+    int b_first, b_count;      // images [b_first, b_first + b_count) of the batch in this launch (set by the launcher)
     int cg, lg_upp;       // channels staged per group and log2 of its 16-byte units per pixel; set by the launcher
     long long* dbg;       // optional [workgroups][8] phase timestamps (tuning aid; nullptr in production)
     int cfg_tile, cfg_bn; // 0 = choose automatically; otherwise force the pixel tile (8 or 16) / channel tile (32 or 64)
@@ -180,7 +181,9 @@ struct LinAttnFusedArgs {
     const float* tail_beta;
     float tail_inv_count;      // 1 / (n * C)
     void* out;                 // [B][n][C]
+    int b_first, b_count;      // images of the second launch (set by the launcher)
 };
+bool linattn_tail_fits(int n, int B, int C, int dtype);   // the closing GroupNorm fits the in-launch exchange's limits
 bool linattn_fused_supported(int C, int heads, int dim_head);
 void linattn_fused_plan(int n, int B, int C, int dtype, int* slice1, int* splits, int* tpw, int* slices);
 int launch_linattn_fused(LinAttnFusedArgs& a, hipStream_t s);

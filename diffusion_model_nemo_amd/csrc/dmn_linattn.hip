@@ -395,7 +395,7 @@ __global__ void __launch_bounds__(256) la_fused_out_kernel(const LinAttnFusedArg
     char* sO = sCtx + kHeads * kD * CTX_ROW;                               // [64 px][O_ROW]
     char* sX = sO + 64 * O_ROW;
     float* sRed = reinterpret_cast<float*>(sX + (size_t)slice * row_bytes);   // 8 floats
-    const int b = blockIdx.y, tid = threadIdx.x;
+    const int b = a.b_first + blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
     const int p0 = blockIdx.x * slice;
@@ -731,9 +731,21 @@ int launch_pair(const LinAttnFusedArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(la_merge_kernel<T>, dim3(a.B), dim3(256), ldsm, s, a);
         DMN_HIP_CHECK(hipGetLastError());
     }
-    if (a.tail.gran) hipLaunchKernelGGL((la_fused_out_kernel<T, C, true>), dim3(a.slices, a.B), dim3(256), lds2, s, a);
-    else hipLaunchKernelGGL((la_fused_out_kernel<T, C, false>), dim3(a.slices, a.B), dim3(256), lds2, s, a);
-    DMN_HIP_CHECK(hipGetLastError());
+    // a second launch whose workgroups wait for each other stays small enough to be resident as a whole (dmn_handoff.h)
+    int per_launch = a.B;
+    if (a.tail.gran && a.slices > 1) {
+        DMN_REQUIRE(lds2 <= (size_t)kHandoffMaxLdsBytes && a.slices <= kHandoffMaxWgsPerImage, DMN_ERR_LIMIT,
+                    "fused linear attention: closing GroupNorm outside the in-launch exchange's limits");
+        per_launch = kHandoffMaxWgsPerLaunch / a.slices;
+    }
+    LinAttnFusedArgs c = a;
+    for (int b0 = 0; b0 < a.B; b0 += per_launch) {
+        c.b_first = b0;
+        c.b_count = a.B - b0 < per_launch ? a.B - b0 : per_launch;
+        if (a.tail.gran) hipLaunchKernelGGL((la_fused_out_kernel<T, C, true>), dim3(a.slices, c.b_count), dim3(256), lds2, s, c);
+        else hipLaunchKernelGGL((la_fused_out_kernel<T, C, false>), dim3(a.slices, c.b_count), dim3(256), lds2, s, c);
+        DMN_HIP_CHECK(hipGetLastError());
+    }
     return DMN_OK;
 }
 
@@ -778,6 +790,16 @@ void linattn_fused_plan(int n, int B, int C, int dtype, int* slice1, int* splits
     while (t > 1 && ((long long)((n + 64 * t - 1) / (64 * t)) * B < 512 || 64 * t * row > 72 * 1024)) t /= 2;
     *tpw = t;
     *slices = (n + 64 * t - 1) / (64 * t);
+}
+
+bool linattn_tail_fits(int n, int B, int C, int dtype) {
+    int slice1, splits, tpw, slices;
+    linattn_fused_plan(n, B, C, dtype, &slice1, &splits, &tpw, &slices);
+    if (slices == 1) return true;   // one workgroup per image: nothing is exchanged, nothing waits
+    const size_t esz = dtype == DMN_F32 ? 4 : 2;
+    const size_t lds2 = ((3 * C + 8) * 4 + 15) / 16 * 16 + (size_t)kHeads * kD * (kD * esz + 32) + 64 * ((size_t)kHidden * esz + 32) +
+                        (size_t)64 * tpw * (C * esz + 32) + 64;
+    return slices <= kHandoffMaxWgsPerImage && lds2 <= (size_t)kHandoffMaxLdsBytes;
 }
 
 int launch_linattn_fused(LinAttnFusedArgs& a, hipStream_t s) {

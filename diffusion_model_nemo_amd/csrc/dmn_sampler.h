@@ -49,6 +49,31 @@ struct LangevinArgs {
     int use_norms;        // 1: Langevin, 0: annealed Langevin dynamics (fixed step)
     float snr;
 };
+// One element of the DDPM / improved-DDPM / DDIM update (gaussian_diffusion.py:118-123,91-101,157-167;
+// learned_gaussian_diffusion.py:35-48; generalized_gaussian_diffusion.py:43-46,84-97): x, eps (and v, the variance
+// channel of a learned-variance network) -> x_{t-1}, with z ~ N(0,1). `tr` is the step's table row. Shared by the
+// stand-alone update kernel and the network's last kernel when it applies the update itself, so both give the same bits.
+#ifdef __HIPCC__
+__device__ __forceinline__ float ddpm_update_element(const DdpmStepArgs& a, const float* tr, float x, float eps, float v, float z) {
+    if (a.ddim) {
+        // row: 1 sqrt(1-at) 2 sqrt(at) 3 sqrt(at_next) 4 c1 5 c2. With the pred_x0 objective the reference clamps the
+        // network output in place, so the direction term uses the clamped value too.
+        float x0 = a.pred_x0 ? eps : (x - eps * tr[1]) / tr[2];
+        x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+        return tr[3] * x0 + tr[4] * z + tr[5] * (a.pred_x0 ? x0 : eps);
+    }
+    const float sra = tr[1], srm1 = tr[2], c1 = tr[3], c2 = tr[4], plv = tr[5], logb = tr[6], mask = tr[7];
+    float x0 = a.pred_x0 ? eps : sra * x - srm1 * eps;
+    x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+    const float mean = c1 * x0 + c2 * x;
+    float logvar = plv;
+    if (a.learned_variance) {
+        const float frac = (v + 1.0f) * 0.5f;
+        logvar = frac * logb + (1.0f - frac) * plv;
+    }
+    return mean + mask * expf(0.5f * logvar) * z;
+}
+#endif
 int launch_ddpm_step(const DdpmStepArgs& a, hipStream_t s);
 int launch_affine_step(const AffineStepArgs& a, hipStream_t s);
 int launch_langevin(LangevinArgs& a, hipStream_t s);

@@ -40,7 +40,6 @@ __global__ void __launch_bounds__(256) ddpm_step_kernel(const DdpmStepArgs a) {
     const int row = c.step_idx ? *c.step_idx : c.step;
     if (a.step_next && q == 0 && b == 0) *a.step_next = row + 1;
     const float* tr = c.table + (size_t)row * DMN_TABLE_COLS;
-    const float sra = tr[1], srm1 = tr[2], c1 = tr[3], c2 = tr[4], plv = tr[5], logb = tr[6], mask = tr[7];
     float z[4];
     load_noise(c, (unsigned)tr[8], 1u, b, q, per, z);
     const int mo_c = a.learned_variance ? 2 * c.C : c.C;
@@ -50,29 +49,8 @@ __global__ void __launch_bounds__(256) ddpm_step_kernel(const DdpmStepArgs a) {
         if (e >= per) break;
         const size_t xi = (size_t)b * per + e;
         const size_t mi = (size_t)b * mo_c * c.HW + e;
-        const float x = c.x[xi];
-        const float eps = c.net[mi];
-        if (a.ddim) {
-            // generalized_gaussian_diffusion.py:43-46,84-97; row: 1 sqrt(1-at) 2 sqrt(at) 3 sqrt(at_next) 4 c1 5 c2.
-            // With the pred_x0 objective the reference clamps the network output in place, so the direction term
-            // uses the clamped value too.
-            float x0 = a.pred_x0 ? eps : (x - eps * tr[1]) / tr[2];
-            x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
-            const float xn = tr[3] * x0 + tr[4] * z[r] + tr[5] * (a.pred_x0 ? x0 : eps);
-            c.x_out[xi] = xn;
-            if (c.keep) c.keep[(size_t)row * c.keep_stride + xi] = xn;
-            continue;
-        }
-        float x0 = a.pred_x0 ? eps : sra * x - srm1 * eps;
-        x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
-        const float mean = c1 * x0 + c2 * x;
-        float logvar = plv;
-        if (a.learned_variance) {
-            const float v = c.net[mi + (size_t)c.C * c.HW];
-            const float frac = (v + 1.0f) * 0.5f;
-            logvar = frac * logb + (1.0f - frac) * plv;
-        }
-        const float xn = mean + mask * expf(0.5f * logvar) * z[r];
+        const float v = a.learned_variance ? c.net[mi + (size_t)c.C * c.HW] : 0.f;
+        const float xn = ddpm_update_element(a, tr, c.x[xi], c.net[mi], v, z[r]);
         c.x_out[xi] = xn;
         if (c.keep) c.keep[(size_t)row * c.keep_stride + xi] = xn;
     }

@@ -544,7 +544,7 @@ static Act lin_attn(Fwd& f, const AttnW& w, Act& x, LazyAttn* defer = nullptr) {
         fa.n = x.H * x.W;
         fa.C = x.C;
         linattn_fused_plan(fa.n, f.planB(), fa.C, c.dtype, &fa.slice1, &fa.splits, &fa.tpw, &fa.slices);
-        if (!defer && f.ho_enabled && !(f.u->path_mask & 256) && fa.slices <= kHandoffMaxSlots) {
+        if (!defer && f.ho_enabled && !(f.u->path_mask & 256) && linattn_tail_fits(fa.n, f.planB(), fa.C, c.dtype)) {
             // the second launch closes the attention itself (GroupNorm(1)(y) + x, partial sums exchanged inside the launch)
             unsigned long long* gran = f.handoff_take((size_t)f.B * fa.slices * 2 * sizeof(unsigned long long));
             if (gran || f.dry) {
@@ -839,7 +839,7 @@ static int pack_fragments(int dtype, const float* W, int rows, int K, bool acc_o
 static int test_linattn_impl(int dtype, const void* x, const float* x_stats, int B, int n, int C, const float* gamma_host,
                              const float* beta_host, const float* wqkv_host, const float* wout_host, const float* bout_host,
                              void* y, float* y_stats, int* slices_out, void* scratch, size_t scratch_bytes, int closing,
-                             const float* og_host, const float* ob_host, void* out, unsigned* giveups, hipStream_t stream) {
+                             const float* og_host, const float* ob_host, void* out, unsigned* giveups, int plan_B, hipStream_t stream) {
     LinAttnFusedArgs fa;
     memset(&fa, 0, sizeof(fa));
     void *fq = nullptr, *fk = nullptr, *fv = nullptr, *fo = nullptr, *ctxT = nullptr, *area = nullptr;
@@ -870,7 +870,7 @@ static int test_linattn_impl(int dtype, const void* x, const float* x_stats, int
     fa.wq = fq; fa.wk = fk; fa.wv = fv; fa.wo = fo;
     fa.bias = bo;
     fa.B = B; fa.n = n; fa.C = C;
-    linattn_fused_plan(n, B, C, dtype, &fa.slice1, &fa.splits, &fa.tpw, &fa.slices);
+    linattn_fused_plan(n, plan_B > 0 ? plan_B : B, C, dtype, &fa.slice1, &fa.splits, &fa.tpw, &fa.slices);
     const size_t need = (size_t)B * 4 * fa.splits * (32 * 32 + 64) * 4;
     if (scratch_bytes < need || hipMalloc(&ctxT, (size_t)B * 4 * 32 * 32 * 4) != hipSuccess) {
         cleanup();
@@ -883,6 +883,11 @@ static int test_linattn_impl(int dtype, const void* x, const float* x_stats, int
     fa.ctxT = ctxT;
     if (giveups) *giveups = 0;
     if (closing == 1) {
+        if (!linattn_tail_fits(n, plan_B > 0 ? plan_B : B, C, dtype)) {
+            cleanup();
+            dmn_set_error("dmn_test_linattn_block: shape outside the in-launch exchange's limits");
+            return DMN_ERR_LIMIT;
+        }
         const size_t bytes = kHandoffHeaderBytes + (size_t)B * fa.slices * 16;
         unsigned hdr[2] = {1u, 0u};   // epoch 1 over a zeroed area
         if (hipMalloc(&area, bytes) != hipSuccess || hipMemset(area, 0, bytes) != hipSuccess ||
@@ -930,7 +935,7 @@ extern "C" int dmn_test_linattn(int dtype, const void* x, const float* x_stats, 
     DMN_REQUIRE(x && x_stats && y && y_stats && scratch, DMN_ERR_INVALID, "dmn_test_linattn: null argument");
     DMN_REQUIRE(linattn_fused_supported(C, 4, 32), DMN_ERR_INVALID, "dmn_test_linattn: C=%d unsupported", C);
     return test_linattn_impl(dtype, x, x_stats, B, n, C, gamma_host, beta_host, wqkv_host, wout_host, bout_host, y, y_stats,
-                             slices_out, scratch, scratch_bytes, 0, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream);
+                             slices_out, scratch, scratch_bytes, 0, nullptr, nullptr, nullptr, nullptr, 0, (hipStream_t)stream);
 }
 
 // The whole Residual(PreNorm(LinearAttention)) block (utils.py:68-93, parts/mha.py:44-59): out = GroupNorm(1)(y) + x behind
@@ -938,13 +943,13 @@ extern "C" int dmn_test_linattn(int dtype, const void* x, const float* x_stats, 
 extern "C" int dmn_test_linattn_block(int dtype, const void* x, const float* x_stats, int B, int n, int C, const float* gamma_host,
                                       const float* beta_host, const float* wqkv_host, const float* wout_host,
                                       const float* bout_host, const float* out_gamma_host, const float* out_beta_host, void* y,
-                                      float* y_stats, void* out, void* scratch, size_t scratch_bytes, int fused,
+                                      float* y_stats, void* out, void* scratch, size_t scratch_bytes, int fused, int plan_B,
                                       unsigned* giveups, void* stream) {
     DMN_REQUIRE(x && x_stats && y && y_stats && out && scratch && out_gamma_host && out_beta_host, DMN_ERR_INVALID,
                 "dmn_test_linattn_block: null argument");
     DMN_REQUIRE(linattn_fused_supported(C, 4, 32), DMN_ERR_INVALID, "dmn_test_linattn_block: C=%d unsupported", C);
     return test_linattn_impl(dtype, x, x_stats, B, n, C, gamma_host, beta_host, wqkv_host, wout_host, bout_host, y, y_stats, nullptr,
-                             scratch, scratch_bytes, fused ? 1 : 2, out_gamma_host, out_beta_host, out, giveups, (hipStream_t)stream);
+                             scratch, scratch_bytes, fused ? 1 : 2, out_gamma_host, out_beta_host, out, giveups, plan_B, (hipStream_t)stream);
 }
 
 // Times the kernel that dominates a denoising step -- the level-0 3x3 convolution with the fused GroupNorm +
@@ -1479,9 +1484,13 @@ extern "C" int dmn_unet_handoff_giveups(DmnUnet* u, unsigned* count) {
     *count = 0;
     for (int c = 0; c < 2; ++c)
         if (u->handoff_mem[c]) {
-            unsigned hdr[2] = {0, 0};
+            unsigned hdr[16] = {0};
             DMN_HIP_CHECK(hipMemcpy(hdr, u->handoff_mem[c], sizeof(hdr), hipMemcpyDeviceToHost));
             *count += hdr[1];
+            if (hdr[1] && getenv("DMN_HANDOFF_DEBUG"))
+                fprintf(stderr, "handoff chain %d: epoch now %u giveups %u; first miss: epoch %u tags %u %u image %u group %u slot %u of %u "
+                        "block %x epoch word then %u G %u\n", c, hdr[0], hdr[1], hdr[3], hdr[4], hdr[5], hdr[6], hdr[7], hdr[8], hdr[9],
+                        hdr[10], hdr[11], hdr[12]);
         }
     return DMN_OK;
 }

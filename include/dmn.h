@@ -247,11 +247,12 @@ int dmn_test_linattn(int dtype, const void* x, const float* x_stats, int B, int 
                      void* y, float* y_stats, int* slices_out, void* scratch, size_t scratch_bytes, void* stream);
 /* The whole Residual(PreNorm(LinearAttention)) block (utils.py:68-93, parts/mha.py:44-59): out = GroupNorm(1)(y) + x
  * behind the fused attention; fused = 1 inside the attention's second launch (partial sums exchanged within it),
- * fused = 0 as a separate pass over y. Both forms give the same bits in `out`. */
+ * fused = 0 as a separate pass over y. Both forms give the same bits in `out`. plan_B: batch the pixel slices are
+ * planned for (0: B). Shapes outside the exchange's limits (more than 8 slices per image) return an error for fused = 1. */
 int dmn_test_linattn_block(int dtype, const void* x, const float* x_stats, int B, int n, int C, const float* gamma_host,
                            const float* beta_host, const float* wqkv_host, const float* wout_host, const float* bout_host,
                            const float* out_gamma_host, const float* out_beta_host, void* y, float* y_stats, void* out,
-                           void* scratch, size_t scratch_bytes, int fused, unsigned* giveups, void* stream);
+                           void* scratch, size_t scratch_bytes, int fused, int plan_B, unsigned* giveups, void* stream);
 /* Softmax attention core (parts/mha.py:21-28: scale, q k^T, row maximum, softmax, attn v) on qkv [B][n][3 * heads * 32]
  * (channels q | k | v, each head-major) -> out [B][n][heads * 32], both in the internal dtype. 64 <= n <= 256 with
  * n % 64 == 0 runs on the matrix cores, other sizes on the vector units. */
@@ -279,7 +280,8 @@ int dmn_test_conv2d(int dtype, const void* in0, const void* in1, int C0, int C1,
                     int* epi_slots_out, int cfg_tile, int cfg_bn, void* stream);
 /* block2.proj of a ResnetBlock with the block's closing SiLU(GroupNorm(h)) + res (parts/convnext.py:81-86) on
  * caller-provided device tensors: fused = 1 in one launch (partial sums exchanged inside it), fused = 0 as the
- * convolution followed by the separate closing pass (h2: its intermediate). Both forms give the same bits in `out`. */
+ * convolution followed by the separate closing pass (h2: its intermediate). Both forms give the same bits in `out`.
+ * Shapes outside the exchange's limits (more than 8 workgroups per image) return an error for fused = 1. */
 int dmn_test_conv_block_tail(int dtype, const void* in, int Cin, int B, int H, int W, const float* w_host,
                              const float* bias_host, int Cout, const float* pro_gamma_host, const float* pro_beta_host,
                              const float* pro_stats_dev, int pro_G, int pro_slots, const float* tail_gamma_host,

@@ -699,6 +699,22 @@ def test_alternative_launch_paths_give_the_same_bits(monkeypatch):
             assert float(d.max()) < 0.15 and float(d.mean()) < 5e-3, (mask, float(d.max()), float(d.mean()))
 
 
+def test_two_launch_chains_never_starve_an_in_launch_exchange():
+    """Workgroups that wait for the partial sums of their image keep their place on the CU; two launch chains must never
+    fill the machine with waiters of both (with 512-workgroup exchanging launches about one step in 3000 stalled until
+    its waits ran out). 3 x 1000 steps of the bench shape with two chains: no wait may run out, same bits every time."""
+    from diffusion_model_nemo_amd.modules import GaussianDiffusion
+    u = build_unet64("bf16")
+    gd = GaussianDiffusion(timesteps=1000, schedule_name="cosine")
+    first = None
+    for _ in range(3):
+        x = gd.p_sample_loop(u, (64, 3, 64, 64), device="cuda", seed=3, keep="last", return_device_tensor=True)
+        torch.cuda.synchronize()
+        assert u.handoff_giveups() == 0
+        first = x.clone() if first is None else first
+        assert torch.equal(x, first)
+
+
 def test_plan_batch_zero_plans_for_the_call_and_still_matches_oracle():
     """set_plan_batch(0): launch geometry chosen for the batch of each call (the small-batch tile and slice choices);
     same parity bar as the default."""

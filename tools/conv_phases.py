@@ -59,6 +59,9 @@ def run(name, B, H, W, cin, cout, k, stride, pad, transposed, pro, epi_G, dtype=
     med = np.median(ph, 0)
     st0 = (d[:, 0] - d[:, 0].min()) / 100.0
     starts = np.sort(st0)
+    if "-s" in sys.argv:   # start-time distribution: workgroups started by 0.5, 1, 1.5, 2, 3, 4, 6, 8, 12 us
+        print("    started by us:", " ".join(f"{t}:{int((st0 <= t).sum())}" for t in (0.5, 1, 1.5, 2, 3, 4, 6, 8, 12)),
+              " ends p50/p90/max:", " ".join(f"{np.percentile((d[:, 5] - d[:, 0].min()) / 100.0, q):.1f}" for q in (50, 90, 100)))
     if starts[-1] > 3.0:   # more than one residency round: medians of the first and of the later workgroups
         for nm, sel in (("first round", st0 < 1.5), ("later rounds", st0 >= 1.5)):
             m = np.median(ph[sel], 0)
@@ -70,7 +73,7 @@ def run(name, B, H, W, cin, cout, k, stride, pad, transposed, pro, epi_G, dtype=
 
 
 if __name__ == "__main__":
-    B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1] != "-s" else 64
     if len(sys.argv) > 2 and sys.argv[2] == "cfg":
         for tile, bn in ((0, 0), (16, 32), (16, 64), (8, 32), (8, 64)):
             print(f"--- tile {tile} bn {bn}")

@@ -70,11 +70,9 @@ if __name__ == "__main__":
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     for dt in (1, 0):
         print("bf16" if dt == 1 else "fp32")
-        run("L0 32->32 64x64", B, 64, 32, 8, dt)
-        run("L0 32->32 64x64 (G_out 8)", B, 64, 32, 8, dt, out_G=8)
         run("L1 64->64 32x32", B, 32, 64, 8, dt)
         run("L2 128->128 16x16", B, 16, 128, 8, dt)
         run("L3 256->256 8x8", B, 8, 256, 8, dt)
         run("L3 256->256 8x8 groups 4", B, 8, 256, 4, dt)
         run("ragged 64->64 24x24", 3, 24, 64, 8, dt)
-        run("128x128 32->32", 2, 128, 32, 8, dt)
+        run("decoder 32->32 32x32 (G_out 8)", B, 32, 32, 8, dt, out_G=8)
