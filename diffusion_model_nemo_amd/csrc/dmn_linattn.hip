@@ -34,6 +34,7 @@ namespace {
     }
 
 constexpr int kHeads = 4, kD = 32, kHidden = 128;
+constexpr int kMergeInOutMaxSplits = 4;   // up to this many split partials per image are merged by the second launch itself
 constexpr int kPartStride = kD * kD + 2 * kD;
 
 template <typename T> struct Sub;   // k-steps per 32 logical k values
@@ -424,21 +425,60 @@ __global__ void __launch_bounds__(256) la_fused_out_kernel(const LinAttnFusedArg
     for (int i = 0; i < YPW; ++i) bias[i] = *reinterpret_cast<const f32x4*>(a.bias + (yt0 + 4 * i) * 16 + lq * 4);
     constexpr int CU = kHeads * kD * kD / PER / 256;   // 16-byte units of ctx^T per thread
     V cr[CU];
-    {
+    // merge_splits > 0: the first pass left that many split partials per image and no merge launch ran; this workgroup
+    // merges them itself (the arithmetic of la_merge_kernel, every workgroup of the image redundantly; worth it for a few
+    // splits, where the partials of an image are a few tens of KB from the L2)
+    const int S = a.merge_splits;
+    const float* part_b = a.ctx_part + (size_t)b * kHeads * (S > 0 ? S : 1) * kPartStride;
+    float* sFac = reinterpret_cast<float*>(sO);    // [128][S] (sO is first written in phase A)
+    if (S == 0) {
         const T* cT = static_cast<const T*>(a.ctxT) + (size_t)b * kHeads * kD * kD;
 #pragma unroll
         for (int j = 0; j < CU; ++j) cr[j] = *reinterpret_cast<const V*>(cT + (size_t)(tid + 256 * j) * PER);
     }
     XStager<T, C> st;
     st.begin(a.x, b, a.n, p0, slice);
-    norm_coefs_to_lds(a.norm, b, C, sCoef, sCoef + 3 * C);
+    if (S > 0 && tid < kHidden) {
+        const int hd = tid;
+        const float* base = part_b + (size_t)(hd >> 5) * S * kPartStride + kD * kD + (hd & 31);
+        float M = -INFINITY;
+        for (int s = 0; s < S; ++s) M = fmaxf(M, base[(size_t)s * kPartStride]);
+        float Z = 0.f;
+        for (int s = 0; s < S; ++s) {
+            const float f = expf(base[(size_t)s * kPartStride] - M);
+            sFac[hd * S + s] = f;
+            Z += base[(size_t)s * kPartStride + kD] * f;
+        }
+        const float inv = 0.17677669529663687f / Z;
+        for (int s = 0; s < S; ++s) sFac[hd * S + s] *= inv;
+    }
+    norm_coefs_to_lds(a.norm, b, C, sCoef, sCoef + 3 * C);   // its barriers also publish sFac
     LA_STAMP(dbg2, 1)
     st.finish(sX, row_bytes, sCoef);
+    if (S == 0) {
 #pragma unroll
-    for (int j = 0; j < CU; ++j) {
-        const int u = tid + 256 * j;               // unit -> row (h*32 + e), 16-byte column
-        constexpr int UPR = kD / PER;
-        *reinterpret_cast<V*>(sCtx + (size_t)(u / UPR) * CTX_ROW + (u % UPR) * 16) = cr[j];
+        for (int j = 0; j < CU; ++j) {
+            const int u = tid + 256 * j;               // unit -> row (h*32 + e), 16-byte column
+            constexpr int UPR = kD / PER;
+            *reinterpret_cast<V*>(sCtx + (size_t)(u / UPR) * CTX_ROW + (u % UPR) * 16) = cr[j];
+        }
+    } else {
+        // ctx^T in operand order: row e, position pos holds ctx[d = perm32(pos)][e]
+        for (int i = tid; i < kHeads * kD * kD / 4; i += 256) {
+            const int hh = i >> 8, d = (i >> 3) & 31, e4 = (i & 7) * 4;
+            const float* base = part_b + (size_t)hh * S * kPartStride + d * kD + e4;
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < S; ++s) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)s * kPartStride);
+                const float f = sFac[(hh * kD + d) * S + s];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = fmaf(v[r], f, acc[r]);
+            }
+            const int pos = sizeof(T) == 4 ? d : ((d & 15) >> 2) * 8 + (d >> 4) * 4 + (d & 3);   // inverse of perm32
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                *reinterpret_cast<T*>(sCtx + (size_t)(hh * kD + e4 + r) * CTX_ROW + pos * sizeof(T)) = from_f32<T>(acc[r]);
+        }
     }
     __syncthreads();
     LA_STAMP(dbg2, 2)
@@ -727,7 +767,10 @@ int launch_pair(const LinAttnFusedArgs& a, hipStream_t s) {
     }
     hipLaunchKernelGGL((la_fused_ctx_kernel<T, C>), dim3(a.splits, a.B), dim3(256), lds1, s, a);
     DMN_HIP_CHECK(hipGetLastError());
-    if (a.splits > 1) {
+    // a few splits: the second launch merges them itself (no merge launch); more: one merge per image
+    LinAttnFusedArgs c = a;
+    c.merge_splits = (a.splits > 1 && a.splits <= kMergeInOutMaxSplits && !a.separate_merge) ? a.splits : 0;
+    if (a.splits > 1 && !c.merge_splits) {
         hipLaunchKernelGGL(la_merge_kernel<T>, dim3(a.B), dim3(256), ldsm, s, a);
         DMN_HIP_CHECK(hipGetLastError());
     }
@@ -738,7 +781,6 @@ int launch_pair(const LinAttnFusedArgs& a, hipStream_t s) {
                     "fused linear attention: closing GroupNorm outside the in-launch exchange's limits");
         per_launch = kHandoffMaxWgsPerLaunch / a.slices;
     }
-    LinAttnFusedArgs c = a;
     for (int b0 = 0; b0 < a.B; b0 += per_launch) {
         c.b_first = b0;
         c.b_count = a.B - b0 < per_launch ? a.B - b0 : per_launch;

@@ -544,6 +544,7 @@ static Act lin_attn(Fwd& f, const AttnW& w, Act& x, LazyAttn* defer = nullptr) {
         fa.n = x.H * x.W;
         fa.C = x.C;
         linattn_fused_plan(fa.n, f.planB(), fa.C, c.dtype, &fa.slice1, &fa.splits, &fa.tpw, &fa.slices);
+        fa.separate_merge = (f.u->path_mask & 1024) != 0;
         if (!defer && f.ho_enabled && !(f.u->path_mask & 256) && linattn_tail_fits(fa.n, f.planB(), fa.C, c.dtype)) {
             // the second launch closes the attention itself (GroupNorm(1)(y) + x, partial sums exchanged inside the launch)
             unsigned long long* gran = f.handoff_take((size_t)f.B * fa.slices * 2 * sizeof(unsigned long long));

@@ -73,7 +73,8 @@ struct DmnUnet {
     // bit 4 leaves the tail of every linear attention to the resampling convolution behind it (fewer launches, slower;
     // bit 5: only on the way down, bit 6: only at the top level), bit 7 closes the ResnetBlocks in front of an attention
     // with a pass of their own instead of inside block2.proj (no in-launch hand-off anywhere), bit 8 does the same for
-    // the closing GroupNorm of the linear attentions only.
+    // the closing GroupNorm of the linear attentions only, bit 10 merges the split partials of a linear attention in a
+    // launch of its own even where its second launch would merge them itself.
     int path_mask = 0;
     // diagnosis: workspace checksums after every launch of a forward (dmn_test_unet_trace)
     unsigned long long* trace_slots = nullptr;

@@ -682,12 +682,13 @@ def test_alternative_launch_paths_give_the_same_bits(monkeypatch):
     bf16 outputs must be bit-identical except where a different kernel does the arithmetic (unfused attention, VALU
     softmax, the block tail as a pass of its own: one more rounding than the fused multiply-add of the staging form; 128,
     block tails closed by a separate pass instead of inside block2.proj: same tensor, but its GroupNorm(1) partial sums
-    are formed per convolution tile instead of per pixel slice), which stays within bf16 noise."""
+    are formed per convolution tile instead of per pixel slice), which stays within bf16 noise. 1024 merges the split
+    partials of the linear attentions in a launch of its own instead of inside their second launch: same arithmetic."""
     g = torch.Generator(device="cuda").manual_seed(4)
     x = torch.randn(4, 3, 64, 64, device="cuda", generator=g)
     t = torch.tensor([3, 500, 999, 40], device="cuda")
     ref = build_unet64("bf16")(x, t)
-    for mask, exact in ((1, True), (16, True), (16 | 32, True), (4, False), (2, False), (8, False), (128, False)):
+    for mask, exact in ((1, True), (16, True), (16 | 32, True), (1024, True), (4, False), (2, False), (8, False), (128, False)):
         monkeypatch.setenv("DMN_UNET_PATHS", str(mask))
         y = build_unet64("bf16")(x, t)
         monkeypatch.delenv("DMN_UNET_PATHS")
