@@ -684,6 +684,12 @@ TileCfg pick_cfg(const ConvArgs& a) {
         else c.th = c.tw = 8;
     }
     if (c.th == 8 && c.bn == 64 && blocks(c) < 256) c.bn = 32;
+    // The sampling loop launches half the planning batch per chain: 3x3 launches that would leave half the CUs of a chain
+    // without a workgroup take the 32-channel tile (measured with two chains on MI355X: 64 channels at 32x32 pixels
+    // -0.7 % of the step, 256 channels at 8x8 -0.6 %; at 16x16 pixels and for the 1x1 kernels the wider tile stays ahead).
+    if (a.kind == DMN_K3X3 && c.bn == 64 && blocks(c) < 512 && !(a.w2 && c.th == 16) &&
+        (c.th == 16 || ((a.Ho + 7) / 8) * ((a.Wo + 7) / 8) == 1))
+        c.bn = 32;
     if (a.w2 && c.th == 16 && c.bn == 64) c.th = c.tw = 8;   // two accumulator sets: keep the per-wave tile small
     return c;
 }
