@@ -201,7 +201,10 @@ __global__ void __launch_bounds__(256) ingest_kernel(const IngestArgs a) {
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
     const int b = blockIdx.y;
     const int y0 = ty * TS - HALO, x0 = tx * TS - HALO;
-    if (a.epoch && blockIdx.x == 0 && b == 0 && threadIdx.x == 0) *a.epoch = *a.epoch + 1;   // a new network evaluation
+    if (a.epoch && blockIdx.x == 0 && b == 0 && threadIdx.x == 0) {   // a new network evaluation; 0 is "never written"
+        const unsigned e = *a.epoch + 1u;
+        *a.epoch = e ? e : 1u;
+    }
     for (int i = threadIdx.x; i < a.Cin * IW * IW; i += 256) {
         const int c = i / (IW * IW), r = i % (IW * IW);
         const int ly = r / IW, lx = r % IW;
@@ -245,7 +248,10 @@ __device__ __forceinline__ void ingest_mfma_body(const IngestArgs& a, int bx, in
     const int tiles_x = (a.W + TS - 1) / TS;
     const int ty = bx / tiles_x, tx = bx % tiles_x;
     const int y0 = ty * TS - HALO, x0 = tx * TS - HALO;
-    if (a.epoch && bx == 0 && b == 0 && tid == 0) *a.epoch = *a.epoch + 1;   // a new network evaluation
+    if (a.epoch && bx == 0 && b == 0 && tid == 0) {   // a new network evaluation; 0 is "never written"
+        const unsigned e = *a.epoch + 1u;
+        *a.epoch = e ? e : 1u;
+    }
     // weights first: 7 * NT fragments per wave, straight into registers
     bf16x8 wf[NT][7];
 #pragma unroll

@@ -36,6 +36,15 @@ def run(name, B, H, C_, G, dtype=1, out_G=1, plan_B=64):
         ost = torch.zeros((B * out_G * 4096 * 2,), device="cuda")
         slots, give = C.c_int(0), C.c_uint(0)
         N.check(lib.dmn_test_set_conv_debug(dbg.data_ptr()))
+        if fused:   # shapes outside the exchange's limits (workgroups per image, LDS per workgroup) are refused
+            rc = lib.dmn_test_conv_block_tail(
+                dtype, x.data_ptr(), C_, B, H, H, w.ctypes.data, bias.ctypes.data, C_, pg.ctypes.data, pb.ctypes.data,
+                pst.data_ptr(), G, 1, tg.ctypes.data, tb.ctypes.data, G, res.data_ptr(), h2.data_ptr(), out.data_ptr(),
+                ost.data_ptr(), out_G, C.byref(slots), fused, plan_B, 0, 0, C.byref(give), None)
+            if rc == -5:
+                N.check(lib.dmn_test_set_conv_debug(None))
+                print(f"{name:28s} refused: outside the in-launch exchange's limits (kept on the two-launch form)", flush=True)
+                return
         for _ in range(3):
             dbg.zero_()
             torch.cuda.synchronize()
