@@ -59,6 +59,9 @@ int dmn_unet_create(const DmnUnetCfg* cfg, DmnUnet** out);
 void dmn_unet_destroy(DmnUnet* u);
 /* Packs the reference's parameters (names as in Unet.state_dict()) into the device layout. Synchronous. */
 int dmn_unet_load_weights(DmnUnet* u, const DmnTensorDesc* params, int n_params);
+/* Bytes of caller workspace one evaluation of this shape needs. Side effect (never call it inside a stream capture): makes
+ * the handle's own device areas for the in-launch exchanges (see dmn_unet_handoff_giveups) large enough for this shape;
+ * when they grow, the device is synchronised and cached step graphs are dropped. */
 int dmn_unet_workspace_bytes(const DmnUnet* u, int B, int H, int W, size_t* bytes);
 /* Class labels of the next forwards / sampling loops (unet.py:134-141): DEVICE int64 [B], borrowed until replaced;
  * NULL selects the extra "null" row num_classes for every image, like classes=None in the reference. */
