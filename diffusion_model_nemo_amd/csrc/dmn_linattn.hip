@@ -324,16 +324,17 @@ __global__ void __launch_bounds__(256) la_fused_ctx_kernel(const LinAttnFusedArg
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// merge of the split partials (only launched when splits > 1): grid (B), one workgroup per image
+// merge of the split partials (only launched when the second pass does not merge them itself): grid (B, heads), one
+// workgroup per image and head (an image's partials are 17 KB per split: four workgroups halve the launch's latency)
 //   factor_s[d] = exp(m_s[d] - M[d]) * 32^-1/2 / sum_s Z_s[d] exp(m_s[d] - M[d]);  ctx^T = sum_s factor_s * ctx_s
 // ------------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(256) la_merge_kernel(const LinAttnFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sFac = reinterpret_cast<float*>(smem);             // [128][splits]
-    const int b = blockIdx.x, S = a.splits;
+    float* sFac = reinterpret_cast<float*>(smem);             // [128][splits] (this head's 32 rows are used)
+    const int b = blockIdx.x, head = blockIdx.y, S = a.splits;
     const float* part_b = a.ctx_part + (size_t)b * kHeads * S * kPartStride;
-    for (int hd = threadIdx.x; hd < kHidden; hd += 256) {
+    for (int hd = head * kD + threadIdx.x; hd < (head + 1) * kD; hd += 256) {
         const float* base = part_b + (size_t)(hd >> 5) * S * kPartStride + kD * kD + (hd & 31);
         float M = -INFINITY;
         for (int s = 0; s < S; ++s) M = fmaxf(M, base[(size_t)s * kPartStride]);
@@ -349,7 +350,7 @@ __global__ void __launch_bounds__(256) la_merge_kernel(const LinAttnFusedArgs a)
     __syncthreads();
     // ctx^T in operand order: row e, position pos holds ctx[d = perm32(pos)][e]
     T* out = static_cast<T*>(a.ctxT) + (size_t)b * kHeads * kD * kD;
-    for (int i = threadIdx.x; i < kHeads * kD * kD / 4; i += 256) {
+    for (int i = head * (kD * kD / 4) + threadIdx.x; i < (head + 1) * (kD * kD / 4); i += 256) {
         const int hh = i >> 8, d = (i >> 3) & 31, e4 = (i & 7) * 4;
         const float* base = part_b + (size_t)hh * S * kPartStride + d * kD + e4;
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -771,7 +772,7 @@ int launch_pair(const LinAttnFusedArgs& a, hipStream_t s) {
     LinAttnFusedArgs c = a;
     c.merge_splits = (a.splits > 1 && a.splits <= kMergeInOutMaxSplits && !a.separate_merge) ? a.splits : 0;
     if (a.splits > 1 && !c.merge_splits) {
-        hipLaunchKernelGGL(la_merge_kernel<T>, dim3(a.B), dim3(256), ldsm, s, a);
+        hipLaunchKernelGGL(la_merge_kernel<T>, dim3(a.B, kHeads), dim3(256), ldsm, s, a);
         DMN_HIP_CHECK(hipGetLastError());
     }
     // a second launch whose workgroups wait for each other stays small enough to be resident as a whole (dmn_handoff.h)
