@@ -350,6 +350,7 @@ __global__ void __launch_bounds__(256) egress_kernel(const EgressArgs a) {
     const bool norm = a.norm.stats != nullptr;
     const int p = blockIdx.x * 256 + threadIdx.x;
     const bool live = p < a.HW;
+    float* sEps = sW + Cout * C + Cout + 2 * (norm ? a.norm.G : 0) + 16;   // [Cout][256] network outputs of the workgroup's pixels (fuse_step)
     const int nv = C / PER;
     const T* in = static_cast<const T*>(a.in) + ((size_t)b * a.HW + (live ? p : 0)) * C;
     // the pixel's channels are requested before the statistics round trip
@@ -361,7 +362,7 @@ __global__ void __launch_bounds__(256) egress_kernel(const EgressArgs a) {
     for (int i = threadIdx.x; i < Cout * C; i += 256) sW[i] = a.w[i];
     for (int i = threadIdx.x; i < Cout; i += 256) sW[Cout * C + i] = a.bias[i];
     __syncthreads();
-    if (!live) return;
+    if (!live && !a.fuse_step) return;
     float acc[NO];
 #pragma unroll
     for (int o = 0; o < NO; ++o) acc[o] = o < Cout ? sW[Cout * C + o] : 0.f;
@@ -409,9 +410,43 @@ __global__ void __launch_bounds__(256) egress_kernel(const EgressArgs a) {
     } else {
         for (int cb = 0; cb < C; cb += PER) consume(*reinterpret_cast<const V*>(in + cb), cb);
     }
+    if (!a.fuse_step) {
+#pragma unroll
+        for (int o = 0; o < NO; ++o)
+            if (o < Cout) __builtin_nontemporal_store(acc[o], &a.out[((size_t)b * Cout + o) * a.HW + p]);
+        return;
+    }
+    // ---- sampler update on the workgroup's 256 pixels: thread (channel c, pixel quad j) takes the four elements
+    //      c * HW + p0 + 4j .. +3 of the image, i.e. exactly one quad of the noise generator (HW and p0 are multiples of 4)
 #pragma unroll
     for (int o = 0; o < NO; ++o)
-        if (o < Cout) __builtin_nontemporal_store(acc[o], &a.out[((size_t)b * Cout + o) * a.HW + p]);
+        if (o < Cout) sEps[o * 256 + threadIdx.x] = acc[o];
+    __syncthreads();
+    const DdpmStepArgs& st = a.step;
+    const StepCommon& sc = st.c;
+    const int row = sc.step_idx ? *sc.step_idx : sc.step;
+    if (st.step_next && blockIdx.x == 0 && b == 0 && threadIdx.x == 0) *st.step_next = row + 1;
+    const float* tr = sc.table + (size_t)row * DMN_TABLE_COLS;
+    const int per = sc.C * a.HW;
+    const int p0 = blockIdx.x * 256;
+    for (int t = threadIdx.x; t < sc.C * 64; t += 256) {
+        const int c = t >> 6, j = t & 63;
+        const int pq = p0 + 4 * j;
+        if (pq >= a.HW) continue;
+        const int e0 = c * a.HW + pq;
+        float z[4];
+        load_noise(sc, (unsigned)tr[8], 1u, b, e0 >> 2, per, z);
+        const size_t xi = (size_t)b * per + e0;
+        const f32x4 x = *reinterpret_cast<const f32x4*>(sc.x + xi);
+        f32x4 xn;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = st.learned_variance ? sEps[(sc.C + c) * 256 + 4 * j + r] : 0.f;
+            xn[r] = ddpm_update_element(st, tr, x[r], sEps[c * 256 + 4 * j + r], v, z[r]);
+        }
+        *reinterpret_cast<f32x4*>(sc.x_out + xi) = xn;
+        if (sc.keep) *reinterpret_cast<f32x4*>(sc.keep + (size_t)row * sc.keep_stride + xi) = xn;
+    }
 }
 
 __global__ void __launch_bounds__(256) checksum_kernel(const uint4* p, size_t n16, unsigned long long* slot) {
@@ -572,7 +607,14 @@ int launch_ingest(IngestArgs& a, hipStream_t s) {
 
 int launch_egress(EgressArgs& a, hipStream_t s) {
     DMN_REQUIRE(a.Cout >= 1 && a.Cout <= 8, DMN_ERR_LIMIT, "egress: Cout=%d (max 8)", a.Cout);
-    const size_t lds = (3 * (size_t)a.C + (size_t)a.Cout * a.C + a.Cout + 2 * (size_t)(a.norm.stats ? a.norm.G : 0) + 16) * 4;
+    size_t lds = (3 * (size_t)a.C + (size_t)a.Cout * a.C + a.Cout + 2 * (size_t)(a.norm.stats ? a.norm.G : 0) + 16) * 4;
+    if (a.fuse_step) {
+        const int ci = a.step.c.C;
+        DMN_REQUIRE(a.HW % 4 == 0 && a.Cout == ci * (a.step.learned_variance ? 2 : 1) && a.step.c.HW == a.HW && a.step.c.B == a.B &&
+                        a.step.c.x && a.step.c.x_out && a.step.c.table,
+                    DMN_ERR_INVALID, "egress: sampler update needs HW %% 4 == 0 and %d network channels", ci * (a.step.learned_variance ? 2 : 1));
+        lds += (size_t)a.Cout * 256 * 4;
+    }
     dim3 grid((a.HW + 255) / 256, a.B);
     DMN_REQUIRE(a.C % 8 == 0, DMN_ERR_INVALID, "egress: C=%d must be a multiple of 8", a.C);
 #define DMN_EGRESS(T, CO) hipLaunchKernelGGL((egress_kernel<T, CO>), grid, dim3(256), lds, s, a)

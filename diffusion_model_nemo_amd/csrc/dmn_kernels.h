@@ -3,6 +3,7 @@
 #pragma once
 #include "dmn_common.h"
 #include "dmn_handoff.h"
+#include "dmn_sampler.h"
 
 enum { DMN_F32 = 0, DMN_BF16 = 1 };
 // convolution shapes the implicit-GEMM kernel is specialised for
@@ -141,8 +142,12 @@ struct EgressArgs {
     NormIn norm;      // stats == nullptr: plain 1x1
     const float* w;   // [Cout][C]
     const float* bias;
-    float* out;       // [B][Cout][HW]
+    float* out;       // [B][Cout][HW]; unused with fuse_step
     int B, HW, C, Cout;
+    // The DDPM loop's last launch of a step: instead of storing the network output, apply the sampler update to it
+    // (step.c.x -> step.c.x_out; step.c.net is ignored) -- the arithmetic and noise of ddpm_step_kernel, same bits.
+    int fuse_step;
+    DdpmStepArgs step;
 };
 int launch_egress(EgressArgs& a, hipStream_t s);
 

@@ -54,6 +54,20 @@ struct LangevinArgs {
 // channel of a learned-variance network) -> x_{t-1}, with z ~ N(0,1). `tr` is the step's table row. Shared by the
 // stand-alone update kernel and the network's last kernel when it applies the update itself, so both give the same bits.
 #ifdef __HIPCC__
+#include "dmn_rng.h"
+// Four N(0,1) values for elements 4q .. 4q+3 of image b: the injected tensor when there is one, else Philox.
+__device__ __forceinline__ void load_noise(const StepCommon& c, unsigned pstep, unsigned stream, int b, int q, int per,
+                                            float z[4]) {
+    if (c.noise) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = 4 * q + r;
+            z[r] = e < per ? c.noise[(size_t)b * per + e] : 0.f;
+        }
+    } else {
+        normal4(c.seed, pstep, stream, (unsigned)(c.img_offset + b), (unsigned)q, z);
+    }
+}
 __device__ __forceinline__ float ddpm_update_element(const DdpmStepArgs& a, const float* tr, float x, float eps, float v, float z) {
     if (a.ddim) {
         // row: 1 sqrt(1-at) 2 sqrt(at) 3 sqrt(at_next) 4 c1 5 c2. With the pred_x0 objective the reference clamps the

@@ -12,23 +12,9 @@
 #include <mutex>
 
 #include "../../include/dmn.h"
-#include "dmn_rng.h"
 #include "dmn_sampler.h"
 
 namespace {
-
-__device__ __forceinline__ void load_noise(const StepCommon& c, unsigned pstep, unsigned stream, int b, int q,
-                                            int per, float z[4]) {
-    if (c.noise) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int e = 4 * q + r;
-            z[r] = e < per ? c.noise[(size_t)b * per + e] : 0.f;
-        }
-    } else {
-        normal4(c.seed, pstep, stream, (unsigned)(c.img_offset + b), (unsigned)q, z);
-    }
-}
 
 // grid (ceil(per/4/256), B)
 __global__ void __launch_bounds__(256) ddpm_step_kernel(const DdpmStepArgs a) {

@@ -665,7 +665,7 @@ int unet_reserve_handoff(DmnUnet* u, size_t bytes) {
 
 int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float, const float* table, int* step_idx,
                       float* out, int B, int H, int W, void* ws, size_t ws_bytes, hipStream_t s, bool dry, size_t* high,
-                      size_t* handoff_need) {
+                      size_t* handoff_need, const DdpmStepArgs* fuse_step) {
     const DmnUnetCfg& c = u->cfg;
     DMN_REQUIRE(u->loaded || dry, DMN_ERR_WEIGHTS, "dmn_unet_forward: weights not loaded");
     const int nlev = c.n_mults;
@@ -824,7 +824,11 @@ int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float,
         ea.bias = u->tail_bias;
         ea.out = out;
         ea.B = B; ea.HW = H * W; ea.C = c.dim; ea.Cout = c.out_dim;
-        if (f.ok() && !dry) f.run(launch_egress(ea, s), "egress");
+        if (fuse_step) {   // the sampler's update rides on the network's last kernel: one launch fewer per step
+            ea.fuse_step = 1;
+            ea.step = *fuse_step;
+        }
+        if (f.ok() && !dry) f.run(launch_egress(ea, s), fuse_step ? "egress + sampler update" : "egress");
         f.free_act(fin);
     }
     if (high) *high = f.ar.high;

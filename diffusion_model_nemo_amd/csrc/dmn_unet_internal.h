@@ -74,7 +74,8 @@ struct DmnUnet {
     // bit 5: only on the way down, bit 6: only at the top level), bit 7 closes the ResnetBlocks in front of an attention
     // with a pass of their own instead of inside block2.proj (no in-launch hand-off anywhere), bit 8 does the same for
     // the closing GroupNorm of the linear attentions only, bit 10 merges the split partials of a linear attention in a
-    // launch of its own even where its second launch would merge them itself.
+    // launch of its own even where its second launch would merge them itself, bit 11 keeps the DDPM update a launch of its
+    // own instead of applying it in the network's last kernel.
     int path_mask = 0;
     // diagnosis: workspace checksums after every launch of a forward (dmn_test_unet_trace)
     unsigned long long* trace_slots = nullptr;
@@ -124,6 +125,6 @@ void conv_args_from(const PackedConv& pc, int dtype, ConvArgs& a, int B, int H, 
 constexpr int kStepCopyOffset = 16;
 int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float, const float* table, int* step_idx,
                       float* out, int B, int H, int W, void* ws, size_t ws_bytes, hipStream_t s, bool dry, size_t* high,
-                      size_t* handoff_need = nullptr);
+                      size_t* handoff_need = nullptr, const struct DdpmStepArgs* fuse_step = nullptr);
 // Makes both chains' granule areas at least `bytes` large (never inside a stream capture: it allocates).
 int unet_reserve_handoff(DmnUnet* u, size_t bytes);

@@ -716,6 +716,35 @@ def test_two_launch_chains_never_starve_an_in_launch_exchange():
         assert torch.equal(x, first)
 
 
+@pytest.mark.parametrize("kind", ["ddpm", "learned", "ddim"])
+def test_sampler_update_inside_the_last_kernel_gives_the_bits_of_its_own_launch(monkeypatch, kind):
+    """In the DDPM loop the network's last kernel applies the sampler update itself (posterior / learned variance / DDIM,
+    same noise quads); DMN_UNET_PATHS bit 11 keeps the update a launch of its own. Same bits for every kept image, graph
+    and eager, two chains and one, a batch that is not a multiple of the workgroup's 256 pixels included (32x32, 24x40)."""
+    from diffusion_model_nemo_amd.modules import GaussianDiffusion, GeneralizedGaussianDiffusion, LearnedGaussianDiffusion
+    if kind == "learned":
+        gd = LearnedGaussianDiffusion(timesteps=30, schedule_name="cosine")
+    elif kind == "ddim":
+        gd = GeneralizedGaussianDiffusion(timesteps=60, schedule_name="cosine", eta=0.3, ddim_timesteps=12)
+    else:
+        gd = GaussianDiffusion(timesteps=30, schedule_name="cosine")
+    outs = []
+    for mask in (0, 2048):
+        if mask:
+            monkeypatch.setenv("DMN_UNET_PATHS", str(mask))
+        for dtype in ("bf16", "fp32"):
+            u = build_unet64(dtype, learned_variance=(kind == "learned"))
+            for shape, graph in (((16, 3, 64, 64), True), ((16, 3, 64, 64), False), ((3, 3, 32, 32), True), ((2, 3, 24, 40), True)):
+                hist = gd.p_sample_loop(u, shape, device="cuda", seed=11, keep="all", use_graph=graph)
+                outs.append(torch.stack(hist))
+        if mask:
+            monkeypatch.delenv("DMN_UNET_PATHS")
+    n = len(outs) // 2
+    for a, b in zip(outs[:n], outs[n:]):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_plan_batch_zero_plans_for_the_call_and_still_matches_oracle():
     """set_plan_batch(0): launch geometry chosen for the batch of each call (the small-batch tile and slice choices);
     same parity bar as the default."""
