@@ -246,6 +246,9 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
                     Vec16<T> v, r2;
                     v.v = sr[j];
                     if constexpr (PRO == 3) r2.v = sr2[j];
+                    // padding skips the prologue's arithmetic: a 16-byte unit belongs to one pixel and the units of a
+                    // wave to one or two, so mostly whole waves skip (the halo rows above and below an image)
+                    if (!PRO || in)
 #pragma unroll
                     for (int e = 0; e < PER; ++e) {
                         float y = v.get(e);
