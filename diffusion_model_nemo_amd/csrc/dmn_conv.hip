@@ -555,6 +555,90 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
             }
         } else {
         const bool want_stats = a.epi.stats != nullptr;
+        bool activated = false;
+        if constexpr (KIND == DMN_K3X3 && TH == 8) {
+            // block1 of a ResnetBlock whose workgroups each hold every pixel and channel of their groups (8x8 images): the
+            // epilogue applies the block's own GroupNorm + SiLU + time bias (parts/convnext.py:33-45,82-84) to the
+            // accumulators -- statistics, coefficients and arithmetic exactly those of a consumer that normalises the
+            // stored convolution while staging it (same bits), but once per element instead of once per consumer
+            // workgroup and halo pixel, and the consumer needs neither the statistics round trip nor the prologue.
+            if (a.act_gamma) {
+                activated = true;
+                const int G = a.epi.G;
+                const int cpg = a.Cout / G;
+                float pgam = 0.f, pbet = 0.f, ptb = 0.f;
+                if (tid < BN) {
+                    pgam = a.act_gamma[n0 + tid];
+                    pbet = a.act_beta[n0 + tid];
+                    if (a.act_tbias) ptb = a.act_tbias[(size_t)b * a.act_tb_stride + n0 + tid];
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    if (col_ok && oyt0 + mt * ROWS < a.Ho) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float v = acc[mt][nt][r] + bias[nt][r];
+                                ssum[nt] += v;
+                                ssq[nt] += v * v;
+                            }
+                    }
+                }
+                // the halo tile is dead behind the barrier inside wg_partials
+                float* sMR = reinterpret_cast<float*>(smem);
+                float* sC = sMR + 2 * kHandoffMaxGroups;
+                wg_partials(ssum, ssq, G, [&](int g, int, float s, float ss) {   // one slot: the sums are the totals
+                    const float mean = s * a.act_inv_count;
+                    float var = ss * a.act_inv_count - mean * mean;
+                    var = var > 0.f ? var : 0.f;
+                    sMR[2 * (g - n0 / cpg)] = mean;
+                    sMR[2 * (g - n0 / cpg) + 1] = __builtin_amdgcn_rsqf(var + 1e-5f);
+                });
+                __syncthreads();
+                if (tid < BN) {
+                    const int gl = cpg >= BN ? 0 : tid / cpg;
+                    const float aa = sMR[2 * gl + 1] * pgam;
+                    sC[tid] = aa;
+                    sC[BN + tid] = pbet - sMR[2 * gl] * aa;
+                    sC[2 * BN + tid] = ptb;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const bool valid = col_ok && oyt0 + mt * ROWS < a.Ho;
+                    const unsigned obase = obase0 + (unsigned)mt * ostep;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int cl = (wn * NT + nt) * 16 + lq * 4;
+                        const int n = n0 + cl;
+                        const f32x4 ca = *reinterpret_cast<const f32x4*>(sC + cl);
+                        const f32x4 cb = *reinterpret_cast<const f32x4*>(sC + BN + cl);
+                        const f32x4 ct = *reinterpret_cast<const f32x4*>(sC + 2 * BN + cl);
+                        if (valid) {
+                            if constexpr (sizeof(T) == 4) {
+                                float y[4];
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    float t = (acc[mt][nt][r] + bias[nt][r]) * ca[r] + cb[r];
+                                    y[r] = silu_precise(t) + ct[r];
+                                }
+                                store_stream(reinterpret_cast<f32x4*>(outp + obase + n), f32x4{y[0], y[1], y[2], y[3]});
+                            } else {
+                                bf16x4 o;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const float x = (float)(__bf16)(acc[mt][nt][r] + bias[nt][r]);
+                                    o[r] = (__bf16)silu_affine_fast(x, ca[r], cb[r], ct[r]);
+                                }
+                                store_stream(reinterpret_cast<bf16x4*>(outp + obase + n), o);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (!activated)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const bool valid = col_ok && oyt0 + mt * ROWS < a.Ho;
@@ -624,7 +708,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
                 }
             }
         }
-        if (want_stats) {
+        if (want_stats && !activated) {
             const int G = a.epi.G;
             wg_partials(ssum, ssq, G, [&](int g, int slot, float s, float ss) {
                 float* dst = a.epi.stats + ((size_t)(b * G + g) * a.epi.slots + slot) * 2;
@@ -747,7 +831,13 @@ int dispatch_fused_shortcut(const ConvArgs& a, const TileCfg& c, size_t lds, hip
 
 // block2.proj that also closes its ResnetBlock (TAIL): 3x3, GroupNorm + SiLU prologue
 template <typename T>
-int dispatch_fused_tail(const ConvArgs& a, const TileCfg& c, size_t lds, hipStream_t s) {
+int dispatch_fused_tail(const ConvArgs& a, const TileCfg& c, size_t lds, hipStream_t s, int pro) {
+    if (pro == 0) {   // the input was normalised and activated by its producer (one 8x8 tile per image)
+        if (c.th == 8 && c.bn == 32) return launch_cfg<T, DMN_K3X3, 8, 8, 32, 2, 2, 0, false, true>(a, lds, s);
+        if (c.th == 8 && c.bn == 64) return launch_cfg<T, DMN_K3X3, 8, 8, 64, 1, 4, 0, false, true>(a, lds, s);
+        dmn_set_error("conv: no fused-tail kernel without prologue for tile %dx%d / %d", c.th, c.tw, c.bn);
+        return DMN_ERR_INVALID;
+    }
     if (c.th == 16 && c.bn == 32) return launch_cfg<T, DMN_K3X3, 16, 16, 32, 2, 2, 2, false, true>(a, lds, s);
     if (c.th == 16 && c.bn == 64) return launch_cfg<T, DMN_K3X3, 16, 16, 64, 2, 2, 2, false, true>(a, lds, s);
     if (c.th == 8 && c.bn == 32) return launch_cfg<T, DMN_K3X3, 8, 8, 32, 2, 2, 2, false, true>(a, lds, s);
@@ -760,11 +850,12 @@ template <typename T>
 int dispatch(const ConvArgs& a, const TileCfg& c, size_t lds, hipStream_t s) {
     const int pro = a.pro.stats ? (a.pro_res ? 3 : a.pro.silu ? 2 : 1) : 0;
     if (a.tail.gran) {
-        if (a.kind != DMN_K3X3 || pro != 2 || a.w2 || a.C1) {
-            dmn_set_error("conv: the fused block tail needs a single-source 3x3 convolution with the GroupNorm + SiLU prologue");
+        if (a.kind != DMN_K3X3 || (pro != 2 && pro != 0) || a.w2 || a.C1) {
+            dmn_set_error("conv: the fused block tail needs a single-source 3x3 convolution with the GroupNorm + SiLU prologue "
+                          "or an input activated by its producer");
             return DMN_ERR_INVALID;
         }
-        return dispatch_fused_tail<T>(a, c, lds, s);
+        return dispatch_fused_tail<T>(a, c, lds, s, pro);
     }
     if (pro == 3) {
         if (a.kind == DMN_K1X1 || a.w2 || a.C1 || a.pro.tbias) {
@@ -846,6 +937,8 @@ int set_attr_all() {
     if ((rc = set_attr<T, DMN_K3X3, 16, 16, 64, 2, 2, 2, false, true>())) return rc;
     if ((rc = set_attr<T, DMN_K3X3, 8, 8, 32, 2, 2, 2, false, true>())) return rc;
     if ((rc = set_attr<T, DMN_K3X3, 8, 8, 64, 1, 4, 2, false, true>())) return rc;
+    if ((rc = set_attr<T, DMN_K3X3, 8, 8, 32, 2, 2, 0, false, true>())) return rc;
+    if ((rc = set_attr<T, DMN_K3X3, 8, 8, 64, 1, 4, 0, false, true>())) return rc;
     return DMN_OK;
 }
 
@@ -878,6 +971,13 @@ static int wgs_per_image(const ConvArgs& a) {
     const TileCfg c = pick_cfg(a);
     return ((a.Ho + c.th - 1) / c.th) * ((a.Wo + c.tw - 1) / c.tw) * (a.Cout / c.bn) * a.nphase;
 }
+// block1 may apply its own GroupNorm + SiLU (+ time bias): 3x3, one 8x8 tile per image, every group inside one workgroup
+bool conv_act_fits(const ConvArgs& a) {
+    if (a.kind != DMN_K3X3 || a.nphase != 1 || a.epi.G < 1 || a.epi.G > kHandoffMaxGroups || a.Cout % a.epi.G) return false;
+    const TileCfg c = pick_cfg(a);
+    const int cpg = a.Cout / a.epi.G;
+    return c.th == 8 && cpg % 4 == 0 && cpg <= c.bn && c.bn % cpg == 0 && conv_epi_slots(a) == 1;
+}
 bool conv_tail_fits(const ConvArgs& a) {
     if (a.epi.G < 1 || a.epi.G > kHandoffMaxGroups) return false;
     const int slots = conv_epi_slots(a);
@@ -904,6 +1004,11 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
                     DMN_ERR_INVALID, "conv: fused block tail needs groups, epoch, parameters and the residual tensor");
         DMN_REQUIRE(conv_tail_fits(a), DMN_ERR_LIMIT, "conv: fused block tail limited to %d groups of %d partial sums",
                     kHandoffMaxGroups, kHandoffMaxSlots);
+    }
+    if (a.act_gamma) {
+        DMN_REQUIRE(!a.epi.stats && !a.tail.gran && !a.res && a.act_beta && conv_act_fits(a), DMN_ERR_INVALID,
+                    "conv: the activating epilogue needs a 3x3 convolution whose workgroups hold whole groups of an image");
+        a.epi.slots = 1;
     }
     if (a.epi.stats || a.tail.gran) {
         DMN_REQUIRE(a.nphase == 1 && a.Cout % a.epi.G == 0 && (a.Cout / a.epi.G) % 4 == 0, DMN_ERR_INVALID,

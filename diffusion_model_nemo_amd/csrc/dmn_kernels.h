@@ -71,6 +71,14 @@ struct ConvArgs {
     float tail_inv_count;      // 1 / elements per (image, group) of that GroupNorm
     NormOut tail_stats;        // optional statistics of `out`
     int b_first, b_count;      // images [b_first, b_first + b_count) of the batch in this launch (set by the launcher)
+    // Activating epilogue (3x3 kind, conv_act_fits; act_gamma != nullptr): out = SiLU(GroupNorm_{epi.G}(conv + bias)) +
+    // act_tbias -- block1 of a ResnetBlock applying its own norm / act / time bias where a workgroup holds whole groups
+    // of its image (epi.stats stays nullptr: the consumer reads a finished tensor)
+    const float* act_gamma;    // [Cout]
+    const float* act_beta;
+    const float* act_tbias;    // optional [B][act_tb_stride]
+    int act_tb_stride;
+    float act_inv_count;       // 1 / elements per (image, group)
     int cg, lg_upp;       // channels staged per group and log2 of its 16-byte units per pixel; set by the launcher
     long long* dbg;       // optional [workgroups][8] phase timestamps (tuning aid; nullptr in production)
     int cfg_tile, cfg_bn; // 0 = choose automatically; otherwise force the pixel tile (8 or 16) / channel tile (32 or 64)
@@ -80,6 +88,7 @@ struct ConvArgs {
 int launch_conv(ConvArgs& a, hipStream_t s);
 int conv_epi_slots(const ConvArgs& a);   // slots per (image, group) launch_conv will write
 int conv_tail_slots(const ConvArgs& a);  // same for tail_stats
+bool conv_act_fits(const ConvArgs& a);   // epi.G groups: the launch may apply its own GroupNorm + SiLU (act_* fields)
 bool conv_tail_fits(const ConvArgs& a);  // epi.G groups / their partial sums within the hand-off's limits
 int conv_init_attributes();
 void conv_set_debug_buffer(long long* dev);

@@ -75,7 +75,10 @@ struct DmnUnet {
     // with a pass of their own instead of inside block2.proj (no in-launch hand-off anywhere), bit 8 does the same for
     // the closing GroupNorm of the linear attentions only, bit 10 merges the split partials of a linear attention in a
     // launch of its own even where its second launch would merge them itself, bit 11 keeps the DDPM update a launch of its
-    // own instead of applying it in the network's last kernel.
+    // own instead of applying it in the network's last kernel, bit 12 leaves the GroupNorm + SiLU + time bias of every
+    // block1 to the convolution behind it (block2.proj) instead of block1.proj's own epilogue, bit 13 leaves the tail of a level's
+    // first ResnetBlock to the second block's first convolution (as everywhere above the levels that fit the in-launch
+    // exchange) instead of closing it in block2.proj, bit 14 does so only where closing it needs an exchange.
     int path_mask = 0;
     // diagnosis: workspace checksums after every launch of a forward (dmn_test_unet_trace)
     unsigned long long* trace_slots = nullptr;

@@ -683,12 +683,16 @@ def test_alternative_launch_paths_give_the_same_bits(monkeypatch):
     softmax, the block tail as a pass of its own: one more rounding than the fused multiply-add of the staging form; 128,
     block tails closed by a separate pass instead of inside block2.proj: same tensor, but its GroupNorm(1) partial sums
     are formed per convolution tile instead of per pixel slice), which stays within bf16 noise. 1024 merges the split
-    partials of the linear attentions in a launch of its own instead of inside their second launch: same arithmetic."""
+    partials of the linear attentions in a launch of its own instead of inside their second launch: same arithmetic.
+    4096 leaves block1's GroupNorm + SiLU + time bias at the 8x8 levels to the convolution behind it instead of
+    block1.proj's epilogue: same statistics, coefficients and arithmetic. 8192 leaves the tail of a level's first block
+    to the next block's first convolution instead of block2.proj's own epilogue (16384: only where that needs an exchange):
+    the consumer adds the residual inside the fused multiply-add of the SiLU, the producer after it -- bf16 noise."""
     g = torch.Generator(device="cuda").manual_seed(4)
     x = torch.randn(4, 3, 64, 64, device="cuda", generator=g)
     t = torch.tensor([3, 500, 999, 40], device="cuda")
     ref = build_unet64("bf16")(x, t)
-    for mask, exact in ((1, True), (16, True), (16 | 32, True), (1024, True), (4, False), (2, False), (8, False), (128, False)):
+    for mask, exact in ((1, True), (16, True), (16 | 32, True), (1024, True), (4096, True), (4, False), (8192, False), (16384, False), (2, False), (8, False), (128, False)):
         monkeypatch.setenv("DMN_UNET_PATHS", str(mask))
         y = build_unet64("bf16")(x, t)
         monkeypatch.delenv("DMN_UNET_PATHS")
@@ -698,6 +702,32 @@ def test_alternative_launch_paths_give_the_same_bits(monkeypatch):
             assert torch.equal(y, ref), (mask, float(d.max()))
         else:
             assert float(d.max()) < 0.15 and float(d.mean()) < 5e-3, (mask, float(d.max()), float(d.mean()))
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_block1_activation_in_its_own_epilogue_gives_the_bits_of_the_consumer_side_form(dtype, monkeypatch):
+    """Where a workgroup of block1.proj holds whole GroupNorm groups of its image (8x8 pixels: the lowest level and the
+    middle blocks at 64x64 input, more at 32x32 input), its epilogue applies the block's GroupNorm + SiLU + time bias
+    (parts/convnext.py:33-45,82-84) and block2.proj reads a finished tensor. Statistics, coefficients and arithmetic are
+    those of block2.proj normalising while it stages, so the network output must be bit-identical (also combined with
+    8192: the first block of a level leaves its tail to the second block's first convolution instead of closing
+    itself), with and without the in-launch exchanges, for plain and class-conditional / learned-variance networks and ragged sizes."""
+    g = torch.Generator(device="cuda").manual_seed(9)
+    cases = [((4, 3, 64, 64), {}), ((3, 3, 32, 32), {}), ((2, 3, 48, 40), {}), ((2, 3, 64, 64), {"learned_variance": True})]
+    for base in (0, 128):
+        for shape, kw in cases:
+            x = torch.randn(*shape, device="cuda", generator=g)
+            t = torch.randint(0, 1000, (shape[0],), device="cuda", generator=g)
+            outs = []
+            for mask in (base, base | 4096, base | 8192, base | 4096 | 8192):
+                monkeypatch.setenv("DMN_UNET_PATHS", str(mask))
+                outs.append(build_unet64(dtype, **kw)(x, t))
+                monkeypatch.delenv("DMN_UNET_PATHS")
+            assert torch.isfinite(outs[0]).all()
+            assert torch.equal(outs[0], outs[1]), (base, shape, kw, float((outs[0] - outs[1]).abs().max()))
+            assert torch.equal(outs[2], outs[3]), (base, shape, kw, float((outs[2] - outs[3]).abs().max()))
+            if dtype == "fp32":   # who closes a level's first block changes bf16 roundings only
+                assert torch.equal(outs[0], outs[2]), (base, shape, kw, float((outs[0] - outs[2]).abs().max()))
 
 
 def test_two_launch_chains_never_starve_an_in_launch_exchange():
