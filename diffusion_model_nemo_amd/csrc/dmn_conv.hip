@@ -773,9 +773,13 @@ TileCfg pick_cfg(const ConvArgs& a) {
     if (c.th == 8 && c.bn == 64 && blocks(c) < 256) c.bn = 32;
     // The sampling loop launches half the planning batch per chain: 3x3 launches that would leave half the CUs of a chain
     // without a workgroup take the 32-channel tile (measured with two chains on MI355X: 64 channels at 32x32 pixels
-    // -0.7 % of the step, 256 channels at 8x8 -0.6 %; at 16x16 pixels and for the 1x1 kernels the wider tile stays ahead).
+    // -0.7 % of the step, 256 channels at 8x8 -0.6 %, 64 channels at 16x16 -0.7 %; 128 channels at 16x16 already have 512
+    // workgroups and lose 1 % with the narrow tile, and for the 1x1 kernels the wider tile stays ahead).
+    // Several 8x8 tiles per image only while the image keeps at most kHandoffMaxWgsPerImage workgroups, so that the
+    // launch still fits the in-launch exchange.
+    const int tiles8 = ((a.Ho + 7) / 8) * ((a.Wo + 7) / 8);
     if (a.kind == DMN_K3X3 && c.bn == 64 && blocks(c) < 512 && !(a.w2 && c.th == 16) &&
-        (c.th == 16 || ((a.Ho + 7) / 8) * ((a.Wo + 7) / 8) == 1))
+        (c.th == 16 || tiles8 == 1 || tiles8 * (a.Cout / 32) <= kHandoffMaxWgsPerImage))
         c.bn = 32;
     if (a.w2 && c.th == 16 && c.bn == 64) c.th = c.tw = 8;   // two accumulator sets: keep the per-wave tile small
     return c;
