@@ -1,8 +1,4 @@
-#!/bin/bash
-# usage: tools/train_sweep.sh <env var> <values...>: the configuration-5 timing under each value of a tuning variable
-var=$1; shift
-cd $GRAFT_REPO_ROOT
-for v in "$@"; do
-  echo "$var=$v" >> gpurun_out/sweep_$var.log
-  env $var=$v timeout -k 10 200 python tools/train_bench.py --steps 10 --warmup 3 2>/dev/null | tail -1 >> gpurun_out/sweep_$var.log || exit 1
-done
+o=gpurun_out/train_sweep.txt; : > $o
+run() { env $1 timeout -k 10 120 python tools/train_bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1', d.get('ms_per_step'))" >> $o || exit 1; }
+run X=base; run DMN_LINATTN_WGS=1024; run DMN_LINATTN_WGS=4096; run DMN_PGEMM_SMALL=1024; run DMN_PGEMM_SMALL=256; run DMN_PGEMM_C32_TILES=4; run DMN_PGEMM_C32_TILES=16; run DMN_WGEMM_WGS=192; run DMN_WGEMM_WGS=320; run X=base2
+cat $o
