@@ -299,44 +299,77 @@ extern "C" int dmn_pc_sample_loop(DmnUnet* u, const float* table, int nsteps, fl
     DMN_REQUIRE(corrector >= 0 && corrector <= 2 && predictor >= 0 && predictor <= 1 && n_corrector_steps >= 0 &&
                     n_corrector_steps <= 64, DMN_ERR_INVALID, "dmn_pc_sample_loop: bad predictor/corrector selection");
     hipStream_t s = (hipStream_t)stream;
-    LoopBufs lb;
-    int rc = carve(u, B, H, W, workspace, workspace_bytes, lb, nullptr);
-    if (rc) return rc;
     const int C = u->cfg.channels;
-    float* xmean = x_mean_out ? x_mean_out : lb.xmean;
-    DMN_HIP_CHECK(hipMemsetAsync(lb.step_idx, 0, 256, s));
+    // Without a corrector nothing couples the images of a batch (the Langevin step size is a batch mean; the predictors
+    // are per element): the loop then runs as two half-batch launch chains like the DDPM loop, with the same bits.
+    const int nchains = (s && !corrector) ? ddpm_chains(u, B) : 1;
+    const int Bc = B / nchains;
+    LoopBufs lb[2];
+    int rc;
+    size_t per_chain = 0;
+    if (nchains == 2) {
+        if ((rc = carve(u, Bc, H, W, nullptr, 0, lb[0], &per_chain))) return rc;
+        per_chain = align256(per_chain);
+        DMN_REQUIRE(workspace_bytes >= 2 * per_chain, DMN_ERR_WORKSPACE, "sampling workspace too small: %zu < %zu",
+                    workspace_bytes, 2 * per_chain);
+    } else {
+        per_chain = workspace_bytes;
+    }
+    for (int c = 0; c < nchains; ++c) {
+        if ((rc = carve(u, Bc, H, W, (char*)workspace + c * per_chain, per_chain, lb[c], nullptr))) return rc;
+        DMN_HIP_CHECK(hipMemsetAsync(lb[c].step_idx, 0, 256, s));
+    }
     if (draw_prior && (rc = launch_prior(x, B, C * H * W, seed, (unsigned)nsteps, img_offset, prior_scale, s))) return rc;
-    SampleKey key = {x, table, workspace, keep, xmean, 2, B, H, W,
+    SampleKey key = {x, table, workspace, keep, x_mean_out, 2 | (nchains << 8), B, H, W,
                      predictor | (corrector << 2) | (n_corrector_steps << 4) | (denoise << 12), nsteps, seed, img_offset, snr, u->labels};
-    auto body = [&]() -> int {
+    const size_t img = (size_t)C * H * W;
+    auto body = [&](int c, hipStream_t cs) -> int {
+        const int b0 = c * Bc;   // first image of the chain
+        float* xc = x + b0 * img;
+        float* keepc = keep ? keep + b0 * img : nullptr;
+        float* xmean = x_mean_out ? x_mean_out + b0 * img : lb[c].xmean;
+        const long long keep_stride = (long long)B * C * H * W;   // kept images of all chains share one [n_kept][B] buffer
         int r;
+        u->label_offset = b0;
+        u->chain_id = c;
+        auto forward = [&]() {
+            return unet_forward_impl(u, xc, nullptr, 1, table, lb[c].step_idx, lb[c].net, Bc, H, W, lb[c].arena, lb[c].arena_bytes, cs,
+                                     false, nullptr);
+        };
+        auto done = [&](int code) {
+            u->label_offset = 0;
+            u->chain_id = 0;
+            return code;
+        };
         if (corrector) {
             for (int k = 0; k < n_corrector_steps; ++k) {
-                if ((r = unet_forward_impl(u, x, nullptr, 1, table, lb.step_idx, lb.net, B, H, W, lb.arena, lb.arena_bytes, s, false, nullptr))) return r;
+                if ((r = forward())) return done(r);
                 LangevinArgs a;
                 memset(&a, 0, sizeof(a));
                 // without a predictor the image kept for an iteration is the corrector's x (NonePredictor returns
                 // (x, x), predictor_corrector_sampler.py:105-113): the last inner step writes it
-                a.c = step_common(table, lb.step_idx, 0, x, lb.net, nullptr, x, B, C, H * W, seed, img_offset,
-                                  (!predictor && k == n_corrector_steps - 1) ? keep : nullptr);
-                a.partials = lb.partials;
+                a.c = step_common(table, lb[c].step_idx, 0, xc, lb[c].net, nullptr, xc, Bc, C, H * W, seed, img_offset + b0,
+                                  (!predictor && k == n_corrector_steps - 1) ? keepc : nullptr);
+                a.c.keep_stride = keep_stride;
+                a.partials = lb[c].partials;
                 a.inner = k;
                 a.use_norms = corrector == 1;
                 a.snr = snr;
-                if ((r = launch_langevin(a, s))) return r;
+                if ((r = launch_langevin(a, cs))) return done(r);
             }
         }
         if (predictor) {
-            if ((r = unet_forward_impl(u, x, nullptr, 1, table, lb.step_idx, lb.net, B, H, W, lb.arena, lb.arena_bytes, s, false, nullptr))) return r;
+            if ((r = forward())) return done(r);
             AffineStepArgs a;
-            a.c = step_common(table, lb.step_idx, 0, x, lb.net, nullptr, x, B, C, H * W, seed, img_offset, keep);
+            a.c = step_common(table, lb[c].step_idx, 0, xc, lb[c].net, nullptr, xc, Bc, C, H * W, seed, img_offset + b0, keepc);
+            a.c.keep_stride = keep_stride;
             a.x_mean = xmean;
             a.keep_mean = denoise;
-            if ((r = launch_affine_step(a, s))) return r;
+            if ((r = launch_affine_step(a, cs))) return done(r);
         }
-        return launch_advance(lb.step_idx, s);
+        return done(launch_advance(lb[c].step_idx, cs));
     };
-    return run_loop(u, key, nsteps, s, use_graph, 1, [&](int, hipStream_t) { return body(); });
+    return run_loop(u, key, nsteps, s, use_graph, nchains, body);
 }
 
 extern "C" int dmn_bpd_loop(DmnUnet* u, const float* table, int nsteps, const float* x0, int B, int H, int W,
