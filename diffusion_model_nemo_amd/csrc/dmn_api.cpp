@@ -381,31 +381,54 @@ extern "C" int dmn_bpd_loop(DmnUnet* u, const float* table, int nsteps, const fl
     DMN_REQUIRE(u->cfg.out_dim == u->cfg.channels * (learned_variance ? 2 : 1), DMN_ERR_INVALID,
                 "network emits %d channels, evaluation expects %d", u->cfg.out_dim, u->cfg.channels * (learned_variance ? 2 : 1));
     hipStream_t s = (hipStream_t)stream;
-    LoopBufs lb;
-    int rc = carve(u, B, H, W, workspace, workspace_bytes, lb, nullptr);
-    if (rc) return rc;
     const int C = u->cfg.channels;
-    DMN_REQUIRE((size_t)B * bpd_slots(C * H * W) * 4 <= dmn_sde_scratch_bytes(B, C, H, W), DMN_ERR_WORKSPACE,
+    // every term is per image: two half-batch launch chains like the DDPM loop
+    const int nchains = s ? ddpm_chains(u, B) : 1;
+    const int Bc = B / nchains;
+    LoopBufs lb[2];
+    int rc;
+    size_t per_chain = 0;
+    if (nchains == 2) {
+        if ((rc = carve(u, Bc, H, W, nullptr, 0, lb[0], &per_chain))) return rc;
+        per_chain = align256(per_chain);
+        DMN_REQUIRE(workspace_bytes >= 2 * per_chain, DMN_ERR_WORKSPACE, "sampling workspace too small: %zu < %zu",
+                    workspace_bytes, 2 * per_chain);
+    } else {
+        per_chain = workspace_bytes;
+    }
+    for (int c = 0; c < nchains; ++c) {
+        if ((rc = carve(u, Bc, H, W, (char*)workspace + c * per_chain, per_chain, lb[c], nullptr))) return rc;
+        DMN_HIP_CHECK(hipMemsetAsync(lb[c].step_idx, 0, 256, s));
+    }
+    DMN_REQUIRE((size_t)Bc * bpd_slots(C * H * W) * 4 <= dmn_sde_scratch_bytes(Bc, C, H, W), DMN_ERR_WORKSPACE,
                 "dmn_bpd_loop: scratch too small");
-    DMN_HIP_CHECK(hipMemsetAsync(lb.step_idx, 0, 256, s));
     if ((rc = launch_bpd_prior(x0, prior, B, C * H * W, prior_sqrt_acp, prior_log_1m_acp, s))) return rc;
-    SampleKey key = {x0, table, workspace, terms, prior, 3, B, H, W, learned_variance, nsteps, seed, img_offset,
+    SampleKey key = {x0, table, workspace, terms, prior, 3 | (nchains << 8), B, H, W, learned_variance, nsteps, seed, img_offset,
                      (float)terms_stride, u->labels};
-    auto body = [&]() -> int {
+    const size_t img = (size_t)C * H * W;
+    auto body = [&](int c, hipStream_t cs) -> int {
+        const int b0 = c * Bc;   // first image of the chain
         BpdArgs a;
         memset(&a, 0, sizeof(a));
-        a.c = step_common(table, lb.step_idx, 0, x0, lb.net, nullptr, lb.xmean, B, C, H * W, seed, img_offset, nullptr);
-        a.partials = lb.partials;
-        a.terms = terms;
+        a.c = step_common(table, lb[c].step_idx, 0, x0 + b0 * img, lb[c].net, nullptr, lb[c].xmean, Bc, C, H * W, seed,
+                          img_offset + b0, nullptr);
+        a.partials = lb[c].partials;
+        a.terms = terms + (size_t)b0 * terms_stride;
         a.terms_stride = terms_stride;
         a.learned_variance = learned_variance;
         int r;
-        if ((r = launch_bpd_qsample(a, s))) return r;
-        if ((r = unet_forward_impl(u, lb.xmean, nullptr, 1, table, lb.step_idx, lb.net, B, H, W, lb.arena, lb.arena_bytes, s, false, nullptr))) return r;
-        if ((r = launch_bpd_term(a, s))) return r;
-        return launch_advance(lb.step_idx, s);
+        if ((r = launch_bpd_qsample(a, cs))) return r;
+        u->label_offset = b0;
+        u->chain_id = c;
+        r = unet_forward_impl(u, lb[c].xmean, nullptr, 1, table, lb[c].step_idx, lb[c].net, Bc, H, W, lb[c].arena, lb[c].arena_bytes,
+                              cs, false, nullptr);
+        u->label_offset = 0;
+        u->chain_id = 0;
+        if (r) return r;
+        if ((r = launch_bpd_term(a, cs))) return r;
+        return launch_advance(lb[c].step_idx, cs);
     };
-    return run_loop(u, key, nsteps, s, use_graph, 1, [&](int, hipStream_t) { return body(); });
+    return run_loop(u, key, nsteps, s, use_graph, nchains, body);
 }
 
 extern "C" int dmn_loop_last_ms(DmnUnet* u, float* ms) {

@@ -155,7 +155,8 @@ int dmn_ddpm_loop_chains(const DmnUnet* u, int B);
  * x_t = q_sample(x0, t) with generator stream 3, network evaluation, then the per-sample variational-bound term in
  * bits (VariationalBoundLoss.compute_variation_loss_terms, loss/variational_bound_loss.py:31-52) into
  * terms[b * terms_stride + t]. prior[b] receives the prior term computed from sqrt(a_{T-1}) and log(1 - a_{T-1}).
- * x0, terms, prior: device float32. workspace: >= dmn_sample_workspace_bytes. */
+ * x0, terms, prior: device float32. workspace: >= dmn_sample_workspace_bytes. Every term is per image: the loop runs as
+ * two half-batch launch chains like dmn_ddpm_sample_loop (same bits). */
 int dmn_bpd_loop(DmnUnet* u, const float* table, int nsteps, const float* x0, int B, int H, int W, int learned_variance,
                  uint64_t seed, int64_t img_offset, float* terms, int terms_stride, float* prior, float prior_sqrt_acp,
                  float prior_log_1m_acp, void* workspace, size_t workspace_bytes, void* stream, int use_graph);

@@ -130,6 +130,38 @@ def test_bits_per_dimension_matches_reference_golden(tag, lv):
     assert r["terms_bpd"].shape == (2, 20)
 
 
+@pytest.mark.parametrize("lv", [False, True])
+def test_bits_per_dimension_in_two_launch_chains_gives_the_bits_of_one_chain(lv):
+    """Every term of calculate_bits_per_dimension is per image, so an even batch of 16 or more runs as two half-batch
+    launch chains like the DDPM loop: same terms, prior and total as one chain, bit for bit; the first two images equal the
+    two-image evaluation the reference golden pins."""
+    from diffusion_model_nemo_amd.models import DDPM
+    g = load_golden("bpd_T20_B2_32")
+    cfg = {"image_size": 32, "timesteps": 20, "channels": 3,
+           "diffusion_model": {"_target_": "diffusion_model_nemo.modules.Unet", "input_dim": 32, "dim": 32,
+                               "dim_mults": [1, 2, 4, 8], "use_convnext": False, "dropout": 0.0,
+                               "learned_variance": lv, "compute_dtype": "fp32"},
+           "sampler": {"_target_": "diffusion_model_nemo.modules." + ("LearnedGaussianDiffusion" if lv else "GaussianDiffusion"),
+                       "timesteps": 20, "schedule_name": "cosine"},
+           "loss": {"_target_": "diffusion_model_nemo.loss.DiffusionLoss", "loss_type": "l2", "reduction": "mean"}}
+    m = DDPM(cfg)
+    sd = make_state_dict(unet_param_shapes(learned_variance=lv))
+    m.diffusion_model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.cuda().eval()
+    gen = torch.Generator().manual_seed(3)
+    x0 = torch.cat([T(g["x0"]), torch.rand(16, 3, 32, 32, generator=gen) * 2 - 1]).cuda()   # 18 images: two chains of 9
+    net = m.diffusion_model
+    net.set_sample_chains(1)
+    one = m.calculate_bits_per_dimension(x0, m.get_diffusion_model({}), seed=4)
+    net.set_sample_chains(2)
+    for rep in range(2):
+        two = m.calculate_bits_per_dimension(x0, m.get_diffusion_model({}), seed=4)
+        for k in ("terms_bpd", "prior_bpd", "total_bpd"):
+            assert torch.equal(one[k], two[k]), (k, rep)
+    small = m.calculate_bits_per_dimension(x0[:2], m.get_diffusion_model({}), seed=4)
+    assert torch.equal(small["terms_bpd"], two["terms_bpd"][:2])
+
+
 def test_class_conditional_unet_and_sampling():
     """unet.py:118-141 and models/conditional_ddpm.py:44-88: labelled / null-class forwards against the reference
     golden; the conditional sampling call shape (a partial of forward) stays on the device loop and equals the
