@@ -300,9 +300,10 @@ extern "C" int dmn_pc_sample_loop(DmnUnet* u, const float* table, int nsteps, fl
                     n_corrector_steps <= 64, DMN_ERR_INVALID, "dmn_pc_sample_loop: bad predictor/corrector selection");
     hipStream_t s = (hipStream_t)stream;
     const int C = u->cfg.channels;
-    // Without a corrector nothing couples the images of a batch (the Langevin step size is a batch mean; the predictors
-    // are per element): the loop then runs as two half-batch launch chains like the DDPM loop, with the same bits.
-    const int nchains = (s && !corrector) ? ddpm_chains(u, B) : 1;
+    // Only the Langevin corrector couples the images of a batch (its step size is a batch mean; the predictors and the
+    // fixed-step annealed Langevin dynamics are per element): every other configuration runs as two half-batch launch
+    // chains like the DDPM loop, with the same bits.
+    const int nchains = (s && corrector != 1) ? ddpm_chains(u, B) : 1;
     const int Bc = B / nchains;
     LoopBufs lb[2];
     int rc;

@@ -134,8 +134,9 @@ int dmn_sde_corrector_step_static(const float* table, int row, const float* x, c
 
 /* PredictorCorrectorSampler.forward (sde_samplers/predictor_corrector_sampler.py:58-120): corrector then predictor
  * per iteration. corrector: 0 none, 1 langevin, 2 ald. predictor: 0 none, 1 affine (table rows). `keep` receives
- * x_mean (denoise != 0) or x after every iteration. prior_scale: sigma_max for VE, 1 for VP. Without a corrector the
- * images of a batch are independent and the loop runs as two half-batch launch chains like dmn_ddpm_sample_loop
+ * x_mean (denoise != 0) or x after every iteration. prior_scale: sigma_max for VE, 1 for VP. Unless the corrector is
+ * langevin (its step size is a batch mean) the images of a batch are independent and the loop runs as two half-batch
+ * launch chains like dmn_ddpm_sample_loop
  * (same bits; the workspace of dmn_sample_workspace_bytes covers both layouts). */
 int dmn_pc_sample_loop(DmnUnet* u, const float* table, int nsteps, float* x, int B, int H, int W, int predictor,
                        int corrector, int n_corrector_steps, float snr, int denoise, int draw_prior, float prior_scale,

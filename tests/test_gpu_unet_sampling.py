@@ -623,17 +623,18 @@ def test_two_launch_chains_give_the_bits_of_one_chain(dtype, lv):
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp32"])
 def test_predictor_only_sde_loop_in_two_launch_chains_gives_the_bits_of_one_chain(dtype):
-    """Without a corrector nothing couples the images of a batch (predictor_corrector_sampler.py:97-113: the predictors
-    are per element; only the Langevin step size is a batch mean), so the predictor-corrector loop runs a predictor-only
-    configuration -- the shipped default euler_maruyama + no corrector -- as two half-batch launch chains like the DDPM
-    loop. Every kept image and the final denoised mean must equal the single chain bit for bit; with a corrector the
-    loop keeps one chain whatever the setting."""
+    """Only the Langevin corrector couples the images of a batch (langevin_corrector.py:26-33: its step size is a batch
+    mean; the predictors and the fixed-step annealed Langevin dynamics, annealed_langevin_dynamics_corrector.py:34-39, are
+    per element), so the predictor-corrector loop runs every other configuration -- among them the shipped default
+    euler_maruyama + no corrector -- as two half-batch launch chains like the DDPM loop. Every kept image and the final
+    denoised mean must equal the single chain bit for bit; with the Langevin corrector the loop keeps one chain whatever
+    the setting."""
     from diffusion_model_nemo_amd.modules import VESDE, VPSDE, PredictorCorrectorSampler
     u = build_unet(dtype, groups=4)
     N = 12
     cases = [("ve", "euler_maruyama", None, {}), ("ve", "reverse_diffusion", None, {"denoise": False}),
              ("ve", "ancestral_sampling", None, {}), ("vp", "euler_maruyama", None, {"probability_flow": False}),
-             ("ve", "reverse_diffusion", "langevin", {})]
+             ("ve", "ancestral_sampling", "ald", {}), ("ve", None, "ald", {}), ("ve", "reverse_diffusion", "langevin", {})]
     for kind, pred, corr, kw in cases:
         sde = VESDE(0.01, 50.0, N) if kind == "ve" else VPSDE(0.1, 20.0, N)
         s = PredictorCorrectorSampler(predictor=pred, corrector=corr, snr=0.16, n_steps=1, **kw)
