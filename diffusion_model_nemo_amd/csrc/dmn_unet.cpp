@@ -261,6 +261,14 @@ struct Fwd {
         a.stats = nullptr;
     }
     int planB() const { return u->plan_batch > 0 ? u->plan_batch : B; }
+    // tuning aid: the convolution launches of an evaluation are numbered; the one selected by DmnUnet::probe_site gets the
+    // per-workgroup phase stamps (in place, also inside captured steps)
+    int conv_seq = 0;
+    long long* site_stamps() {
+        const int seq = conv_seq++;
+        if (dry || u->probe_on != 2 || !u->probe_stamps || u->probe_site < 0 || seq != u->probe_site) return nullptr;
+        return u->probe_stamps + (size_t)u->chain_id * kProbeMaxWgs * 8;
+    }
     bool ok() const { return rc == DMN_OK; }
     // granule area of this chain (dmn_handoff.h): every fused launch takes the next range. The dry run only adds up;
     // a real run returns nullptr when the area is missing or too small and the caller takes the two-launch form.
@@ -354,7 +362,8 @@ static Act do_conv(Fwd& f, const PackedConv& pc, const Act& in0, const Act* in1,
     if (f.ok() && !f.dry) {
         // measurement hook: events around the dominant launch as it runs inside the step (block2.proj of downs.0.0)
         DmnUnet* u = f.u;
-        const bool target = u->probe_on && &pc == &u->downs[0].rb[0].c2;
+        if (long long* st = f.site_stamps()) a.dbg = st;
+        const bool target = u->probe_on && u->probe_site < 0 && &pc == &u->downs[0].rb[0].c2;
         bool probe = target && u->probe_on == 1 && u->probe_n < kProbePairs;
         if (probe) {   // never inside a stream capture: a captured event record carries no time
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -435,6 +444,7 @@ static Act resblock(Fwd& f, const ResBlockW& w, Act& x, Act* x2, const float* tb
             h1.stats = f.new_stats(G, h1.sSlots);
             a.epi.stats = h1.stats;
         }
+        if (long long* st = f.site_stamps()) a.dbg = st;
         if (f.ok() && !f.dry) f.run(launch_conv(a, f.s), "conv1 + previous block's tail");
         f.free_act(pending->h2);
         if (pending->has_r) f.free_act(pending->r);
@@ -479,6 +489,7 @@ static Act resblock(Fwd& f, const ResBlockW& w, Act& x, Act* x2, const float* tb
                     out.stats = f.new_stats(statsG, out.sSlots);
                     a.tail_stats.stats = out.stats;
                 }
+                if (long long* st = f.site_stamps()) a.dbg = st;
                 if (f.ok() && !f.dry) f.run(launch_conv(a, f.s), "conv2 + block tail (in-launch statistics)");
                 f.free_act(h1);
                 if (w.has_res) f.free_act(r);
@@ -1312,6 +1323,7 @@ extern "C" int dmn_unet_create(const DmnUnetCfg* cfg, DmnUnet** out) {
     u->cfg = *cfg;
     if (const char* e = getenv("DMN_UNET_PATHS")) u->path_mask = atoi(e);
     if (const char* e = getenv("DMN_SAMPLE_CHAINS")) u->sample_chains = atoi(e) == 1 ? 1 : 2;
+    if (const char* e = getenv("DMN_PROBE_SITE")) u->probe_site = atoi(e);
     if (const char* e = getenv("DMN_SAMPLE_SKEW_US")) u->sample_skew_us = atoi(e) < 0 ? 0 : (atoi(e) > 5000 ? 5000 : atoi(e));
     u->downs.resize(cfg->n_mults);
     u->ups.resize(cfg->n_mults - 1);
@@ -1527,6 +1539,17 @@ extern "C" int dmn_unet_workspace_bytes(const DmnUnet* u, int B, int H, int W, s
     *bytes = high + 4096;
     // the granule areas of the in-launch hand-offs belong to the handle and grow with the largest shape asked about
     if (!(u->path_mask & 128) && (rc = unet_reserve_handoff(uu, handoff))) return rc;
+    return DMN_OK;
+}
+
+// Tuning aid: the raw per-workgroup stamps ([n][8] 64-bit words, layout in dmn_conv.hip) of the launch selected by
+// DMN_PROBE_SITE, as its last execution on launch chain `chain` left them.
+extern "C" int dmn_test_probe_read(DmnUnet* u, int chain, long long* host, int nwgs) {
+    DMN_REQUIRE(u && host && chain >= 0 && chain < 2 && nwgs > 0 && nwgs <= kProbeMaxWgs && u->probe_stamps, DMN_ERR_INVALID,
+                "dmn_test_probe_read: bad argument or probe never enabled");
+    DMN_HIP_CHECK(hipDeviceSynchronize());
+    DMN_HIP_CHECK(hipMemcpy(host, u->probe_stamps + (size_t)chain * kProbeMaxWgs * 8, (size_t)nwgs * 8 * sizeof(long long),
+                            hipMemcpyDeviceToHost));
     return DMN_OK;
 }
 

@@ -106,6 +106,8 @@ struct DmnUnet {
     std::vector<hipEvent_t> probe_ev;    // 3 * kProbePairs events once enabled
     int probe_n = 0;                     // pairs recorded since the probe was switched on
     int probe_on = 0;                    // 1: HIP events around eager launches, 2: device clock stamps (also in graphs)
+    int probe_site = -1;                 // tuning aid (environment DMN_PROBE_SITE): with probe_on == 2 the n-th convolution launch
+                                         // of an evaluation stamps its phases instead of the dominant one (dmn_test_probe_read)
     long long* probe_stamps = nullptr;   // [2 chains][kProbeMaxWgs][8] per-workgroup stamps of the probed launch
     unsigned long long* probe_acc = nullptr;   // per chain {sum of spans in 10 ns ticks, launches}
     double probe_bytes = 0.0;            // algorithmic bytes of one probed launch

@@ -80,6 +80,10 @@ int dmn_unet_set_plan_batch(DmnUnet* u, int batch);
  * asked about; a shape never asked about runs the separate closing passes instead). The waits are bounded (0.5 s); one
  * that runs out is counted and the evaluation's result is invalid. Returns the count since the handle was created;
  * waits for the device. No counterpart in the reference. */
+/* Tuning aid, no counterpart in the reference: per-workgroup phase stamps of the convolution launch selected by the
+ * environment variable DMN_PROBE_SITE (its number among an evaluation's convolution launches), taken inside the sampling
+ * loops while dmn_unet_probe_dominant(u, 2) is on. host: [nwgs][8] 64-bit words. */
+int dmn_test_probe_read(DmnUnet* u, int chain, long long* host, int nwgs);
 int dmn_unet_handoff_giveups(DmnUnet* u, unsigned* count);
 
 /* eps = Unet(x, t).  t: [B] int64 (t_is_float = 0) or float32 (1), device memory. out: [B][out_dim][H][W]. */
