@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_dominant_kernel_traffic.json")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -49,7 +49,17 @@ def parse():
     ap.add_argument("--learned-variance", action="store_true",
                     help="improved DDPM: 6-channel network + LearnedGaussianDiffusion (benchmark configuration 3 per GPU)")
     ap.add_argument("--probe-steps", type=int, default=100, help="eager steps for the in-loop timing of the dominant kernel")
-    return ap.parse_args()
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for --gpus > 1 (nccl is RCCL on ROCm; gloo only together with --dry-run)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rehearsal of the multi-rank control flow on CPU tensors: the sampler is replaced by one that fills every "
+                         "image with its global index and the training step by a fixed gradient, so process-group set-up, image "
+                         "offsets, the gather, the agreement reduce of the training extra, the timing reduce and the JSON line "
+                         "can be exercised without a GPU (the number it prints measures nothing)")
+    a = ap.parse_args(argv)
+    if a.backend == "gloo" and not a.dry_run:
+        ap.error("--backend gloo moves no device tensors here: use it with --dry-run")
+    return a
 
 
 def cpu_model_name():
@@ -106,34 +116,63 @@ def cpu_baseline(batch, image_size, timesteps, budget_s, learned_variance=False)
             "config1_32x32_batch4": c1}
 
 
-def train_step_extra(dev, rank, world, dist):
+def _dry_train_step(dev, rank, world):
+    """Stand-in for the training step in --dry-run: a fixed per-rank gradient through the same all-reduce helper."""
+    from diffusion_model_nemo_amd.parallel import all_reduce_flat_grads
+
+    def step(i, reduce):
+        grads = torch.full((1024,), float(rank + 1), device=dev)
+        scale = all_reduce_flat_grads(grads) if reduce else 1.0
+        if reduce:   # the mean over the ranks of (rank + 1)
+            assert abs(float(grads[0]) * scale - (world + 1) / 2.0) < 1e-6, (float(grads[0]), scale)
+        return torch.tensor(1.0 / (i + 1), device=dev)
+
+    return step
+
+
+def _real_train_step(dev, rank):
+    from diffusion_model_nemo_amd.modules import GaussianDiffusion, Unet
+    from diffusion_model_nemo_amd.training import UnetTrainer, cosine_annealing_lr
+    Bt, St = 32, 128
+    net = Unet(input_dim=St, dim=32, dim_mults=[1, 2, 4, 8], channels=3, resnet_block_groups=8, use_convnext=False,
+               dropout=0.0, compute_dtype="bf16").to(dev)
+    tr = UnetTrainer(net, "l2")
+    gd = GaussianDiffusion(timesteps=1000, schedule_name="cosine")
+    sa, sb = gd.sqrt_alphas_cumprod.to(dev), gd.sqrt_one_minus_alphas_cumprod.to(dev)
+    gen = torch.Generator(device=dev).manual_seed(100 + rank)
+    x0 = torch.rand(Bt, 3, St, St, device=dev, generator=gen) * 2 - 1
+
+    def step(i, reduce):
+        t = torch.randint(0, 1000, (Bt,), device=dev, generator=gen)
+        eps = torch.randn(Bt, 3, St, St, device=dev, generator=gen)
+        loss = tr.loss_and_grads(x0, t, eps, sa, sb)
+        scale = tr.all_reduce_grads() if reduce else 1.0
+        tr.optimizer_step(lr=cosine_annealing_lr(i, 10000, 1e-3, 1e-4), betas=(0.9, 0.98), weight_decay=1e-3,
+                          max_grad_norm=1.0, grad_scale=scale)
+        return loss
+
+    return step
+
+
+def train_step_extra(dev, rank, world, dist, dry=False):
     """Extra, reported beside the headline: the DDPM training step of benchmark configuration 5 (128x128, 32 images per
     GPU: q_sample + forward + L_simple + backward, ONE all-reduce of the flat gradient buffer over RCCL when N > 1,
     global-norm clip + AdamW), bf16 matrix-core operands, fp32 activations. Every rank first runs one step without any
     collective and the ranks agree that all succeeded before the timed loop with the all-reduce starts, so a failure
     here cannot hang the job; it only drops this entry."""
-    ok, tr, step = 1, None, None
+    ok, step = 1, None
+
+    def sync():
+        if not dry:
+            torch.cuda.synchronize(dev)
+
     try:
-        from diffusion_model_nemo_amd.modules import GaussianDiffusion, Unet
-        from diffusion_model_nemo_amd.training import UnetTrainer, cosine_annealing_lr
-        Bt, St = 32, 128
-        net = Unet(input_dim=St, dim=32, dim_mults=[1, 2, 4, 8], channels=3, resnet_block_groups=8, use_convnext=False,
-                   dropout=0.0, compute_dtype="bf16").to(dev)
-        tr = UnetTrainer(net, "l2")
-        gd = GaussianDiffusion(timesteps=1000, schedule_name="cosine")
-        sa, sb = gd.sqrt_alphas_cumprod.to(dev), gd.sqrt_one_minus_alphas_cumprod.to(dev)
-        gen = torch.Generator(device=dev).manual_seed(100 + rank)
-        x0 = torch.rand(Bt, 3, St, St, device=dev, generator=gen) * 2 - 1
-
-        def step(i, reduce):
-            t = torch.randint(0, 1000, (Bt,), device=dev, generator=gen)
-            eps = torch.randn(Bt, 3, St, St, device=dev, generator=gen)
-            loss = tr.loss_and_grads(x0, t, eps, sa, sb)
-            scale = tr.all_reduce_grads() if reduce else 1.0
-            tr.optimizer_step(lr=cosine_annealing_lr(i, 10000, 1e-3, 1e-4), betas=(0.9, 0.98), weight_decay=1e-3,
-                              max_grad_norm=1.0, grad_scale=scale)
-            return loss
-
+        if dry:
+            step = _dry_train_step(dev, rank, world)
+            if os.environ.get("DMN_BENCH_DRY_FAIL_RANK") == str(rank):   # rehearsal of a rank that cannot run the extra
+                raise RuntimeError("injected failure")
+        else:
+            step = _real_train_step(dev, rank)
         first = float(step(0, False))
         ok = 1 if first == first else 0   # NaN check
     except Exception as e:   # noqa: BLE001 - the headline number must survive a failure of the extra
@@ -144,18 +183,18 @@ def train_step_extra(dev, rank, world, dist):
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if int(flag.item()) == 0:
         return None
-    warm, iters = 4, 20
+    warm, iters = (1, 2) if dry else (4, 20)
     for i in range(warm):
         step(1 + i, True)
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize(dev)
+    sync()
     t0 = time.perf_counter()
     for i in range(iters):
         loss = step(1 + warm + i, True)
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize(dev)
+    sync()
     tt = torch.tensor([(time.perf_counter() - t0) / iters], device=dev, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -168,41 +207,54 @@ def train_step_extra(dev, rank, world, dist):
             "tflops_per_gpu": 32 * 3 * 10.677e9 / dt / 1e12, "loss": float(loss)}
 
 
-def main():
-    a = parse()
+def main(argv=None):
+    a = parse(argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    dry = a.dry_run
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
+    dev = torch.device("cpu") if dry else torch.device("cuda", local)
+    if not dry:
+        torch.cuda.set_device(dev)
 
-    from diffusion_model_nemo_amd import _native as N
-    from diffusion_model_nemo_amd.modules import GaussianDiffusion, LearnedGaussianDiffusion, Unet
     from diffusion_model_nemo_amd.parallel import gather_images
-
-    torch.manual_seed(1234)
-    unet = Unet(input_dim=a.image_size, dim=32, dim_mults=[1, 2, 4, 8], channels=3, resnet_block_groups=8,
-                use_convnext=False, dropout=0.0, learned_variance=a.learned_variance, compute_dtype=a.dtype).to(dev).eval()
-    gd = (LearnedGaussianDiffusion if a.learned_variance else GaussianDiffusion)(timesteps=a.timesteps, schedule_name="cosine")
     B, S = a.batch, a.image_size
     shape = (B, 3, S, S)
+    unet = gd = N = None
+    if not dry:
+        from diffusion_model_nemo_amd import _native as N
+        from diffusion_model_nemo_amd.modules import GaussianDiffusion, LearnedGaussianDiffusion, Unet
+        torch.manual_seed(1234)
+        unet = Unet(input_dim=a.image_size, dim=32, dim_mults=[1, 2, 4, 8], channels=3, resnet_block_groups=8,
+                    use_convnext=False, dropout=0.0, learned_variance=a.learned_variance, compute_dtype=a.dtype).to(dev).eval()
+        gd = (LearnedGaussianDiffusion if a.learned_variance else GaussianDiffusion)(timesteps=a.timesteps, schedule_name="cosine")
+
+    def local_images(k, image_offset):
+        if dry:   # every image carries its global index: the gather below can be checked exactly
+            return (torch.arange(B, dtype=torch.float32) + image_offset).view(B, 1, 1, 1).expand(*shape).contiguous()
+        # the call waits for the chain and raises if an in-launch exchange of GroupNorm sums timed out
+        return gd.p_sample_loop(unet, shape, device=dev, seed=1000 + k, image_offset=image_offset, return_device_tensor=True,
+                                use_graph=not a.no_graph)
 
     def one_sample(k):
-        x0 = gd.p_sample_loop(unet, shape, device=dev, seed=1000 + k, image_offset=rank * B, return_device_tensor=True,
-                               use_graph=not a.no_graph)
+        x0 = local_images(k, rank * B)
         x0 = gather_images(x0) if world > 1 else x0
         return x0.cpu() if rank == 0 else x0   # final images on the host, as the reference returns them
 
     def fence():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        if not dry:
+            torch.cuda.synchronize(dev)
 
     for k in range(a.warmup):
         one_sample(-1 - k)
@@ -213,10 +265,36 @@ def main():
     fence()
     el = time.perf_counter() - t0
     assert torch.isfinite(out).all()
+    assert out.shape[0] == world * B, (tuple(out.shape), world, B)
+    if dry:
+        assert torch.equal(out[:, 0, 0, 0], torch.arange(world * B, dtype=torch.float32)), "gather order / image offsets"
     tmax = torch.tensor([el], device=dev, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     el = float(tmax.item())
+    # in-launch exchanges that ran into their time limit, over all ranks (p_sample_loop has already raised on the rank
+    # concerned; the count is reported so that a reader of the line sees it was looked at)
+    gv = torch.tensor([0 if dry else unet.handoff_giveups()], device=dev, dtype=torch.int64)
+    if dist is not None:
+        dist.all_reduce(gv, op=dist.ReduceOp.SUM)
+    giveups = int(gv.item())
+
+    if dry:
+        train = None if a.no_train else train_step_extra(dev, rank, world, dist, dry=True)
+        if rank == 0:
+            res = {"metric": "images/sec, 1000-step DDPM sample, 64x64 U-Net", "value": world * B * a.steps / el, "unit": "images/sec",
+                   "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3,
+                   "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype,
+                   "data": "none: dry run of the control flow (index-valued images, fixed gradients); the value measures nothing",
+                   "dry_run": True, "backend": a.backend if world > 1 else None, "handoff_giveups": giveups,
+                   "config": {"workload": f"dry run, batch {B} per rank", "global_batch": world * B, "parallelism": f"dp{world}"}}
+            if train is not None:
+                res["train_step"] = train
+            print(json.dumps(res), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     # device time of the last chain, from HIP events recorded on the loop's own stream
     loop_ms = N.loop_last_ms(unet.native_handle())
@@ -290,7 +368,7 @@ def main():
             "metric": "images/sec, 1000-step DDPM sample, 64x64 U-Net" + (" (improved DDPM, learned variance)" if a.learned_variance else ""),
             "value": imgs / el, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": a.dtype, "data": "synthetic (Philox x_T and noise, random-init weights)",
+            "dtype": a.dtype, "data": "synthetic (Philox x_T and noise, random-init weights)", "handoff_giveups": giveups,
             "config": {"workload": f"{S}x{S}x3 {'improved-DDPM (6-channel head)' if a.learned_variance else 'DDPM'} U-Net (dim 32, mults 1-2-4-8), {a.timesteps}-step p_sample_loop, "
                                    f"batch {B} per GPU", "global_batch": world * B, "parallelism": f"dp{world}",
                        "graph": not a.no_graph, "launch_chains": chains},

@@ -94,7 +94,7 @@ struct LoopBufs {
 
 static size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
-static int carve(const DmnUnet* u, int B, int H, int W, void* ws, size_t ws_bytes, LoopBufs& lb, size_t* need) {
+static int carve(DmnUnet* u, int B, int H, int W, void* ws, size_t ws_bytes, LoopBufs& lb, size_t* need) {
     const size_t img = (size_t)B * u->cfg.channels * H * W * 4;
     const size_t net = (size_t)B * u->cfg.out_dim * H * W * 4;
     size_t unet_bytes = 0;
@@ -137,7 +137,7 @@ extern "C" int dmn_unet_set_sample_chains(DmnUnet* u, int chains, int skew_us) {
     return DMN_OK;
 }
 
-extern "C" int dmn_sample_workspace_bytes(const DmnUnet* u, int B, int H, int W, size_t* bytes) {
+extern "C" int dmn_sample_workspace_bytes(DmnUnet* u, int B, int H, int W, size_t* bytes) {
     DMN_REQUIRE(u && bytes, DMN_ERR_INVALID, "dmn_sample_workspace_bytes: null argument");
     LoopBufs lb;
     int rc = carve(u, B, H, W, nullptr, 0, lb, bytes);
@@ -165,15 +165,30 @@ static int ensure_side_stream(DmnUnet* u) {
     return DMN_OK;
 }
 
+// `evals`: network evaluations one step of a chain makes (epoch housekeeping of the in-launch exchanges).
 template <typename Body>
-static int run_loop(DmnUnet* u, const SampleKey& key, int nsteps, hipStream_t s, int use_graph, int nchains, Body body) {
+static int run_loop(DmnUnet* u, const SampleKey& key_in, int nsteps, int evals, hipStream_t s, int use_graph, int nchains, Body body) {
     if (!u->ev_start) {
         DMN_HIP_CHECK(hipEventCreate(&u->ev_start));
         DMN_HIP_CHECK(hipEventCreate(&u->ev_stop));
     }
     u->ev_valid = false;
-    DMN_HIP_CHECK(hipEventRecord(u->ev_start, s));
-    int rc = run_loop_inner(u, key, nsteps, s, use_graph, nchains, body);
+    // The in-launch exchanges are only safe while the exchanging launches on the GPU are those of ONE handle's chains
+    // (dmn_handoff.h): a loop that starts while another handle's exchanging work is in flight closes every block with
+    // the separate passes instead (same bits). Its captured step differs, hence the extra key bit.
+    const bool want_exchange = !(u->path_mask & 128);
+    const bool entered = want_exchange && exchange_guard_enter(u);
+    u->exchange_off = want_exchange && !entered;
+    SampleKey key = key_in;
+    if (u->exchange_off) key.kind |= 1 << 16;
+    int rc = want_exchange ? unet_epoch_reserve(u, (unsigned long long)nsteps * (unsigned long long)evals, s) : DMN_OK;
+    if (rc == DMN_OK && hipEventRecord(u->ev_start, s) != hipSuccess) {
+        dmn_set_error("hipEventRecord failed at the start of a sampling loop");
+        rc = DMN_ERR_HIP;
+    }
+    if (rc == DMN_OK) rc = run_loop_inner(u, key, nsteps, s, use_graph, nchains, body);
+    u->exchange_off = false;
+    if (entered) exchange_guard_leave(u, s);   // behind the join: both chains have been enqueued on or joined to `s`
     if (rc) return rc;
     DMN_HIP_CHECK(hipEventRecord(u->ev_stop, s));
     u->ev_valid = true;
@@ -287,7 +302,7 @@ extern "C" int dmn_ddpm_sample_loop(DmnUnet* u, const float* table, int nsteps, 
         if ((r = launch_ddpm_step(a, cs))) return r;
         return handoff ? DMN_OK : launch_advance(lb[c].step_idx, cs);
     };
-    return run_loop(u, key, nsteps, s, use_graph, nchains, body);
+    return run_loop(u, key, nsteps, 1, s, use_graph, nchains, body);
 }
 
 extern "C" int dmn_pc_sample_loop(DmnUnet* u, const float* table, int nsteps, float* x, int B, int H, int W, int predictor,
@@ -370,7 +385,7 @@ extern "C" int dmn_pc_sample_loop(DmnUnet* u, const float* table, int nsteps, fl
         }
         return done(launch_advance(lb[c].step_idx, cs));
     };
-    return run_loop(u, key, nsteps, s, use_graph, nchains, body);
+    return run_loop(u, key, nsteps, n_corrector_steps + 1, s, use_graph, nchains, body);
 }
 
 extern "C" int dmn_bpd_loop(DmnUnet* u, const float* table, int nsteps, const float* x0, int B, int H, int W,
@@ -429,7 +444,7 @@ extern "C" int dmn_bpd_loop(DmnUnet* u, const float* table, int nsteps, const fl
         if ((r = launch_bpd_term(a, cs))) return r;
         return launch_advance(lb[c].step_idx, cs);
     };
-    return run_loop(u, key, nsteps, s, use_graph, nchains, body);
+    return run_loop(u, key, nsteps, 1, s, use_graph, nchains, body);
 }
 
 extern "C" int dmn_loop_last_ms(DmnUnet* u, float* ms) {

@@ -5,6 +5,15 @@
 
 namespace {
 
+// Row of the class-embedding table for image b (unet.py:134-141): the label, or the extra "no class" row when no labels are
+// given. A label outside [0, num_classes] is clamped so that the kernel never reads outside the table (the host reports such
+// labels as an error at its next synchronisation point instead of paying a device round trip before every launch).
+__device__ __forceinline__ long long ingest_label(const IngestArgs& a, int b) {
+    if (!a.labels) return a.num_classes;
+    const long long l = a.labels[b];
+    return l < 0 ? 0 : (l > a.num_classes ? a.num_classes : l);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // out = [SiLU](GN(in)) [+ res], 16 bytes per lane, with optional partial statistics of `out`.
 // Closes a ResnetBlock (parts/convnext.py:85-86: block2's norm+act, then + res_conv(x)) and a
@@ -216,7 +225,7 @@ __global__ void __launch_bounds__(256) ingest_kernel(const IngestArgs a) {
     __syncthreads();
     const int py = threadIdx.x / TS, px = threadIdx.x % TS;
     float acc[COUT];
-    const float* emb = a.class_embed ? a.class_embed + (size_t)(a.labels ? a.labels[b] : a.num_classes) * COUT : nullptr;
+    const float* emb = a.class_embed ? a.class_embed + (size_t)ingest_label(a, b) * COUT : nullptr;
 #pragma unroll
     for (int o = 0; o < COUT; ++o) acc[o] = a.bias[o] + (emb ? emb[o] : 0.f);
     for (int c = 0; c < a.Cin; ++c)
@@ -263,7 +272,7 @@ __device__ __forceinline__ void ingest_mfma_body(const IngestArgs& a, int bx, in
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) bias[nt] = *reinterpret_cast<const f32x4*>(a.bias + nt * 16 + lq * 4);
     if (a.class_embed) {   // class embedding row of this image, added like a second bias (unet.py:139-141)
-        const float* emb = a.class_embed + (size_t)(a.labels ? a.labels[b] : a.num_classes) * COUT;
+        const float* emb = a.class_embed + (size_t)ingest_label(a, b) * COUT;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bias[nt] += *reinterpret_cast<const f32x4*>(emb + nt * 16 + lq * 4);
     }

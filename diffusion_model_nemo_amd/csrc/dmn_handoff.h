@@ -30,7 +30,7 @@
 
 typedef __attribute__((address_space(1))) unsigned long long dmn_gu64;
 
-constexpr int kHandoffHeaderBytes = 256;           // word 0: epoch, word 1: spins given up
+constexpr int kHandoffHeaderBytes = 256;           // word 0: epoch, word 1: spins given up, words 2..12: diagnosis of the first
 constexpr long long kHandoffSpinTicks = 50000000;  // 0.5 s of the 100 MHz wall clock
 constexpr int kHandoffMaxSlots = 64;               // partial sums per (image, group): one per lane of a wave
 constexpr int kHandoffMaxGroups = 32;
@@ -79,7 +79,8 @@ __device__ __forceinline__ void handoff_group_stats(const HandoffArgs& h, unsign
             if (__all(ok)) break;
             if (wall_clock64() - t0 > kHandoffSpinTicks) {   // wave-uniform: every lane reads the same clock region
                 if (lane == 0) atomicAdd(h.giveups, 1u);
-                // diagnosis: the first lane that still misses a granule describes it in words 2..9 of the header
+                // diagnosis: word 2 of the header is claimed by the first lane that still misses a granule, which then
+                // describes it in words 3..12
                 if (!ok && atomicCAS(h.giveups + 1, 0u, 1u) == 0u) {
                     unsigned* d = h.giveups + 2;
                     d[0] = epoch;

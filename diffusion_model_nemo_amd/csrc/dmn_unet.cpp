@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -698,7 +699,8 @@ static Act full_attn(Fwd& f, const AttnW& w, Act& x) {
 int unet_reserve_handoff(DmnUnet* u, size_t bytes) {
     if (bytes <= u->handoff_bytes && u->handoff_mem[0] && u->handoff_mem[1]) return DMN_OK;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;   // a capture on the legacy stream forbids allocation
-    if (hipStreamIsCapturing(nullptr, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return DMN_OK;
+    DMN_REQUIRE(!(hipStreamIsCapturing(nullptr, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone), DMN_ERR_INVALID,
+                "the in-launch exchange areas cannot grow inside a stream capture: size the workspace for this shape before capturing");
     const size_t want = bytes < ((size_t)1 << 20) ? ((size_t)1 << 20) : bytes + bytes / 2;
     DMN_HIP_CHECK(hipDeviceSynchronize());   // evaluations in flight still poll the old areas
     if (u->graph_exec) {                     // captured steps hold the old addresses
@@ -717,7 +719,87 @@ int unet_reserve_handoff(DmnUnet* u, size_t bytes) {
     }
     DMN_HIP_CHECK(hipDeviceSynchronize());
     u->handoff_bytes = want;
+    u->epoch_used = 0;
     return DMN_OK;
+}
+
+int unet_epoch_reserve(DmnUnet* u, unsigned long long evals, hipStream_t s) {
+    if (!u->handoff_mem[0] || !u->handoff_mem[1]) return DMN_OK;
+    if (u->epoch_used + evals < u->epoch_limit) {
+        u->epoch_used += evals;
+        return DMN_OK;
+    }
+    // Every earlier loop of this handle has joined `s`; once `s` is idle nothing polls the areas, and what the coming
+    // work finds is epoch 0 and no tag at all, as after allocation. The give-up counts go to the host first.
+    DMN_HIP_CHECK(hipStreamSynchronize(s));
+    for (int c = 0; c < 2; ++c) {
+        unsigned hdr[2] = {0, 0};
+        DMN_HIP_CHECK(hipMemcpy(hdr, u->handoff_mem[c], sizeof(hdr), hipMemcpyDeviceToHost));
+        u->giveups_carry += hdr[1];
+        DMN_HIP_CHECK(hipMemsetAsync(u->handoff_mem[c], 0, u->handoff_bytes, s));
+    }
+    u->epoch_used = evals;
+    return DMN_OK;
+}
+
+// ---- which handles have exchanging work in flight ---------------------------------------------------------------
+namespace {
+struct GuardEntry {
+    DmnUnet* u;
+    int device;
+    bool enqueuing;        // its host call is still issuing launches
+    bool pending;          // `done` has been recorded and not yet been seen complete
+    hipEvent_t done;
+};
+std::mutex g_guard_mu;
+std::vector<GuardEntry> g_guard;
+}  // namespace
+
+bool exchange_guard_enter(DmnUnet* u) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lock(g_guard_mu);
+    GuardEntry* mine = nullptr;
+    bool busy = false;
+    for (auto& e : g_guard) {
+        if (e.u == u) {
+            mine = &e;
+            continue;
+        }
+        if (e.device != dev) continue;
+        if (e.pending && hipEventQuery(e.done) == hipSuccess) e.pending = false;
+        if (e.enqueuing || e.pending) busy = true;
+    }
+    if (busy) return false;
+    if (!mine) {
+        g_guard.push_back(GuardEntry{u, dev, false, false, nullptr});
+        mine = &g_guard.back();
+    }
+    mine->device = dev;
+    mine->enqueuing = true;
+    return true;
+}
+
+void exchange_guard_leave(DmnUnet* u, hipStream_t s) {
+    std::lock_guard<std::mutex> lock(g_guard_mu);
+    for (auto& e : g_guard)
+        if (e.u == u) {
+            e.enqueuing = false;
+            if (!e.done && hipEventCreateWithFlags(&e.done, hipEventDisableTiming) != hipSuccess) e.done = nullptr;
+            // without an event the work cannot be followed: it then counts as finished (the spins stay bounded)
+            e.pending = e.done && hipEventRecord(e.done, s) == hipSuccess;
+            return;
+        }
+}
+
+void exchange_guard_forget(DmnUnet* u) {
+    std::lock_guard<std::mutex> lock(g_guard_mu);
+    for (size_t i = 0; i < g_guard.size(); ++i)
+        if (g_guard[i].u == u) {
+            if (g_guard[i].done) (void)hipEventDestroy(g_guard[i].done);
+            g_guard.erase(g_guard.begin() + i);
+            return;
+        }
 }
 
 int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float, const float* table, int* step_idx,
@@ -735,7 +817,7 @@ int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float,
     f.B = B;
     f.dry = dry;
     f.ar.reset(ws, ws_bytes, dry);
-    f.ho_enabled = !(u->path_mask & 128);
+    f.ho_enabled = !(u->path_mask & 128) && !u->exchange_off;
     if (!dry && f.ho_enabled) {
         f.ho_base = static_cast<char*>(u->handoff_mem[u->chain_id & 1]);
         f.ho_cap = u->handoff_bytes;
@@ -1324,6 +1406,10 @@ extern "C" int dmn_unet_create(const DmnUnetCfg* cfg, DmnUnet** out) {
     if (const char* e = getenv("DMN_UNET_PATHS")) u->path_mask = atoi(e);
     if (const char* e = getenv("DMN_SAMPLE_CHAINS")) u->sample_chains = atoi(e) == 1 ? 1 : 2;
     if (const char* e = getenv("DMN_PROBE_SITE")) u->probe_site = atoi(e);
+    if (const char* e = getenv("DMN_HANDOFF_EPOCH_LIMIT")) {
+        const unsigned long long v = strtoull(e, nullptr, 0);
+        if (v >= 1 && v <= 0xFFF00000ull) u->epoch_limit = v;
+    }
     if (const char* e = getenv("DMN_SAMPLE_SKEW_US")) u->sample_skew_us = atoi(e) < 0 ? 0 : (atoi(e) > 5000 ? 5000 : atoi(e));
     u->downs.resize(cfg->n_mults);
     u->ups.resize(cfg->n_mults - 1);
@@ -1382,6 +1468,7 @@ extern "C" int dmn_unet_set_plan_batch(DmnUnet* u, int batch) {
 
 extern "C" void dmn_unet_destroy(DmnUnet* u) {
     if (!u) return;
+    exchange_guard_forget(u);
     if (u->graph_exec) (void)hipGraphExecDestroy(u->graph_exec);
     if (u->graph_exec2) (void)hipGraphExecDestroy(u->graph_exec2);
     if (u->side_stream) (void)hipStreamDestroy(u->side_stream);
@@ -1518,10 +1605,10 @@ extern "C" int dmn_unet_load_weights(DmnUnet* u, const DmnTensorDesc* params, in
     return DMN_OK;
 }
 
-extern "C" int dmn_unet_workspace_bytes(const DmnUnet* u, int B, int H, int W, size_t* bytes) {
+extern "C" int dmn_unet_workspace_bytes(DmnUnet* u, int B, int H, int W, size_t* bytes) {
     DMN_REQUIRE(u && bytes, DMN_ERR_INVALID, "dmn_unet_workspace_bytes: null argument");
     size_t high = 0;
-    DmnUnet* uu = const_cast<DmnUnet*>(u);
+    DmnUnet* uu = u;
     int saved_total = uu->tb_total;
     if (!u->loaded) {   // time-bias width is known from the configuration alone
         int total = 0;
@@ -1554,10 +1641,12 @@ extern "C" int dmn_test_probe_read(DmnUnet* u, int chain, long long* host, int n
 }
 
 // Spins of the in-launch hand-offs that ran into their time limit since the handle was created (both chains; waits for
-// the device). Non-zero means an evaluation used incomplete GroupNorm statistics: its results are invalid.
+// the device). A count that has grown since the caller last looked means that an evaluation in between used incomplete
+// GroupNorm statistics: its results are invalid.
 extern "C" int dmn_unet_handoff_giveups(DmnUnet* u, unsigned* count) {
     DMN_REQUIRE(u && count, DMN_ERR_INVALID, "dmn_unet_handoff_giveups: null argument");
-    *count = 0;
+    DMN_HIP_CHECK(hipDeviceSynchronize());   // the loops run on non-blocking streams, which a plain copy does not wait for
+    *count = u->giveups_carry;
     for (int c = 0; c < 2; ++c)
         if (u->handoff_mem[c]) {
             unsigned hdr[16] = {0};
@@ -1574,6 +1663,24 @@ extern "C" int dmn_unet_handoff_giveups(DmnUnet* u, unsigned* count) {
 extern "C" int dmn_unet_forward(DmnUnet* u, const float* x, const void* t, int t_is_float, float* out, int B, int H, int W,
                                 void* workspace, size_t workspace_bytes, void* stream) {
     DMN_REQUIRE(u && x && t && out && workspace, DMN_ERR_INVALID, "dmn_unet_forward: null argument");
-    return unet_forward_impl(u, x, t, t_is_float, nullptr, nullptr, out, B, H, W, workspace, workspace_bytes,
-                             (hipStream_t)stream, false, nullptr);
+    hipStream_t s = (hipStream_t)stream;
+    // Inside a caller's stream capture neither an event nor a memset of the exchange areas may be issued: the capture
+    // keeps the exchanges and the caller answers for not replaying it beside another handle's sampling.
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+    bool entered = false;
+    if (!capturing && !(u->path_mask & 128)) {
+        entered = exchange_guard_enter(u);
+        u->exchange_off = !entered;
+        const int rc = unet_epoch_reserve(u, 1, s);
+        if (rc) {
+            u->exchange_off = false;
+            if (entered) exchange_guard_leave(u, s);
+            return rc;
+        }
+    }
+    const int rc = unet_forward_impl(u, x, t, t_is_float, nullptr, nullptr, out, B, H, W, workspace, workspace_bytes, s, false, nullptr);
+    u->exchange_off = false;
+    if (entered) exchange_guard_leave(u, s);
+    return rc;
 }

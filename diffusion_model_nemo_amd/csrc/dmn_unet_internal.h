@@ -117,6 +117,18 @@ struct DmnUnet {
     // falls back to the separate closing passes.
     void* handoff_mem[2] = {nullptr, nullptr};
     size_t handoff_bytes = 0;
+    // Epoch housekeeping: the tag of a granule is a 32-bit epoch that the device increments once per evaluation. The host
+    // keeps an upper bound of the epochs consumed since the areas were last zeroed and zeroes them again (stream-ordered,
+    // in front of a loop or forward, never inside a capture) before the bound reaches `epoch_limit`, so a wrapped epoch
+    // can never meet a stale tag of the same value. Environment DMN_HANDOFF_EPOCH_LIMIT (tests use a small one).
+    unsigned long long epoch_used = 0;
+    unsigned long long epoch_limit = 0xFFF00000ull;
+    unsigned giveups_carry = 0;          // give-ups counted in areas that have been zeroed since
+    // Set while a loop / forward of this handle is being enqueued or captured although another handle's exchanging work
+    // is in flight on the device (exchange_guard_enter returned false): every closing then takes its separate pass, as
+    // under DMN_UNET_PATHS bit 7 -- same bits, no waiting workgroups -- because the residency guarantee of
+    // dmn_handoff.h covers the exchanging launches of ONE handle's two chains only.
+    bool exchange_off = false;
 };
 constexpr int kProbePairs = 256;
 constexpr int kProbeMaxWgs = 16384;
@@ -133,3 +145,12 @@ int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float,
                       size_t* handoff_need = nullptr, const struct DdpmStepArgs* fuse_step = nullptr);
 // Makes both chains' granule areas at least `bytes` large (never inside a stream capture: it allocates).
 int unet_reserve_handoff(DmnUnet* u, size_t bytes);
+// Accounts for `evals` coming network evaluations per chain; zeroes the granule areas on `s` first when the epoch bound
+// would pass the limit (see DmnUnet::epoch_used). Not inside a stream capture.
+int unet_epoch_reserve(DmnUnet* u, unsigned long long evals, hipStream_t s);
+// Process-wide registry of handles whose exchanging work (in-launch GroupNorm hand-offs) is being enqueued or still in
+// flight. enter: true when no OTHER handle has such work pending on the current device -- the caller may exchange and must
+// call leave(u, s) after its last launch on `s`; false: run without exchanges (set DmnUnet::exchange_off), no leave.
+bool exchange_guard_enter(DmnUnet* u);
+void exchange_guard_leave(DmnUnet* u, hipStream_t s);
+void exchange_guard_forget(DmnUnet* u);   // handle destruction

@@ -1,0 +1,86 @@
+"""Static check of the device code inside libdmn_hip.so: no packed-FP32 VALU instruction may be present.
+
+Why: with ``v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32`` in the kernels (the SLP vectoriser emits them for the
+epilogues) this library returned wrong GroupNorm partial sums and linear-attention merge rows in lanes 48..63 of a
+wave whenever a kernel of another stream shared the compute unit (measured on MI355X, ROCm 7.2). The build switches
+them off (``build.py``); this module makes a dropped flag, a toolchain change or a vector-typed source line fail the
+build and the CPU test suite instead of silently bringing the wrong results back.
+
+``python -m diffusion_model_nemo_amd.isa_check [path/to/lib.so]`` prints the per-code-object instruction counts.
+"""
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+from typing import Dict, List
+
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+FORBIDDEN = re.compile(r"\bv_pk_(add|mul|fma)_f32\b")
+MFMA = re.compile(r"\bv_mfma_")
+
+
+def _tool(name: str) -> str:
+    exe = os.path.join(LLVM_BIN, name)
+    if not os.path.exists(exe):
+        exe = shutil.which(name) or ""
+    if not exe:
+        raise RuntimeError(f"{name} not found (looked in {LLVM_BIN} and PATH)")
+    return exe
+
+
+def extract_code_objects(lib_path: str, workdir: str) -> List[str]:
+    """Unbundles the gfx950 code objects of a HIP fat binary into `workdir` (the tool writes next to its input, so the
+    library is copied there first) and returns their paths."""
+    local = os.path.join(workdir, os.path.basename(lib_path))
+    shutil.copy(lib_path, local)
+    subprocess.run([_tool("llvm-objdump"), "--offloading", local], check=True, capture_output=True, text=True)
+    return sorted(os.path.join(workdir, f) for f in os.listdir(workdir) if "amdgcn-amd-amdhsa--gfx950" in f)
+
+
+def disassemble(code_object: str) -> str:
+    r = subprocess.run([_tool("llvm-objdump"), "-d", "--mcpu=gfx950", code_object], check=True, capture_output=True, text=True)
+    return r.stdout
+
+
+def instruction_census(lib_path: str) -> Dict[str, Dict[str, int]]:
+    """code object name -> {"forbidden": n, "mfma": n, "kernels": n, "lines": n} for every gfx950 code object of the
+    library."""
+    out: Dict[str, Dict[str, int]] = {}
+    with tempfile.TemporaryDirectory(prefix="dmn_isa_") as tmp:
+        objs = extract_code_objects(lib_path, tmp)
+        if not objs:
+            raise RuntimeError(f"{lib_path} holds no gfx950 code object")
+        for co in objs:
+            text = disassemble(co)
+            lines = text.splitlines()
+            out[os.path.basename(co)] = {
+                "forbidden": sum(1 for ln in lines if FORBIDDEN.search(ln)),
+                "mfma": sum(1 for ln in lines if MFMA.search(ln)),
+                "kernels": sum(1 for ln in lines if ln.endswith(">:") and not ln.startswith(" ")),
+                "lines": len(lines),
+            }
+    return out
+
+
+def assert_no_packed_fp32(lib_path: str) -> Dict[str, Dict[str, int]]:
+    census = instruction_census(lib_path)
+    bad = {k: v["forbidden"] for k, v in census.items() if v["forbidden"]}
+    if bad:
+        raise RuntimeError(
+            f"{lib_path}: packed-FP32 instructions (v_pk_add/mul/fma_f32) in the device code: {bad}. They gave wrong "
+            "sums beside a foreign stream on MI355X; keep `-fno-slp-vectorize -Xclang -target-feature -Xclang "
+            "-packed-fp32-ops` in the build and do not use float vector arithmetic in device code.")
+    return census
+
+
+if __name__ == "__main__":
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "lib", "libdmn_hip.so")
+    total = {"forbidden": 0, "mfma": 0, "kernels": 0}
+    for name, c in assert_no_packed_fp32(path).items():
+        print(f"{name}: {c['kernels']} symbols, {c['mfma']} v_mfma_*, {c['forbidden']} v_pk_(add|mul|fma)_f32")
+        for k in total:
+            total[k] += c[k]
+    print(f"total: {total}")

@@ -42,7 +42,11 @@ class AbstractDiffusionModel(nn.Module):
     # model_weights.ckpt; used by examples/ddpm/eval_ddpm.py:70 and the other example scripts) --------------------
     CONFIG_MEMBER = "model_config.yaml"
     WEIGHTS_MEMBER = "model_weights.ckpt"
-    OPTIM_PREFIX = "__optimizer__."   # extra entries of the weights file: flat AdamW moments + step count
+    # AdamW moments, step count and the digest of the flat-buffer layout they belong to travel as a member of their own:
+    # `model_weights.ckpt` stays the pure state_dict that the reference restores with a strict load_state_dict, and a
+    # reader that does not know this member ignores it
+    OPTIM_MEMBER = "optimizer_state.ckpt"
+    OPTIM_PREFIX = "__optimizer__."   # where earlier archives of this package kept the same entries: still read
 
     def save_to(self, save_path: str):
         """Writes the model section of the config and the state_dict in the `.nemo` layout (uncompressed tar)."""
@@ -61,11 +65,18 @@ class AbstractDiffusionModel(nn.Module):
         blobs = {self.CONFIG_MEMBER: yaml.safe_dump(plain(self.cfg), sort_keys=False).encode()}
         buf = io.BytesIO()
         tensors = {k: v.detach().cpu() for k, v in self.state_dict().items()}
-        tr = getattr(self, "_native_trainer", None)
-        if tr is not None and tr.step_count > 0:   # AdamW moments and step count, so a restored run resumes them
-            tensors.update({self.OPTIM_PREFIX + k: v.cpu() for k, v in tr.state_dict().items()})
         torch.save(tensors, buf)
         blobs[self.WEIGHTS_MEMBER] = buf.getvalue()
+        tr = getattr(self, "_native_trainer", None)
+        opt_state = None
+        if tr is not None and tr.step_count > 0:   # AdamW moments and step count, so a restored run resumes them
+            opt_state = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in tr.state_dict().items()}
+        elif getattr(self, "_pending_optimizer_state", None):
+            opt_state = self._pending_optimizer_state   # restored and saved again without a training step in between
+        if opt_state:
+            obuf = io.BytesIO()
+            torch.save(opt_state, obuf)
+            blobs[self.OPTIM_MEMBER] = obuf.getvalue()
         with tarfile.open(save_path, "w:") as tar:
             for name, data in blobs.items():
                 info = tarfile.TarInfo("./" + name)
@@ -88,6 +99,7 @@ class AbstractDiffusionModel(nn.Module):
                     raise FileNotFoundError(f"{restore_path} holds no {need}")
             cfg = yaml.load(tar.extractfile(members[cls.CONFIG_MEMBER]).read().decode(), Loader=yaml.SafeLoader)
             blob = tar.extractfile(members[cls.WEIGHTS_MEMBER]).read()
+            oblob = tar.extractfile(members[cls.OPTIM_MEMBER]).read() if cls.OPTIM_MEMBER in members else None
         if isinstance(cfg, dict) and "model" in cfg and "diffusion_model" not in cfg:
             cfg = cfg["model"]            # a full experiment config rather than its model section
         model = cls(to_config(cfg, overrides), trainer=trainer)
@@ -96,6 +108,8 @@ class AbstractDiffusionModel(nn.Module):
             state = state["state_dict"]
         opt_state = {k[len(cls.OPTIM_PREFIX):]: state.pop(k) for k in [k for k in state if k.startswith(cls.OPTIM_PREFIX)]}
         model.load_state_dict(state, strict=strict)
+        if oblob is not None:
+            opt_state = torch.load(io.BytesIO(oblob), map_location="cpu", weights_only=True)
         if opt_state:
             model._pending_optimizer_state = opt_state   # handed to the trainer when it is created on a device
         return model
@@ -142,6 +156,7 @@ class AbstractDiffusionModel(nn.Module):
             terms.data_ptr(), T, prior.data_ptr(), float(sampler.sqrt_alphas_cumprod[T - 1]),
             float(sampler.log_one_minus_alphas_cumprod[T - 1]), ws.data_ptr(), ws.numel(),
             N.current_stream_handle(dev), 1))
+        net.check_handoffs()   # waits for the loop; terms computed from starved statistics must not be handed on
         return {'total_bpd': terms.sum(dim=1) + prior, 'terms_bpd': terms, 'prior_bpd': prior}
 
 

@@ -249,12 +249,14 @@ class GaussianDiffusion(AbstractDiffusionProcess):
     @torch.no_grad()
     def p_sample_loop(self, model, shape, device=None, use_tqdm=True, keep: str = "all", seed: Optional[int] = None,
                       image_offset: int = 0, x_T: Optional[torch.Tensor] = None, return_device_tensor: bool = False,
-                      use_graph: bool = True):
+                      use_graph: bool = True, check: bool = True):
         """Algorithm 2 of DDPM (gaussian_diffusion.py:171-189).
 
         Default return value as in the reference: a Python list of T CPU tensors mapped to [0, 1] by (x + 1) / 2.
         ``keep='last'`` returns a one-element list (only the final image is kept and copied);
-        ``return_device_tensor=True`` returns the final x_0 in model range on the device instead.
+        ``return_device_tensor=True`` returns the final x_0 in model range on the device instead; the call then still
+        waits for the chain to check that no in-launch exchange timed out, unless ``check=False`` (asynchronous return;
+        the caller then calls ``Unet.check_handoffs()`` before using the images).
         ``image_offset`` is the global index of image 0 (batch-sharded sampling draws the same noise per image
         whatever the split)."""
         if keep not in ("all", "last"):
@@ -271,12 +273,14 @@ class GaussianDiffusion(AbstractDiffusionProcess):
         else:
             x = torch.empty(shape, dtype=torch.float32, device=device)
         hist = self._run_chain(model, x, 0, self.timesteps, x_T is None, keep, seed, image_offset, use_graph=use_graph)
+        net = _unwrap_conditional(model)[0]
         if return_device_tensor:
+            if check and isinstance(net, Unet):
+                net.check_handoffs()   # waits for the chain: a starved in-launch exchange must not go unnoticed here either
             return x
         imgs = [((x + 1) * 0.5).cpu()] if keep == "last" else list(((hist + 1) * 0.5).cpu().unbind(0))
-        net = _unwrap_conditional(model)[0]
         if isinstance(net, Unet):
-            net.check_handoffs()   # the copies above have waited for the chain
+            net.check_handoffs()
         return imgs
 
     @torch.no_grad()
@@ -300,4 +304,8 @@ class GaussianDiffusion(AbstractDiffusionProcess):
         if t == 0:
             return []
         hist = self._run_chain(model, img, self.timesteps - t, t, False, "all", self._resolve_seed(seed), 0)
-        return list(((hist + 1) * 0.5).cpu().unbind(0))
+        out = list(((hist + 1) * 0.5).cpu().unbind(0))
+        net = _unwrap_conditional(model)[0]
+        if isinstance(net, Unet):
+            net.check_handoffs()
+        return out

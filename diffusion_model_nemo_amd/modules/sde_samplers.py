@@ -143,9 +143,11 @@ class PredictorCorrectorSampler(torch.nn.Module):
     @torch.no_grad()
     def forward(self, model, shape: List[int], device, return_nfe: bool = True, use_tqdm: bool = True,
                 keep: str = "all", seed: Optional[int] = None, image_offset: int = 0,
-                return_device_tensor: bool = False, use_graph: bool = True):
+                return_device_tensor: bool = False, use_graph: bool = True, check: bool = True):
         """Returns (imgs, nfe) like the reference: imgs is a list of N CPU tensors ((x_mean or x) + 1) / 2, or a
-        one-element list with keep='last'. nfe keeps the reference's formula N * (n_steps + 1)."""
+        one-element list with keep='last'. nfe keeps the reference's formula N * (n_steps + 1).
+        ``return_device_tensor=True`` returns the final image on the device; ``check=False`` then skips the wait for
+        the chain and leaves ``Unet.check_handoffs()`` to the caller."""
         if self.sde is None:
             raise ValueError("Must explicitly set `update_sde(sde)` for this module prior to calling forward()")
         if keep not in ("all", "last"):
@@ -189,8 +191,8 @@ class PredictorCorrectorSampler(torch.nn.Module):
             out = [((final + 1.0) * 0.5).cpu()] * (1 if keep == "last" else sde.N)
         else:
             out = list(((hist + 1.0) * 0.5).cpu().unbind(0))
-        if not return_device_tensor and hasattr(model, "check_handoffs"):
-            model.check_handoffs()   # the copies above have waited for the chain
+        if check or not return_device_tensor:
+            model.check_handoffs()   # waits for the chain; a starved in-launch exchange invalidates the images
         return (out, nfe) if return_nfe else out
 
     def sample(self, model, shape, device=None, return_nfe: bool = False, **kwargs):

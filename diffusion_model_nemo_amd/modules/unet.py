@@ -110,6 +110,8 @@ class Unet(nn.Module):
         self.num_classes = num_classes
         self.compute_dtype = compute_dtype
         self._labels = None   # device labels of the current forward / sampling chain (kept alive here)
+        self._label_flag = None      # device bool: a label handed over as a device tensor was out of range
+        self._giveups_seen = 0       # hand-off give-ups already reported by check_handoffs
         self.init_conv = nn.Conv2d(channels, dim, kernel_size=7, padding=3)
 
         dims = [dim, *[dim * m for m in dim_mults]]
@@ -190,7 +192,8 @@ class Unet(nn.Module):
 
     def handoff_giveups(self) -> int:
         """Bounded waits of the in-launch GroupNorm hand-offs that ran out since the handle was created (synchronises
-        the device). Anything but 0 means an evaluation used incomplete statistics."""
+        the device; the count never goes down). A count that grew means an evaluation in between used incomplete
+        statistics."""
         if self._handle is None:
             return 0
         n = C.c_uint()
@@ -199,9 +202,19 @@ class Unet(nn.Module):
         return int(n.value)
 
     def check_handoffs(self):
+        """Call where results are handed on (the sampling loops and the bits-per-dimension evaluation do; after a bare
+        `forward` it is the caller's turn): waits for the device, then raises if an in-launch hand-off timed out since
+        the last check -- only the results produced in between are invalid, later calls are not affected -- or if a
+        class label given as a device tensor was out of range (the kernels clamp it; the reference raises IndexError)."""
         n = self.handoff_giveups()
-        if n:
-            raise RuntimeError(f"{n} in-launch GroupNorm hand-offs timed out: the last results are invalid")
+        new = n - self._giveups_seen
+        self._giveups_seen = n
+        bad_labels = self._label_flag is not None and bool(self._label_flag.item())
+        self._label_flag = None
+        if new > 0:
+            raise RuntimeError(f"{new} in-launch GroupNorm hand-offs timed out: the results since the last check are invalid")
+        if bad_labels:
+            raise IndexError("class label out of range")
 
     def _device(self) -> torch.device:
         dev = self.init_conv.weight.device
@@ -234,11 +247,17 @@ class Unet(nn.Module):
         if classes is None:
             self._labels = None
         else:
-            classes = classes.to(device=device, dtype=torch.int64).contiguous()
             if classes.dim() != 1 or classes.numel() != batch:
                 raise ValueError("classes must have shape [B]")
-            if int(classes.min()) < 0 or int(classes.max()) > self.num_classes:
-                raise IndexError("class label out of range")
+            on_host = not classes.is_cuda
+            if on_host and (int(classes.min()) < 0 or int(classes.max()) > self.num_classes):
+                raise IndexError("class label out of range")   # labels on the host are checked where they are
+            classes = classes.to(device=device, dtype=torch.int64).contiguous()
+            if not on_host:
+                # device labels: no round trip to the host here (it would stall the stream before every forward); the
+                # kernels clamp, and the verdict is read at the next synchronisation point (check_handoffs)
+                bad = ((classes < 0) | (classes > self.num_classes)).any()
+                self._label_flag = bad if self._label_flag is None else (self._label_flag | bad)
             self._labels = classes
         with torch.cuda.device(device):
             N.check(N.lib().dmn_unet_set_class_labels(self.native_handle(), None if self._labels is None
@@ -291,6 +310,7 @@ class Unet(nn.Module):
         self._weights_version = None
         self._workspace = None
         self._ws_key = None
+        self._giveups_seen = 0   # a new handle counts from zero
 
     def __del__(self):
         try:

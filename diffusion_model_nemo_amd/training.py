@@ -100,11 +100,21 @@ class UnetTrainer:
             pass
 
     # ---- optimiser state (AdamW moments + step count) for checkpoints -------------------------------------------
+    def layout_digest(self) -> str:
+        """Names, offsets and shapes of the flat buffers in one string: the moments of a checkpoint only mean something
+        under the layout they were written with."""
+        import hashlib
+        text = ";".join(f"{n}@{off}:{'x'.join(map(str, shape))}" for n, (off, shape) in sorted(self.layout.items()))
+        return hashlib.sha1(f"{self.flat_size}|{text}".encode()).hexdigest()
+
     def state_dict(self) -> Dict[str, torch.Tensor]:
         return {"exp_avg": self.exp_avg.detach().clone(), "exp_avg_sq": self.exp_avg_sq.detach().clone(),
-                "step_count": torch.tensor(self.step_count, dtype=torch.int64)}
+                "step_count": torch.tensor(self.step_count, dtype=torch.int64), "layout": self.layout_digest()}
 
     def load_state_dict(self, state: Dict[str, torch.Tensor]):
+        if "layout" in state and state["layout"] != self.layout_digest():
+            raise ValueError("optimizer state was written under another flat-buffer layout (names / offsets / shapes differ): "
+                             "its moments would be applied to the wrong parameters")
         for k in ("exp_avg", "exp_avg_sq"):
             if state[k].numel() != self.flat_size:
                 raise ValueError(f"optimizer state '{k}' has {state[k].numel()} elements, expected {self.flat_size}")
@@ -122,12 +132,23 @@ class UnetTrainer:
 
     def sync_replicas(self, group=None):
         """Data parallel: rank 0's parameters, AdamW moments and step count to every rank (what Lightning DDP does for
-        parameters when it wraps the module). Called by the first `all_reduce_grads`; a no-op without
-        torch.distributed."""
+        parameters when it wraps the module, i.e. BEFORE the first forward). Runs in front of the first gradient
+        computation once a process group of more than one rank exists (`_before_step`); a no-op, to be tried again at
+        the next step, while torch.distributed is not initialised."""
+        import torch.distributed as dist
         from .parallel import broadcast_training_state
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+            return False
         self.step_count = broadcast_training_state((self.params, self.exp_avg, self.exp_avg_sq), self.step_count, group)
         self.unet._weights_version = None   # the sampling handle repacks from the (possibly replaced) parameters
         self._synced = True
+        return True
+
+    def _before_step(self):
+        """In front of every gradient computation: replicas that have not been brought together yet are now, so that no
+        rank ever differentiates at parameters the others do not hold."""
+        if not self._synced:
+            self.sync_replicas()
 
     def grad_of(self, name: str) -> torch.Tensor:
         off, shape = self.layout[name]
@@ -154,6 +175,7 @@ class UnetTrainer:
         if x0.device != self.device:
             raise RuntimeError(f"batch on {x0.device}, trainer on {self.device}")
         self._check_views()
+        self._before_step()
         B, Cc, H, W = x0.shape
         if Cc != self.unet.channels:
             raise ValueError(f"expected {self.unet.channels} channels, got {Cc}")
@@ -191,8 +213,6 @@ class UnetTrainer:
         """Data parallel: ONE summing all-reduce (RCCL over xGMI under backend 'nccl') of the flat gradient tensor.
         Returns the factor that turns the sum into the mean; `optimizer_step` applies it on the device."""
         from .parallel import all_reduce_flat_grads
-        if not self._synced:
-            self.sync_replicas()
         return all_reduce_flat_grads(self.grads)
 
     def optimizer_step(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01,

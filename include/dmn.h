@@ -59,10 +59,12 @@ int dmn_unet_create(const DmnUnetCfg* cfg, DmnUnet** out);
 void dmn_unet_destroy(DmnUnet* u);
 /* Packs the reference's parameters (names as in Unet.state_dict()) into the device layout. Synchronous. */
 int dmn_unet_load_weights(DmnUnet* u, const DmnTensorDesc* params, int n_params);
-/* Bytes of caller workspace one evaluation of this shape needs. Side effect (never call it inside a stream capture): makes
- * the handle's own device areas for the in-launch exchanges (see dmn_unet_handoff_giveups) large enough for this shape;
- * when they grow, the device is synchronised and cached step graphs are dropped. */
-int dmn_unet_workspace_bytes(const DmnUnet* u, int B, int H, int W, size_t* bytes);
+/* Bytes of caller workspace one evaluation of this shape needs. It also changes the handle (hence no const): the handle's own
+ * device areas for the in-launch exchanges (see dmn_unet_handoff_giveups) are made large enough for this shape; when they
+ * have to grow, the device is synchronised, memory is allocated and cached step graphs are dropped. Call it before a stream
+ * capture, not inside one (a capture on the legacy stream is detected and refused with DMN_ERR_INVALID; a capture on
+ * another stream cannot be seen from here). */
+int dmn_unet_workspace_bytes(DmnUnet* u, int B, int H, int W, size_t* bytes);
 /* Class labels of the next forwards / sampling loops (unet.py:134-141): DEVICE int64 [B], borrowed until replaced;
  * NULL selects the extra "null" row num_classes for every image, like classes=None in the reference. */
 int dmn_unet_set_class_labels(DmnUnet* u, const int64_t* labels);
@@ -78,13 +80,15 @@ int dmn_unet_set_plan_batch(DmnUnet* u, int batch);
  * convolution itself: the workgroups of an image exchange their GroupNorm partial sums inside the launch through a
  * device area the handle owns (allocated by dmn_unet_workspace_bytes / dmn_sample_workspace_bytes for the largest shape
  * asked about; a shape never asked about runs the separate closing passes instead). The waits are bounded (0.5 s); one
- * that runs out is counted and the evaluation's result is invalid. Returns the count since the handle was created;
- * waits for the device. No counterpart in the reference. */
+ * that runs out is counted and the evaluation's result is invalid. Returns the count since the handle was created (it
+ * never goes down: a caller compares it with the value it saw last); waits for the device. The exchanges are only
+ * used while no OTHER handle has exchanging work in flight on the GPU: a loop or forward that starts beside one takes
+ * the separate closing passes (same bits). No counterpart in the reference. */
+int dmn_unet_handoff_giveups(DmnUnet* u, unsigned* count);
 /* Tuning aid, no counterpart in the reference: per-workgroup phase stamps of the convolution launch selected by the
  * environment variable DMN_PROBE_SITE (its number among an evaluation's convolution launches), taken inside the sampling
  * loops while dmn_unet_probe_dominant(u, 2) is on. host: [nwgs][8] 64-bit words. */
 int dmn_test_probe_read(DmnUnet* u, int chain, long long* host, int nwgs);
-int dmn_unet_handoff_giveups(DmnUnet* u, unsigned* count);
 
 /* eps = Unet(x, t).  t: [B] int64 (t_is_float = 0) or float32 (1), device memory. out: [B][out_dim][H][W]. */
 int dmn_unet_forward(DmnUnet* u, const float* x, const void* t, int t_is_float, float* out, int B, int H, int W,
@@ -165,7 +169,7 @@ int dmn_ddpm_loop_chains(const DmnUnet* u, int B);
 int dmn_bpd_loop(DmnUnet* u, const float* table, int nsteps, const float* x0, int B, int H, int W, int learned_variance,
                  uint64_t seed, int64_t img_offset, float* terms, int terms_stride, float* prior, float prior_sqrt_acp,
                  float prior_log_1m_acp, void* workspace, size_t workspace_bytes, void* stream, int use_graph);
-int dmn_sample_workspace_bytes(const DmnUnet* u, int B, int H, int W, size_t* bytes);
+int dmn_sample_workspace_bytes(DmnUnet* u, int B, int H, int W, size_t* bytes);
 /* Device time (HIP events on the loop's stream) of the last dmn_*_sample_loop call on this handle; waits for it.
  * No counterpart in the reference: measurement hook used by bench.py. */
 int dmn_loop_last_ms(DmnUnet* u, float* ms);

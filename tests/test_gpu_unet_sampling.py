@@ -177,8 +177,15 @@ def test_class_conditional_unet_and_sampling():
     x, t, labels = T(g["x"]).cuda(), T(g["t"]).cuda(), T(g["labels"]).cuda()
     assert err(u(x, t, labels), g["y_labels"])[0] <= 2e-4
     assert err(u(x, t), g["y_default"])[0] <= 2e-4
+    with pytest.raises(IndexError):                       # labels on the host are refused at once
+        u(x, t, torch.tensor([0, 11, 2]))
+    # labels on the device are not read back before the launch (no stall): the kernel clamps, the verdict comes at the
+    # next synchronisation point and concerns only the calls since the last one
+    clamped = u(x, t, torch.tensor([0, 11, 2], device="cuda"))
+    assert torch.equal(clamped, u(x, t, torch.tensor([0, 10, 2], device="cuda")))
     with pytest.raises(IndexError):
-        u(x, t, torch.tensor([0, 11, 2], device="cuda"))
+        u.check_handoffs()
+    u.check_handoffs()
     gd = GaussianDiffusion(timesteps=12, schedule_name="linear")
     fn = functools.partial(u.forward, classes=labels)
     a = gd.p_sample_loop(fn, (3, 3, 32, 32), device="cuda", seed=5, return_device_tensor=True)          # device loop
@@ -875,3 +882,74 @@ def test_nemo_archive_round_trip_samples_bit_for_bit(tmp_path):
                       "schedule_name": "cosine", "eta": 0.0, "ddim_timesteps": 5})
     imgs = r.sample(batch_size=3, image_size=32, seed=9)
     assert len(imgs) == 5 and torch.isfinite(imgs[-1]).all()
+
+
+def test_two_handles_sampling_side_by_side_never_starve_an_exchange(monkeypatch):
+    """The residency guarantee of the in-launch exchanges covers the exchanging launches of ONE handle's two chains. A second
+    handle that starts a loop while the first one's is in flight therefore closes its blocks with the separate passes
+    (what DMN_UNET_PATHS=128 selects by hand): no wait can starve, and every handle returns the bits of a run alone in
+    the form it took (which of the two keeps the exchanges depends on which thread got there first)."""
+    import threading
+    from diffusion_model_nemo_amd.modules import GaussianDiffusion
+    shape, steps = (32, 3, 64, 64), 150
+    units, alone = [], []
+    for seed in (21, 22):
+        torch.manual_seed(seed)
+        u = build_unet64("bf16")
+        gd = GaussianDiffusion(timesteps=steps, schedule_name="cosine")
+        with_exchange = gd.p_sample_loop(u, shape, device="cuda", seed=seed, return_device_tensor=True).clone()
+        monkeypatch.setenv("DMN_UNET_PATHS", "128")
+        torch.manual_seed(seed)
+        without = gd.p_sample_loop(build_unet64("bf16"), shape, device="cuda", seed=seed, return_device_tensor=True).clone()
+        monkeypatch.delenv("DMN_UNET_PATHS")
+        units.append((u, gd, torch.cuda.Stream(), seed))
+        alone.append((with_exchange, without))
+    torch.cuda.synchronize()
+    out = [None, None]
+
+    def run(i):
+        u, gd, st, seed = units[i]
+        with torch.cuda.stream(st):
+            out[i] = gd.p_sample_loop(u, shape, device="cuda", seed=seed, return_device_tensor=True, check=False)
+
+    for rep in range(3):
+        th = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+        for h in th:
+            h.start()
+        for h in th:
+            h.join(timeout=100)
+        torch.cuda.synchronize()
+        took = []
+        for i in range(2):
+            assert units[i][0].handoff_giveups() == 0
+            took.append("exchange" if torch.equal(out[i], alone[i][0]) else "passes" if torch.equal(out[i], alone[i][1]) else None)
+        print("side by side:", took)
+        assert None not in took and took.count("exchange") <= 1, took
+    # one after the other again: both may exchange
+    for i in range(2):
+        u, gd, _, seed = units[i]
+        assert torch.equal(gd.p_sample_loop(u, shape, device="cuda", seed=seed, return_device_tensor=True), alone[i][0])
+
+
+def test_exchange_areas_are_zeroed_before_the_epoch_can_wrap(monkeypatch):
+    """The tag of an exchanged partial sum is a 32-bit epoch. Long before it could wrap into the value of a stale tag the
+    host zeroes the handle's exchange areas in front of a loop; with the limit lowered to 40 evaluations that happens
+    before every loop here, and also in front of single forwards: same bits as with the default limit, no starved wait."""
+    from diffusion_model_nemo_amd.modules import GaussianDiffusion
+    gd = GaussianDiffusion(timesteps=25, schedule_name="cosine")
+    g = torch.Generator(device="cuda").manual_seed(2)
+    x = torch.randn(8, 3, 64, 64, device="cuda", generator=g)
+    t = torch.full((8,), 321, device="cuda", dtype=torch.long)
+    u = build_unet64("bf16")
+    want = [gd.p_sample_loop(u, (32, 3, 64, 64), device="cuda", seed=s, return_device_tensor=True).clone() for s in (1, 2, 3)]
+    want_fwd = u(x, t).clone()
+    monkeypatch.setenv("DMN_HANDOFF_EPOCH_LIMIT", "40")
+    v = build_unet64("bf16")
+    v.native_handle()            # the limit is read when the native handle is created
+    monkeypatch.delenv("DMN_HANDOFF_EPOCH_LIMIT")
+    for s in (1, 2, 3):
+        assert torch.equal(gd.p_sample_loop(v, (32, 3, 64, 64), device="cuda", seed=s, return_device_tensor=True), want[s - 1])
+    for _ in range(50):
+        y = v(x, t)
+    assert torch.equal(y, want_fwd)
+    assert v.handoff_giveups() == 0

@@ -184,3 +184,94 @@ def test_two_rank_replicas_hold_equal_parameters_after_a_step(tmp_path):
     p0 = torch.randn(1000, generator=g0)
     assert torch.equal(p0, want)
     assert np.array_equal(a[1], torch.randn(1000, generator=g0).numpy())     # rank 0's first moment everywhere
+
+
+# ---- data-parallel training: the broadcast comes BEFORE the first gradient is taken ------------------------------------
+def _cpu_trainer(seed):
+    """`UnetTrainer` with its device buffers replaced by CPU tensors and its gradient kernels by a closed form
+    (grad = 2 * params * data): what is under test is the ORDER of its calls, which needs no GPU."""
+    from diffusion_model_nemo_amd.training import UnetTrainer
+
+    class CpuTrainer(UnetTrainer):
+        def __init__(self):   # noqa: D401 - no native handle, no device
+            gen = torch.Generator().manual_seed(seed)
+            self.params, self.exp_avg, self.exp_avg_sq = (torch.randn(64, generator=gen) for _ in range(3))
+            self.grads = torch.zeros(64)
+            self.step_count = seed
+            self._synced = False
+            self._handle = None
+            self.unet = type("Net", (), {"_weights_version": 1})()
+
+        def loss_and_grads(self, data):
+            self._before_step()                     # what the real loss_and_grads does in front of its launches
+            self.grads = 2.0 * self.params * data
+            return (self.params ** 2 * data).sum()
+
+    return CpuTrainer()
+
+
+def _first_step_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    tr = _cpu_trainer(100 + rank)                   # every rank starts from its own parameters
+    data = torch.full((64,), float(rank + 1))
+    tr.loss_and_grads(data)                         # no process group yet: nothing to synchronise with ...
+    assert not tr._synced                           # ... and the trainer must not believe that it has
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tr.loss_and_grads(data)                     # the first gradient under the group is taken at rank 0's parameters
+        assert tr._synced and tr.step_count == 100
+        scale = tr.all_reduce_grads()
+        np.save(os.path.join(out_dir, f"first_step_rank{rank}.npy"), torch.stack([tr.params, tr.grads * scale]).numpy())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_replicas_are_synchronised_before_the_first_gradient(tmp_path):
+    mp.spawn(_first_step_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "first_step_rank0.npy"), np.load(tmp_path / "first_step_rank1.npy")
+    assert np.array_equal(a, b)
+    p0 = _cpu_trainer(100).params                  # rank 0's start
+    assert np.array_equal(a[0], p0.numpy())
+    want = (2.0 * p0 * 1.0 + 2.0 * p0 * 2.0) / 2    # mean over the ranks of gradients taken at THE SAME parameters
+    assert np.allclose(a[1], want.numpy(), rtol=1e-6, atol=0)
+
+
+# ---- bench.py's multi-rank control flow, rehearsed on the CPU ------------------------------------------------------------
+def _bench_worker(rank, world, port, out_dir, fail_rank):
+    """What `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` gives every rank: the rendezvous
+    variables, then bench.main(). stdout / stderr go to one file per rank."""
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "LOCAL_RANK": str(rank),
+                       "WORLD_SIZE": str(world)})
+    if fail_rank is not None:
+        os.environ["DMN_BENCH_DRY_FAIL_RANK"] = str(fail_rank)
+    sys.stdout = open(os.path.join(out_dir, f"bench_rank{rank}.out"), "w")
+    sys.stderr = open(os.path.join(out_dir, f"bench_rank{rank}.err"), "w")
+    import bench
+    bench.main(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--batch", "5", "--image-size", "8",
+                "--backend", "gloo", "--dry-run"])
+    assert not dist.is_initialized()          # the process group was destroyed on the way out
+    sys.stdout.flush()
+    sys.stderr.flush()
+
+
+@pytest.mark.parametrize("fail_rank", [None, 1])
+def test_bench_main_runs_two_ranks_through_its_control_flow(tmp_path, fail_rank):
+    """Process-group set-up from the launcher's environment, image_offset = rank * B (checked inside bench.py through the
+    index-valued images), the gather, the MIN-reduced agreement of the training extra (with one rank failing it: the
+    entry is dropped on every rank and nothing hangs), MAX-reduced times, ONE JSON line on rank 0 only, clean exit."""
+    import json
+    mp.spawn(_bench_worker, args=(2, _free_port(), str(tmp_path), fail_rank), nprocs=2, join=True)
+    lines0 = [ln for ln in open(tmp_path / "bench_rank0.out").read().splitlines() if ln.strip()]
+    lines1 = [ln for ln in open(tmp_path / "bench_rank1.out").read().splitlines() if ln.strip()]
+    assert len(lines0) == 1 and lines1 == [], (lines0, lines1)
+    res = json.loads(lines0[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["warmup"] == 1 and res["scaling"] == "weak"
+    assert res["config"]["global_batch"] == 10 and res["config"]["parallelism"] == "dp2"
+    assert res["dry_run"] is True and res["backend"] == "gloo" and res["handoff_giveups"] == 0 and res["value"] > 0
+    if fail_rank is None:
+        assert res["train_step"]["n_gpus"] == 2 and res["train_step"]["config"]["global_batch"] == 64
+    else:
+        assert "train_step" not in res
+        assert "injected failure" in open(tmp_path / f"bench_rank{fail_rank}.err").read()
