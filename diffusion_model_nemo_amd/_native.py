@@ -10,6 +10,10 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdmn_hip.so")
+# Tuning aid: DMN_LIB_VARIANT=<tag> loads lib/libdmn_hip_<tag>.so instead (another build of the same sources, for A/B runs on
+# one box). There is still no fallback: a variant that is missing raises like the default library would.
+if os.environ.get("DMN_LIB_VARIANT"):
+    LIB_PATH = os.path.join(_HERE, "lib", f"libdmn_hip_{os.environ['DMN_LIB_VARIANT']}.so")
 
 DMN_MAX_MULTS = 8
 TABLE_COLS = 12

@@ -563,7 +563,7 @@ extern "C" int dmn_test_conv_block_tail(int dtype, const void* in, int Cin, int 
     const float inv_count = 1.0f / ((float)(Cout / G) * H * W);
     if (giveups) *giveups = 0;
     if (fused) {
-        const size_t bytes = kHandoffHeaderBytes + (size_t)B * G * conv_epi_slots(a) * 16;
+        const size_t bytes = kHandoffHeaderBytes + (size_t)B * G * conv_epi_slots(a) * kHandoffGranulesPerSlot * sizeof(unsigned long long);
         unsigned hdr[2] = {1u, 0u};   // epoch 1 over a zeroed area
         if (!conv_tail_fits(a) || hipMalloc(&area, bytes) != hipSuccess || hipMemset(area, 0, bytes) != hipSuccess ||
             hipMemcpy(area, hdr, sizeof(hdr), hipMemcpyHostToDevice) != hipSuccess) {
@@ -589,7 +589,7 @@ extern "C" int dmn_test_conv_block_tail(int dtype, const void* in, int Cin, int 
         if (giveups) (void)hipMemcpy(giveups, (char*)area + 4, 4, hipMemcpyDeviceToHost);
     } else {
         const int slots = conv_epi_slots(a);
-        if (hipMalloc((void**)&h2_stats, (size_t)B * G * slots * 8) != hipSuccess) {
+        if (hipMalloc((void**)&h2_stats, (size_t)B * G * slots * 4 * sizeof(float)) != hipSuccess) {
             cleanup();
             return DMN_ERR_HIP;
         }

@@ -116,6 +116,55 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ---- GroupNorm statistics as partial moments (layout, combination rule and rationale: dmn_norm.h) -----------------
+// A partial is {s = sum, m2 = sum of squared deviations from the partial's own mean, n = element count}.
+// Value of the first lane of each aligned row of 16 lanes, in every lane of that row (four scalar reads and three
+// selects: no LDS routing). Reads the four lanes whatever the exec mask is.
+__device__ __forceinline__ float row16_first(float v) {
+    const int iv = __builtin_bit_cast(int, v);
+    const int s0 = __builtin_amdgcn_readlane(iv, 0), s1 = __builtin_amdgcn_readlane(iv, 16);
+    const int s2 = __builtin_amdgcn_readlane(iv, 32), s3 = __builtin_amdgcn_readlane(iv, 48);
+    const int q = (threadIdx.x & 63) >> 4;
+    return __builtin_bit_cast(float, q == 0 ? s0 : q == 1 ? s1 : q == 2 ? s2 : s3);
+}
+
+// Sums of deviations from a shift K (any value of the right magnitude: a sample of the distribution) over n elements,
+// sd = sum (x - K), qd = sum (x - K)^2, as a partial {s, m2, n}. The squares summed are those of differences of the order
+// of the spread, so qd - sd^2 / n cancels digits of the spread's scale only, not of the mean's.
+__device__ __forceinline__ void moments_from_shifted(float sd, float qd, float n, float K, float& s, float& m2) {
+    s = n > 0.f ? __builtin_fmaf(n, K, sd) : 0.f;
+    const float m = n > 0.f ? qd - sd * sd * __builtin_amdgcn_rcpf(n) : 0.f;
+    m2 = m > 0.f ? m : 0.f;
+}
+
+// Contribution of one partial to the M2 of the union whose mean is `mean`.
+__device__ __forceinline__ float moments_term(float s, float m2, float n, float mean) {
+    const float d = __builtin_fmaf(-n, mean, s);   // n * (mean_i - mean) with one rounding
+    return n > 0.f ? m2 + d * d * __builtin_amdgcn_rcpf(n) : 0.f;
+}
+
+// Sum over an aligned segment of `seg` lanes (16, 32 or 64), the same order-fixed result in every lane of the segment.
+__device__ __forceinline__ float seg_sum(float v, int seg) {
+    v = row16_sum(v);
+    if (seg >= 32) v += __shfl_xor(v, 16, 64);
+    if (seg == 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// mean / rstd of a group from its total sum S and total M2 (both already combined over all partials).
+__device__ __forceinline__ void moments_finish(float M2, float inv_count, float& rstd) {
+    float var = M2 * inv_count;
+    var = var > 0.f ? var : 0.f;
+    rstd = __builtin_amdgcn_rsqf(var + 1e-5f);   // 1 ulp; the IEEE sqrt + divide pair is ~35 instructions
+}
+
+// A group that has ONE partial (the workgroup that needs the statistics holds every element of the group): the
+// arithmetic of the general combination with one slot, so both forms give the same bits.
+__device__ __forceinline__ void moments_single(float s, float m2, float n, float inv_count, float& mean, float& rstd) {
+    mean = s * inv_count;
+    moments_finish(moments_term(s, m2, n, mean), inv_count, rstd);
+}
+
 // ---- error plumbing shared by the C-ABI translation units -------------------------------------
 enum DmnStatus {
     DMN_OK = 0,

@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
     char* sX = smem;
     float* sCoef = reinterpret_cast<float*>(smem + (size_t)NPIX * rowB + kLdsSlack);
     float* sTmp = sCoef + (PRO ? 3 * Cin : 0);      // 2*G floats of normalisation scratch
-    float* sRed = sTmp + (PRO ? 2 * a.pro.G : 0);   // 2*WM*BN/4 floats of statistics scratch
+    float* sRed = sTmp + (PRO ? (2 * a.pro.G + 3) & ~3 : 0);   // 4*WM*BN/4 floats of statistics scratch, 16-byte aligned
 
     // ---- everything that only depends on the block index is requested first -------------------------------
     // weight ring: fragment (ct, flat = ks*NTAPS + tap) is 64 lanes x 16 B, contiguous in flat
@@ -404,38 +404,71 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
                                 (unsigned)a.Cout;
         const unsigned ostep = (unsigned)(ROWS * a.out_sy * a.out_W) * (unsigned)a.Cout;
         const bool col_ok = oxt < a.Wo;
-        // Per-lane sums of 4-channel quads -> one {sum, sum of squares} per (group, workgroup), handed to emit(g, slot,
-        // s, ss) by the first threads. Contains one barrier, which every wave reaches behind its MFMA loop.
-        auto wg_partials = [&](float (&ps)[NT], float (&pq)[NT], int G, auto emit) {
+        // Partial moments {sum, squared deviations from the partial's own mean, count} (dmn_norm.h) of value(mt, nt, r): one
+        // partial per ROW of 16 pixel lanes and 4-channel quad, formed without LDS or barrier. The 16 lanes sum deviations
+        // from ONE shift, the first value of the row's first lane (a valid pixel whenever the row holds one: tiles start
+        // inside the image), so their sums simply add -- independent butterflies as for plain sums -- and the row's
+        // first lane takes the shift out. Slots of a group are numbered (workgroup, wave row wm, quad inside the group);
+        // combining them is the consumer's work (combine_groups: one lane per slot).
+        auto mt_valid = [&](int mt) { return col_ok && oyt0 + mt * ROWS < a.Ho; };
+        auto row_moments = [&](auto value, float (&rs)[NT], float (&rm2)[NT], float& nrow) {
+            float ps[NT], pq[NT], pk[NT];
+            float cnt = 0.f;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                // reduce over the 16 pixel lanes; lane (lane&15)==0 of each quarter holds the sums of a 4-channel quad
-                ps[nt] = row16_sum(ps[nt]);
-                pq[nt] = row16_sum(pq[nt]);
-                if (l15 == 0) {
+                ps[nt] = pq[nt] = 0.f;
+                pk[nt] = row16_first(value(0, nt, 0));
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                if (mt_valid(mt)) {
+                    cnt += 4.f;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float d = value(mt, nt, r) - pk[nt];
+                            ps[nt] += d;
+                            pq[nt] += d * d;
+                        }
+                }
+            nrow = row16_sum(cnt);   // elements of a 4-channel quad over the row's valid pixels
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) moments_from_shifted(row16_sum(ps[nt]), row16_sum(pq[nt]), nrow, pk[nt], rs[nt], rm2[nt]);
+        };
+        // the row partials as slots: sink(g, slot, s, m2, n) runs in the first lane of every row
+        auto rows_to_slots = [&](auto value, int G, auto sink) {
+            float rs[NT], rm2[NT], nrow;
+            row_moments(value, rs, rm2, nrow);
+            if (l15 == 0) {
+                const int cpg = a.Cout / G;
+                const int qpg = (cpg >= BN ? BN : cpg) / 4;    // quads per touched group inside this workgroup
+                const int sub = cpg > BN ? cpg / BN : 1;       // workgroups (along N) sharing one group
+                const int wgslot = blockIdx.x * sub + (cpg > BN ? (n0 % cpg) / BN : 0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
                     const int quad = (wn * NT + nt) * 4 + lq;  // local quad index in [0, BN/4)
-                    sRed[(wm * (BN / 4) + quad) * 2] = ps[nt];
-                    sRed[(wm * (BN / 4) + quad) * 2 + 1] = pq[nt];
+                    sink((n0 + quad * 4) / cpg, (wgslot * WM + wm) * qpg + quad % qpg, rs[nt], rm2[nt], nrow);
                 }
             }
-            __syncthreads();
-            const int cpg = a.Cout / G;
-            const int ngl = cpg >= BN ? 1 : BN / cpg;      // groups this workgroup touches
-            const int qpg = (cpg >= BN ? BN : cpg) / 4;    // quads per touched group inside this workgroup
-            const int sub = cpg > BN ? cpg / BN : 1;       // workgroups (along N) sharing one group
-            if (tid < ngl) {
-                float s = 0.f, ss = 0.f;
-                for (int w_ = 0; w_ < WM; ++w_)
-                    for (int q = 0; q < qpg; ++q) {
-                        s += sRed[(w_ * (BN / 4) + tid * qpg + q) * 2];
-                        ss += sRed[(w_ * (BN / 4) + tid * qpg + q) * 2 + 1];
-                    }
-                emit(n0 / cpg + tid, blockIdx.x * sub + (cpg > BN ? (n0 % cpg) / BN : 0), s, ss);
-            }
         };
-        float ssum[NT], ssq[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) ssum[nt] = ssq[nt] = 0.f;
+        // A workgroup that holds every pixel and channel of its groups: the row partials go to LDS in slot order and are
+        // combined there, by the consumer's own routine (same values, same order: same bits as through a buffer).
+        auto local_stats = [&](auto value, int G, float inv_count, float* sMR) {
+            const int cpg = a.Cout / G;
+            const int qpg = (cpg >= BN ? BN : cpg) / 4;
+            const int ngl = cpg >= BN ? 1 : BN / cpg;
+            rows_to_slots(value, G, [&](int g, int slot, float s_, float m2_, float n_) {
+                *reinterpret_cast<f32x4*>(sRed + ((g - n0 / cpg) * (WM * qpg) + slot) * 4) = f32x4{s_, m2_, n_, 0.f};
+            });
+            __syncthreads();
+            combine_groups(ngl, WM * qpg, inv_count, sMR, [&](int g, int i) { return *reinterpret_cast<const f32x4*>(sRed + (g * (WM * qpg) + i) * 4); });
+        };
+        auto conv_value = [&](int mt, int nt, int r) { return acc[mt][nt][r] + bias[nt][r]; };
+        auto store_partial = [&](const NormOut& o, int g, int slot, float s_, float m2_, float n_) {
+            f32x4* dst = reinterpret_cast<f32x4*>(o.stats) + (size_t)(b * o.G + g) * o.slots + slot;
+            *dst = f32x4{s_, m2_, n_, 0.f};
+        };
         if constexpr (TAIL) {
             // (0) requests whose answers are only needed behind the wait: the residual operand of every output
             //     fragment, this thread's channel of the closing GroupNorm
@@ -459,40 +492,22 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
             }
             // (1) statistics of conv + bias over this workgroup's pixels, published as granules -- unless this workgroup
             //     holds every pixel and channel of its groups (one slot per group: nothing to exchange)
-            const bool exchange = a.epi.slots > 1;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                if (col_ok && oyt0 + mt * ROWS < a.Ho) {
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float v = acc[mt][nt][r] + bias[nt][r];
-                            ssum[nt] += v;
-                            ssq[nt] += v * v;
-                        }
-                }
-            }
-            // the halo tile is dead behind the barrier inside wg_partials: its LDS holds mean / rstd of this
-            // workgroup's groups and then the per-channel coefficients
+            const bool exchange = a.epi_wgs > 1;
+            // The halo tile is dead once every wave has left its MFMA loop: its LDS then holds mean / rstd of this
+            // workgroup's groups and the per-channel coefficients. The statistics scratch sRed lies behind the tile.
             float* sMR = reinterpret_cast<float*>(smem);
             float* sC = sMR + 2 * kHandoffMaxGroups;
             const int ng = cpg >= BN ? 1 : BN / cpg;
-            wg_partials(ssum, ssq, G, [&](int g, int slot, float s, float ss) {
-                if (exchange) {
-                    unsigned long long* dst = a.tail.gran + ((size_t)(b * G + g) * a.epi.slots + slot) * 2;
-                    granule_store(dst, epoch, s);
-                    granule_store(dst + 1, epoch, ss);
-                } else {   // the arithmetic of the exchange with one slot
-                    const float mean = s * a.tail_inv_count;
-                    float var = ss * a.tail_inv_count - mean * mean;
-                    var = var > 0.f ? var : 0.f;
-                    sMR[2 * (g - n0 / cpg)] = mean;
-                    sMR[2 * (g - n0 / cpg) + 1] = __builtin_amdgcn_rsqf(var + 1e-5f);
-                }
-            });
-            // (2) wait for the image's other workgroups
-            if (exchange) handoff_group_stats(a.tail, epoch, b, G, a.epi.slots, n0 / cpg, ng, a.tail_inv_count, sMR);
+            if (exchange) {
+                rows_to_slots(conv_value, G, [&](int g, int slot, float s_, float m2_, float n_) {
+                    handoff_publish(a.tail, epoch, b, G, a.epi.slots, g, slot, s_, m2_, n_);
+                });
+                __syncthreads();   // every wave is done with the halo tile
+                // (2) wait for the image's other workgroups
+                handoff_group_stats(a.tail, epoch, b, G, a.epi.slots, n0 / cpg, ng, a.tail_inv_count, sMR);
+            } else {   // the arithmetic of the exchange on this workgroup's own partials
+                local_stats(conv_value, G, a.tail_inv_count, sMR);
+            }
             __syncthreads();
             if (a.dbg && tid == 0) a.dbg[wgid * 8 + 6] = clock64();
             if (tid < BN) {
@@ -505,8 +520,6 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
             // (3) out = SiLU(GroupNorm(conv + bias)) + res, in the arithmetic of the stand-alone closing pass (which
             //     reads the convolution's output rounded to the activation type)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) ssum[nt] = ssq[nt] = 0.f;
-#pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const bool valid = col_ok && oyt0 + mt * ROWS < a.Ho;
                 const unsigned obase = obase0 + (unsigned)mt * ostep;
@@ -517,27 +530,23 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
                     const f32x4 ca = *reinterpret_cast<const f32x4*>(sC + cl);
                     const f32x4 cb = *reinterpret_cast<const f32x4*>(sC + BN + cl);
                     if (valid) {
-                        float y[4];
+                        // the result replaces the accumulator: the statistics below take it from there
                         if constexpr (sizeof(T) == 4) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 float t = (acc[mt][nt][r] + bias[nt][r]) * ca[r] + cb[r];
                                 t = silu_precise(t);
                                 t += 0.f;
-                                y[r] = t + rv[mt][nt][r];
-                                ssum[nt] += y[r];
-                                ssq[nt] += y[r] * y[r];
+                                acc[mt][nt][r] = t + rv[mt][nt][r];
                             }
-                            store_stream(reinterpret_cast<f32x4*>(outp + obase + n), f32x4{y[0], y[1], y[2], y[3]});
+                            store_stream(reinterpret_cast<f32x4*>(outp + obase + n), acc[mt][nt]);
                         } else {
                             bf16x4 o;
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const float x = (float)(__bf16)(acc[mt][nt][r] + bias[nt][r]);
                                 o[r] = (__bf16)(silu_affine_fast(x, ca[r], cb[r], 0.f) + (float)rv[mt][nt][r]);
-                                const float yr = (float)o[r];   // statistics of the value the consumer will read
-                                ssum[nt] += yr;
-                                ssq[nt] += yr * yr;
+                                acc[mt][nt][r] = (float)o[r];   // statistics of the value the consumer will read
                             }
                             store_stream(reinterpret_cast<bf16x4*>(outp + obase + n), o);
                         }
@@ -546,12 +555,8 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
             }
             // (4) partial statistics of the block's output
             if (a.tail_stats.stats) {
-                const int Go = a.tail_stats.G;
-                wg_partials(ssum, ssq, Go, [&](int g, int slot, float s, float ss) {
-                    float* dst = a.tail_stats.stats + ((size_t)(b * Go + g) * a.tail_stats.slots + slot) * 2;
-                    dst[0] = s;
-                    dst[1] = ss;
-                });
+                rows_to_slots([&](int mt, int nt, int r) { return acc[mt][nt][r]; }, a.tail_stats.G,
+                              [&](int g, int slot, float s_, float m2_, float n_) { store_partial(a.tail_stats, g, slot, s_, m2_, n_); });
             }
         } else {
         const bool want_stats = a.epi.stats != nullptr;
@@ -572,29 +577,10 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
                     pbet = a.act_beta[n0 + tid];
                     if (a.act_tbias) ptb = a.act_tbias[(size_t)b * a.act_tb_stride + n0 + tid];
                 }
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    if (col_ok && oyt0 + mt * ROWS < a.Ho) {
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float v = acc[mt][nt][r] + bias[nt][r];
-                                ssum[nt] += v;
-                                ssq[nt] += v * v;
-                            }
-                    }
-                }
-                // the halo tile is dead behind the barrier inside wg_partials
+                // the halo tile is dead behind the barrier inside local_stats
                 float* sMR = reinterpret_cast<float*>(smem);
                 float* sC = sMR + 2 * kHandoffMaxGroups;
-                wg_partials(ssum, ssq, G, [&](int g, int, float s, float ss) {   // one slot: the sums are the totals
-                    const float mean = s * a.act_inv_count;
-                    float var = ss * a.act_inv_count - mean * mean;
-                    var = var > 0.f ? var : 0.f;
-                    sMR[2 * (g - n0 / cpg)] = mean;
-                    sMR[2 * (g - n0 / cpg) + 1] = __builtin_amdgcn_rsqf(var + 1e-5f);
-                });
+                local_stats(conv_value, G, a.act_inv_count, sMR);
                 __syncthreads();
                 if (tid < BN) {
                     const int gl = cpg >= BN ? 0 : tid / cpg;
@@ -650,13 +636,6 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = acc[mt][nt][r] + bias[nt][r];
                 if (valid) {
-                    if (want_stats) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            ssum[nt] += v[r];
-                            ssq[nt] += v[r] * v[r];
-                        }
-                    }
                     if (resp) {
                         if constexpr (sizeof(T) == 4) {
                             const f32x4 rv = *reinterpret_cast<const f32x4*>(resp + obase + n);
@@ -708,13 +687,9 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
                 }
             }
         }
-        if (want_stats && !activated) {
-            const int G = a.epi.G;
-            wg_partials(ssum, ssq, G, [&](int g, int slot, float s, float ss) {
-                float* dst = a.epi.stats + ((size_t)(b * G + g) * a.epi.slots + slot) * 2;
-                dst[0] = s;
-                dst[1] = ss;
-            });
+        if (want_stats && !activated) {   // of conv + bias, before the residual
+            rows_to_slots(conv_value, a.epi.G,
+                          [&](int g, int slot, float s_, float m2_, float n_) { store_partial(a.epi, g, slot, s_, m2_, n_); });
         }
         }
     }
@@ -796,7 +771,7 @@ size_t lds_bytes(const ConvArgs& a, const TileCfg& c, int cg) {
     size_t n = tile_pixels(a, c) * (cg * esz + kRowPad) + kLdsSlack;
     const int Cin = a.C0 + a.C1;
     if (a.pro.stats) n += (size_t)3 * Cin * 4;
-    size_t red = 2 * 4 * (c.bn / 4);
+    size_t red = 4 * 4 * (c.bn / 4) + 4;
     if (a.pro.stats) red += 2 * a.pro.G;
     n += red * 4 + 64;
     return n;
@@ -962,13 +937,23 @@ int conv_init_attributes() {
     return DMN_OK;
 }
 
+// partials per (image, group): one per workgroup that touches the group, wave row and 4-channel quad of the group inside it
+static int rows_per_wg(const TileCfg& c) { return (c.th == 8 && c.bn == 64) ? 1 : 2; }   // WM of the kernel that serves the tile
 static int slots_for_groups(const ConvArgs& a, int G) {
+    const TileCfg c = pick_cfg(a);
+    const int tiles = ((a.Ho + c.th - 1) / c.th) * ((a.Wo + c.tw - 1) / c.tw);
+    const int cpg = a.Cout / G;
+    return tiles * (cpg > c.bn ? cpg / c.bn : 1) * rows_per_wg(c) * ((cpg >= c.bn ? c.bn : cpg) / 4);
+}
+// workgroups that touch a group of an image: 1 = the workgroup holds the whole group (nothing to exchange)
+static int wgs_per_group(const ConvArgs& a, int G) {
     const TileCfg c = pick_cfg(a);
     const int tiles = ((a.Ho + c.th - 1) / c.th) * ((a.Wo + c.tw - 1) / c.tw);
     const int cpg = a.Cout / G;
     return tiles * (cpg > c.bn ? cpg / c.bn : 1);
 }
 int conv_epi_slots(const ConvArgs& a) { return slots_for_groups(a, a.epi.G); }
+int conv_epi_wgs(const ConvArgs& a) { return wgs_per_group(a, a.epi.G); }
 int conv_tail_slots(const ConvArgs& a) { return slots_for_groups(a, a.tail_stats.G); }
 // workgroups of one image in the launch
 static int wgs_per_image(const ConvArgs& a) {
@@ -980,12 +965,12 @@ bool conv_act_fits(const ConvArgs& a) {
     if (a.kind != DMN_K3X3 || a.nphase != 1 || a.epi.G < 1 || a.epi.G > kHandoffMaxGroups || a.Cout % a.epi.G) return false;
     const TileCfg c = pick_cfg(a);
     const int cpg = a.Cout / a.epi.G;
-    return c.th == 8 && cpg % 4 == 0 && cpg <= c.bn && c.bn % cpg == 0 && conv_epi_slots(a) == 1;
+    return c.th == 8 && cpg % 4 == 0 && cpg <= c.bn && c.bn % cpg == 0 && wgs_per_group(a, a.epi.G) == 1;
 }
 bool conv_tail_fits(const ConvArgs& a) {
     if (a.epi.G < 1 || a.epi.G > kHandoffMaxGroups) return false;
     const int slots = conv_epi_slots(a);
-    if (slots == 1) return true;   // every group lies inside one workgroup: nothing is exchanged, nothing waits
+    if (wgs_per_group(a, a.epi.G) == 1) return true;   // every group lies inside one workgroup: nothing is exchanged, nothing waits
     ConvArgs t = a;
     t.pro.stats = t.pro.stats ? t.pro.stats : reinterpret_cast<const float*>(1);   // the tail rides on the prologue kernel
     const TileCfg c = pick_cfg(t);
@@ -1013,6 +998,7 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
         DMN_REQUIRE(!a.epi.stats && !a.tail.gran && !a.res && a.act_beta && conv_act_fits(a), DMN_ERR_INVALID,
                     "conv: the activating epilogue needs a 3x3 convolution whose workgroups hold whole groups of an image");
         a.epi.slots = 1;
+        a.epi_wgs = 1;
     }
     if (a.epi.stats || a.tail.gran) {
         DMN_REQUIRE(a.nphase == 1 && a.Cout % a.epi.G == 0 && (a.Cout / a.epi.G) % 4 == 0, DMN_ERR_INVALID,
@@ -1020,6 +1006,7 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
         const int cpg = a.Cout / a.epi.G;
         DMN_REQUIRE(cpg >= c.bn ? cpg % c.bn == 0 : c.bn % cpg == 0, DMN_ERR_INVALID, "conv: group size %d vs tile %d", cpg, c.bn);
         a.epi.slots = conv_epi_slots(a);
+        a.epi_wgs = conv_epi_wgs(a);
     }
     if (a.tail.gran && a.tail_stats.stats) {
         DMN_REQUIRE(a.tail_stats.G >= 1 && a.Cout % a.tail_stats.G == 0 && (a.Cout / a.tail_stats.G) % 4 == 0, DMN_ERR_INVALID,
@@ -1044,7 +1031,7 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
     DMN_REQUIRE(lds <= 160 * 1024, DMN_ERR_INVALID, "conv: LDS request %zu too large", lds);
     // a launch whose workgroups wait for each other stays small enough to be resident as a whole (dmn_handoff.h)
     int per_launch = a.B;
-    if (a.tail.gran && a.epi.slots > 1) {
+    if (a.tail.gran && a.epi_wgs > 1) {
         per_launch = kHandoffMaxWgsPerLaunch / wgs_per_image(a);
         if (per_launch < 1) per_launch = 1;
     }

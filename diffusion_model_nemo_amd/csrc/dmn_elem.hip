@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(kNormThreads) norm_apply_kernel(const NormAppl
     using V = decltype(Vec16<T>::v);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sCoef = reinterpret_cast<float*>(smem);
-    float* sTmp = sCoef + 3 * a.C;            // max(2*G_in, 2*4*G_out)
+    float* sTmp = sCoef + 3 * a.C;            // 2*G_in
     const int b = blockIdx.y;
     const int C = a.C;
     const int vec_per_pix = C / PER;
@@ -62,14 +62,10 @@ __global__ void __launch_bounds__(kNormThreads) norm_apply_kernel(const NormAppl
     // launcher), so the group of each of its quads is fixed. Statistics are accumulated per 4-channel quad of
     // the thread's 16-byte vector (a quad never straddles an output group: groups hold a multiple of 4 channels).
     constexpr int NQ = PER / 4;
-    float s[NQ], ss[NQ];
     int qgroup[NQ];
     const int cb = (threadIdx.x % vec_per_pix) * PER;
 #pragma unroll
-    for (int k = 0; k < NQ; ++k) {
-        s[k] = ss[k] = 0.f;
-        qgroup[k] = (cb + 4 * k) / cpg_o;
-    }
+    for (int k = 0; k < NQ; ++k) qgroup[k] = (cb + 4 * k) / cpg_o;
     float ca[PER], cbeta[PER], ct[PER];
 #pragma unroll
     for (int e = 0; e < PER; ++e) {
@@ -77,10 +73,17 @@ __global__ void __launch_bounds__(kNormThreads) norm_apply_kernel(const NormAppl
         cbeta[e] = sCoef[C + cb + e];
         ct[e] = sCoef[2 * C + cb + e];
     }
+    // Statistics of the result as sums of deviations from a per-thread shift, the first value of each of the thread's
+    // 4-channel quads (dmn_common.h: moments_from_shifted): one subtraction per element more than plain sums.
+    int nmine = 0;   // vectors of this thread inside the slice
+    float sd[NQ], qd[NQ], kshift[NQ];
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) sd[k] = qd[k] = kshift[k] = 0.f;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int i = threadIdx.x + j * kNormThreads;
         if (i < nvec) {
+            ++nmine;
             Vec16<T> v, r;
             v.v = vin[j];
             if (res) r.v = vres[j];
@@ -101,42 +104,51 @@ __global__ void __launch_bounds__(kNormThreads) norm_apply_kernel(const NormAppl
                 if (res) y += r.get(e);
                 v.set(e, y);
                 const float yr = v.get(e);  // statistics of the value the consumer will read
-                s[e / 4] += yr;
-                ss[e / 4] += yr * yr;
+                if (j == 0 && e % 4 == 0) kshift[e / 4] = yr;   // a thread's vectors are valid from j = 0 on
+                const float d = yr - kshift[e / 4];
+                sd[e / 4] += d;
+                qd[e / 4] += d * d;
             }
             store_stream(reinterpret_cast<V*>(out + (size_t)i * PER), v.v);
         }
     }
     if (want) {
-        // threads -> LDS per (group, thread) would be large; instead reduce with LDS atomics-free two-step:
-        // each wave reduces lanes that share a group via a small per-wave table.
-        __syncthreads();
-        float* sAcc = sTmp;  // [4 waves][Go][2]
+        // thread -> wave by the two-pass rule of dmn_norm.h, four groups at a time so that their cross-lane sums are in
+        // flight together; every wave writes its own slot (4 * workgroup + wave): no LDS, no barrier, the consumer combines
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        for (int g = 0; g < Go; ++g) {
-            float ms = 0.f, mss = 0.f;
+        float ts[NQ], tm2[NQ];
+        const float tn = 4.f * nmine;
 #pragma unroll
-            for (int k = 0; k < NQ; ++k) {
-                ms += (qgroup[k] == g) ? s[k] : 0.f;
-                mss += (qgroup[k] == g) ? ss[k] : 0.f;
+        for (int k = 0; k < NQ; ++k) moments_from_shifted(sd[k], qd[k], tn, kshift[k], ts[k], tm2[k]);
+        for (int g0 = 0; g0 < Go; g0 += 4) {
+            float ws[4], wn[4], wq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float ms = 0.f, mn = 0.f;
+#pragma unroll
+                for (int k = 0; k < NQ; ++k) {
+                    ms += (qgroup[k] == g0 + u) ? ts[k] : 0.f;
+                    mn += (qgroup[k] == g0 + u) ? tn : 0.f;
+                }
+                ws[u] = wave_sum(ms);
+                wn[u] = wave_sum(mn);
             }
-            const float ws = wave_sum(ms), wss = wave_sum(mss);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float wmean = wn[u] > 0.f ? ws[u] * __builtin_amdgcn_rcpf(wn[u]) : 0.f;
+                float mq = 0.f;
+#pragma unroll
+                for (int k = 0; k < NQ; ++k) mq += (qgroup[k] == g0 + u) ? moments_term(ts[k], tm2[k], tn, wmean) : 0.f;
+                wq[u] = wave_sum(mq);
+            }
             if (lane == 0) {
-                sAcc[(wave * Go + g) * 2] = ws;
-                sAcc[(wave * Go + g) * 2 + 1] = wss;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (g0 + u < Go) {
+                        f32x4* dst = reinterpret_cast<f32x4*>(a.epi.stats) + (size_t)(b * Go + g0 + u) * a.epi.slots + blockIdx.x * 4 + wave;
+                        *dst = f32x4{ws[u], wq[u], wn[u], 0.f};
+                    }
             }
-        }
-        __syncthreads();
-        if (threadIdx.x < Go) {
-            const int g = threadIdx.x;
-            float ts = 0.f, tss = 0.f;
-            for (int w = 0; w < kNormThreads / 64; ++w) {
-                ts += sAcc[(w * Go + g) * 2];
-                tss += sAcc[(w * Go + g) * 2 + 1];
-            }
-            float* dst = a.epi.stats + ((size_t)(b * Go + g) * a.epi.slots + blockIdx.x) * 2;
-            dst[0] = ts;
-            dst[1] = tss;
         }
     }
 }
@@ -537,30 +549,30 @@ static int norm_apply_elems(int B, int HW, int C) {
     return (long long)B * HW * C / kNormElems >= 1024 ? kNormElems : kNormElemsSmall;
 }
 
-int norm_apply_slots(int B, int HW, int C) {
+static int norm_apply_wgs(int B, int HW, int C) {   // workgroups (pixel slices) per image
     int pix = norm_apply_elems(B, HW, C) / C;
     if (pix < 1) pix = 1;
     if (pix > HW) pix = HW;
     return (HW + pix - 1) / pix;
 }
+// partial moments per (image, group) of the output statistics: one per wave of every workgroup
+int norm_apply_slots(int B, int HW, int C) { return 4 * norm_apply_wgs(B, HW, C); }
 
 int launch_norm_apply(NormApplyArgs& a, hipStream_t s) {
     const int per = a.dtype == DMN_F32 ? 4 : 8;
     DMN_REQUIRE(a.C % per == 0 && a.C % a.norm.G == 0, DMN_ERR_INVALID, "norm_apply: C=%d groups=%d", a.C, a.norm.G);
     DMN_REQUIRE(kNormThreads % (a.C / per) == 0 && a.C <= kNormElemsSmall, DMN_ERR_INVALID, "norm_apply: C=%d must be a power-of-two multiple of %d", a.C, per);
     const int planB = a.plan_B > 0 ? a.plan_B : a.B;
-    const int slots = norm_apply_slots(planB, a.HW, a.C);
+    const int slots = norm_apply_wgs(planB, a.HW, a.C);
     const bool small = norm_apply_elems(planB, a.HW, a.C) == kNormElemsSmall;
     const int pix = (a.HW + slots - 1) / slots;
     int Go = 1;
     if (a.epi.stats) {
         Go = a.epi.G;
         DMN_REQUIRE(a.C % Go == 0 && (a.C / Go) % 4 == 0, DMN_ERR_INVALID, "norm_apply: output groups %d", Go);
-        a.epi.slots = slots;
+        a.epi.slots = 4 * slots;
     }
-    size_t tmp = 2 * (size_t)a.norm.G;
-    if ((size_t)8 * Go > tmp) tmp = 8 * Go;
-    const size_t lds = (3 * (size_t)a.C + tmp) * 4;
+    const size_t lds = (3 * (size_t)a.C + 2 * (size_t)a.norm.G) * 4;
     dim3 grid(slots, a.B);
     if (a.dtype == DMN_F32) {
         if (small) hipLaunchKernelGGL((norm_apply_kernel<float, kNormElemsSmall>), grid, dim3(kNormThreads), lds, s, a, pix);

@@ -4,7 +4,7 @@
 // A kernel whose epilogue needs statistics of its own output (the closing SiLU(GroupNorm(h)) + res of a ResnetBlock,
 // parts/convnext.py:85-86, or the GroupNorm(1) + residual behind a linear attention, parts/mha.py:41-42) would
 // otherwise end at a kernel boundary and hand its tile to a second pass. Here every workgroup of an image publishes its
-// partial {sum, sum of squares} as 8-byte GRANULES {tag = epoch, value = float bits}, each written by one agent-scope
+// partial moments {sum, squared deviations, count} (dmn_norm.h) as 8-byte GRANULES {tag = epoch, value = float bits}, each written by one agent-scope
 // relaxed atomic store (a write-through store that every XCD observes) and read by agent-scope relaxed atomic loads
 // (which bypass the reader's L1): the data is its own flag, so no fence, no counter and no ordering between granules
 // is needed. A reader polls its granules until all carry the current epoch.
@@ -40,7 +40,7 @@ constexpr int kHandoffMaxLdsBytes = 80 * 1024;     // half a CU
 
 // Host view of a fused tail's statistics hand-off (kernel argument).
 struct HandoffArgs {
-    unsigned long long* gran;   // [B][G][slots][2] granules; nullptr: the launch has no fused tail
+    unsigned long long* gran;   // [B][G][slots][kHandoffGranulesPerSlot] granules; nullptr: the launch has no fused tail
     const unsigned* epoch;      // current epoch of the chain
     unsigned* giveups;          // incremented when a bounded spin runs out
 };
@@ -53,28 +53,45 @@ __device__ __forceinline__ unsigned long long granule_load(const unsigned long l
     return __hip_atomic_load((const dmn_gu64*)g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Granules per partial: {sum, sum of squared deviations from the partial's own mean, element count} (dmn_norm.h); the
+// fourth keeps the stride a power of two.
+constexpr int kHandoffGranulesPerSlot = 4;
+
 // Mean / rstd of `ng` consecutive groups (first group g_first) of image `b` from the granules of all its workgroups;
-// result pairs in sMR[2 * local group]. Called by every wave of a 256-thread workgroup; no barrier inside. The slots
-// of a group are summed exactly as norm_coefs_to_lds sums the slots of a stats buffer (one slot per lane of a 16-, 32-
-// or 64-lane segment, then a fixed butterfly), so the coefficients equal those of the two-launch form bit for bit.
+// result pairs in sMR[2 * local group]. Called by every wave of a 256-thread workgroup; no barrier inside. The partials
+// of a group are combined exactly as combine_groups (dmn_norm.h) combines the slots of a stats buffer -- 16 lanes per
+// group, lane l holds slots l, l + 16, l + 32, l + 48, a fixed butterfly for the sum, then one for the squared
+// deviations -- so the coefficients equal those of the two-launch form bit for bit. slots <= kHandoffMaxSlots.
 __device__ __forceinline__ void handoff_group_stats(const HandoffArgs& h, unsigned epoch, int b, int G, int slots, int g_first,
                                                     int ng, float inv_count, float* sMR) {
+    constexpr int KEEP = kHandoffMaxSlots / 16;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nwaves = blockDim.x >> 6;
-    const int seg = slots <= 16 ? 16 : slots <= 32 ? 32 : 64;
-    const int gpw = 64 / seg;
-    const int sl = lane & (seg - 1);
-    for (int g0 = wave * gpw; g0 < ng; g0 += nwaves * gpw) {
-        const int gl = g0 + lane / seg;
-        const bool mine = gl < ng && sl < slots;
-        const unsigned long long* p = h.gran + (((size_t)b * G + g_first + (mine ? gl : 0)) * slots + (mine ? sl : 0)) * 2;
-        unsigned long long va = 0, vb = 0;
+    const int sl = lane & 15;
+    for (int g0 = wave * 4; g0 < ng; g0 += nwaves * 4) {
+        const int gl = g0 + (lane >> 4);
+        const bool live = gl < ng;
+        const unsigned long long* p = h.gran + ((size_t)b * G + g_first + (live ? gl : 0)) * slots * kHandoffGranulesPerSlot;
+        unsigned long long va[KEEP], vb[KEEP], vc[KEEP];
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) va[k] = vb[k] = vc[k] = 0;
+        unsigned bad_a = 0, bad_b = 0;
         const long long t0 = wall_clock64();
         for (;;) {
             bool ok = true;
-            if (mine) {
-                va = granule_load(p);
-                vb = granule_load(p + 1);
-                ok = (unsigned)(va >> 32) == epoch && (unsigned)(vb >> 32) == epoch;
+#pragma unroll
+            for (int k = 0; k < KEEP; ++k) {
+                const int i = sl + 16 * k;
+                if (live && i < slots) {
+                    va[k] = granule_load(p + (size_t)i * kHandoffGranulesPerSlot);
+                    vb[k] = granule_load(p + (size_t)i * kHandoffGranulesPerSlot + 1);
+                    vc[k] = granule_load(p + (size_t)i * kHandoffGranulesPerSlot + 2);
+                    const bool here = (unsigned)(va[k] >> 32) == epoch && (unsigned)(vb[k] >> 32) == epoch && (unsigned)(vc[k] >> 32) == epoch;
+                    if (!here) {
+                        bad_a = (unsigned)(va[k] >> 32);
+                        bad_b = (unsigned)(vb[k] >> 32);
+                    }
+                    ok = ok && here;
+                }
             }
             if (__all(ok)) break;
             if (wall_clock64() - t0 > kHandoffSpinTicks) {   // wave-uniform: every lane reads the same clock region
@@ -84,8 +101,8 @@ __device__ __forceinline__ void handoff_group_stats(const HandoffArgs& h, unsign
                 if (!ok && atomicCAS(h.giveups + 1, 0u, 1u) == 0u) {
                     unsigned* d = h.giveups + 2;
                     d[0] = epoch;
-                    d[1] = (unsigned)(va >> 32);
-                    d[2] = (unsigned)(vb >> 32);
+                    d[1] = bad_a;
+                    d[2] = bad_b;
                     d[3] = (unsigned)b;
                     d[4] = (unsigned)(g_first + gl);
                     d[5] = (unsigned)sl;
@@ -98,24 +115,29 @@ __device__ __forceinline__ void handoff_group_stats(const HandoffArgs& h, unsign
             }
             __builtin_amdgcn_s_sleep(4);
         }
-        float s = mine ? __uint_as_float((unsigned)va) : 0.f;
-        float ss = mine ? __uint_as_float((unsigned)vb) : 0.f;
-        s = row16_sum(s);
-        ss = row16_sum(ss);
-        if (seg >= 32) {
-            s += __shfl_xor(s, 16, 64);
-            ss += __shfl_xor(ss, 16, 64);
-        }
-        if (seg == 64) {
-            s += __shfl_xor(s, 32, 64);
-            ss += __shfl_xor(ss, 32, 64);
-        }
-        if (sl == 0 && gl < ng) {
-            const float mean = s * inv_count;
-            float var = ss * inv_count - mean * mean;
-            var = var > 0.f ? var : 0.f;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) s += __uint_as_float((unsigned)va[k]);   // slots not held are zero
+        const float mean = seg_sum(s, 16) * inv_count;
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k)
+            t += moments_term(__uint_as_float((unsigned)va[k]), __uint_as_float((unsigned)vb[k]), __uint_as_float((unsigned)vc[k]), mean);
+        const float M2 = seg_sum(t, 16);
+        if (sl == 0 && live) {
+            float rstd;
+            moments_finish(M2, inv_count, rstd);
             sMR[2 * gl] = mean;
-            sMR[2 * gl + 1] = __builtin_amdgcn_rsqf(var + 1e-5f);
+            sMR[2 * gl + 1] = rstd;
         }
     }
+}
+
+// One workgroup's partial of (image b, group g) into its granules.
+__device__ __forceinline__ void handoff_publish(const HandoffArgs& h, unsigned epoch, int b, int G, int slots, int g, int slot,
+                                                float s, float m2, float n) {
+    unsigned long long* dst = h.gran + (((size_t)b * G + g) * slots + slot) * kHandoffGranulesPerSlot;
+    granule_store(dst, epoch, s);
+    granule_store(dst + 1, epoch, m2);
+    granule_store(dst + 2, epoch, n);
 }

@@ -10,10 +10,11 @@ enum { DMN_F32 = 0, DMN_BF16 = 1 };
 enum { DMN_K3X3 = 0, DMN_K1X1 = 1, DMN_K4X4S2 = 2, DMN_KT2X2 = 3 };
 
 // ---- group-norm statistics passed between kernels -----------------------------------------------
-// A producer writes, for every (image, group), `slots` partial {sum, sum of squares} pairs, one per
-// contributing workgroup, each slot written exactly once: layout [B][G][slots][2] fp32. A consumer
-// adds the slots in index order (deterministic) and derives mean / rstd. `count` is the number of
-// elements per (image, group).
+// A producer writes, for every (image, group), `slots` partial moments {sum, squared deviations from the
+// partial's own mean, element count, unused}, one per contributing workgroup, each slot written exactly
+// once: layout [B][G][slots][4] fp32. A consumer combines the slots in a fixed order (dmn_norm.h:
+// deterministic, and free of the cancellation of sum / sum-of-squares pairs) and derives mean / rstd.
+// 1 / inv_count is the number of elements per (image, group).
 struct NormIn {
     const float* stats;   // nullptr: no normalisation
     int G;
@@ -59,6 +60,7 @@ struct ConvArgs {
     void* pro_out;        // optional with pro_res: receives the resulting tensor (same shape as in0)
     const void* res;      // optional residual added in the epilogue, same shape as out
     NormOut epi;          // statistics of the output after bias (taken before the residual add)
+    int epi_wgs;          // workgroups that touch one group of an image (1: a workgroup holds whole groups); set by the launcher
     const void* w2;       // optional fused 1x1 convolution of the same input (3x3 kind, no input normalisation):
     const float* bias2;   //   weights packed like `w` with one tap, bias [Cout],
     void* out2;           //   output [B][out_H][out_W][Cout]
@@ -87,6 +89,7 @@ struct ConvArgs {
 };
 int launch_conv(ConvArgs& a, hipStream_t s);
 int conv_epi_slots(const ConvArgs& a);   // slots per (image, group) launch_conv will write
+int conv_epi_wgs(const ConvArgs& a);     // workgroups that contribute to one (image, group)
 int conv_tail_slots(const ConvArgs& a);  // same for tail_stats
 bool conv_act_fits(const ConvArgs& a);   // epi.G groups: the launch may apply its own GroupNorm + SiLU (act_* fields)
 bool conv_tail_fits(const ConvArgs& a);  // epi.G groups / their partial sums within the hand-off's limits
@@ -183,7 +186,7 @@ struct LinAttnFusedArgs {
     const float* bias;    // [C] to_out bias
     float* ctx_part;      // workspace [B][4][splits][32*32 + 64]
     void* ctxT;           // workspace [B][4][32][32] in the activation dtype: merged, scaled context, transposed
-    float* y_stats;       // [B][1][slices][2]
+    float* y_stats;       // [B][1][slices][4] partial moments
     int B, n, C;
     int slice1, splits;   // pass 1: workgroup slice in pixels (multiple of 32)
     int tpw, slices;      // pass 2: workgroup slice = 64*tpw pixels

@@ -396,7 +396,7 @@ __global__ void __launch_bounds__(256) la_fused_out_kernel(const LinAttnFusedArg
     char* sCtx = smem + ((3 * C + 8) * 4 + 15) / 16 * 16;                  // [4][32 rows e][CTX_ROW]
     char* sO = sCtx + kHeads * kD * CTX_ROW;                               // [64 px][O_ROW]
     char* sX = sO + 64 * O_ROW;
-    float* sRed = reinterpret_cast<float*>(sX + (size_t)slice * row_bytes);   // 8 floats
+    float* sRed = reinterpret_cast<float*>(sX + (size_t)slice * row_bytes);   // 16 floats: partial moments of the four waves
     const int b = a.b_first + blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
@@ -494,7 +494,12 @@ __global__ void __launch_bounds__(256) la_fused_out_kernel(const LinAttnFusedArg
     Vec16<T> ones;
 #pragma unroll
     for (int e = 0; e < ElemTraits<T>::kPer16B; ++e) ones.set(e, 1.0f);
-    float ssum = 0.f, ssq = 0.f;
+    // GroupNorm(1) statistics of y as partial moments (dmn_norm.h), one per wave. The values leave the registers as they
+    // are produced, so the wave sums deviations from ONE shift, the first value its first lane produces (the wave's
+    // lowest pixel: inside the image whenever any of the wave's pixels is; any value of the distribution will do as a
+    // shift: what matters is that the squares summed are those of differences of the order of the spread, not of the
+    // mean). With a common shift the lanes' sums simply add, and the shift is taken out once at the end.
+    float ssum = 0.f, ssq = 0.f, scnt = 0.f, sshift = 0.f;
     T* yout = static_cast<T*>(a.y) + (size_t)b * a.n * C;
     for (int g = 0; g < a.tpw; ++g) {
         // ---- phase A: head `wave` on the four pixel tiles of the group ------------------------------------------
@@ -605,6 +610,7 @@ __global__ void __launch_bounds__(256) la_fused_out_kernel(const LinAttnFusedArg
                 for (int i = 0; i < YPW; ++i) mma_step(wor[i][ko], of, y[i][pt]);
             }
         }
+        if (g == 0) sshift = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, y[0][0][0] + bias[0][0])));
 #pragma unroll
         for (int pt = 0; pt < PTW; ++pt) {
             const int px = p0 + g * 64 + (ptb + pt) * 16 + l15;
@@ -614,10 +620,13 @@ __global__ void __launch_bounds__(256) la_fused_out_kernel(const LinAttnFusedArg
                     const int c = (yt0 + 4 * i) * 16 + lq * 4;
                     float v[4];
 #pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = y[i][pt][r] + bias[i][r];
+                    scnt += 4.f;
+#pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        v[r] = y[i][pt][r] + bias[i][r];
-                        ssum += v[r];
-                        ssq += v[r] * v[r];
+                        const float d = v[r] - sshift;
+                        ssum += d;
+                        ssq += d * d;
                     }
                     // TAIL: y replaces the staged pixel it came from (every wave is done with the group's rows of sX
                     // since the barrier between the phases)
@@ -639,31 +648,24 @@ __global__ void __launch_bounds__(256) la_fused_out_kernel(const LinAttnFusedArg
         if (g + 1 < a.tpw) __syncthreads();       // sO is rewritten by the next group
     }
     LA_STAMP(dbg2, 3)
-    // GroupNorm(1) partial statistics of y: one slot per workgroup
-    ssum = wave_sum(ssum);
-    ssq = wave_sum(ssq);
-    if (lane == 0) {
-        sRed[2 * wave] = ssum;
-        sRed[2 * wave + 1] = ssq;
+    // one partial per WAVE (slot 4 * workgroup + wave); the consumer combines them
+    float pws, pwq, pwn;   // this wave's partial moments: three independent cross-lane sums, then the shift taken out
+    {
+        const float sd = wave_sum(ssum), qd = wave_sum(ssq);
+        pwn = wave_sum(scnt);
+        moments_from_shifted(sd, qd, pwn, sshift, pws, pwq);
     }
-    __syncthreads();
     if constexpr (!TAIL) {
-        if (tid == 0) {
-            float s = 0.f, ss = 0.f;
-            for (int w = 0; w < 4; ++w) {
-                s += sRed[2 * w];
-                ss += sRed[2 * w + 1];
-            }
-            float* dst = a.y_stats + ((size_t)b * gridDim.x + blockIdx.x) * 2;
-            dst[0] = s;
-            dst[1] = ss;
+        if (lane == 0) {
+            f32x4* dst = reinterpret_cast<f32x4*>(a.y_stats) + ((size_t)b * gridDim.x + blockIdx.x) * 4 + wave;
+            *dst = f32x4{pws, pwq, pwn, 0.f};
         }
     } else {
         // ---- closing GroupNorm(1) + residual ------------------------------------------------------------------------
         constexpr int PARTS = C / PER;                 // 16-byte units per pixel
         constexpr int XB = 4;                          // residual units requested ahead of the wait
         const unsigned epoch = *a.tail.epoch;
-        const int slots = gridDim.x;
+        const int slots = 4 * gridDim.x;               // one partial per wave of every workgroup of the image
         float* sMR = sCoef + 3 * C;
         const T* xres = static_cast<const T*>(a.x) + (size_t)b * a.n * C;
         T* outp = static_cast<T*>(a.out) + (size_t)b * a.n * C;
@@ -683,25 +685,14 @@ __global__ void __launch_bounds__(256) la_fused_out_kernel(const LinAttnFusedArg
             pgam = a.tail_gamma[tid];
             pbet = a.tail_beta[tid];
         }
-        if (tid == 0) {
-            float s = 0.f, ss = 0.f;
-            for (int w = 0; w < 4; ++w) {
-                s += sRed[2 * w];
-                ss += sRed[2 * w + 1];
-            }
-            if (slots > 1) {
-                unsigned long long* dst = a.tail.gran + ((size_t)b * slots + blockIdx.x) * 2;
-                granule_store(dst, epoch, s);
-                granule_store(dst + 1, epoch, ss);
-            } else {   // the arithmetic of the exchange with one slot
-                const float mean = s * a.tail_inv_count;
-                float var = ss * a.tail_inv_count - mean * mean;
-                var = var > 0.f ? var : 0.f;
-                sMR[0] = mean;
-                sMR[1] = __builtin_amdgcn_rsqf(var + 1e-5f);
-            }
+        if (slots > 4) {   // several workgroups per image: exchange
+            if (lane == 0) handoff_publish(a.tail, epoch, b, 1, slots, 0, blockIdx.x * 4 + wave, pws, pwq, pwn);
+            handoff_group_stats(a.tail, epoch, b, 1, slots, 0, 1, a.tail_inv_count, sMR);
+        } else {           // the arithmetic of the exchange on this workgroup's own four partials
+            if (lane == 0) *reinterpret_cast<f32x4*>(sRed + 4 * wave) = f32x4{pws, pwq, pwn, 0.f};
+            __syncthreads();
+            combine_groups(1, 4, a.tail_inv_count, sMR, [&](int, int i) { return *reinterpret_cast<const f32x4*>(sRed + 4 * i); });
         }
-        if (slots > 1) handoff_group_stats(a.tail, epoch, b, 1, slots, 0, 1, a.tail_inv_count, sMR);
         __syncthreads();
         for (int c = tid; c < C; c += 256) {           // C <= 256: one channel per thread
             const float aa = sMR[1] * pgam;
@@ -854,7 +845,7 @@ int launch_linattn_fused(LinAttnFusedArgs& a, hipStream_t s) {
     DMN_REQUIRE(a.ctxT, DMN_ERR_INVALID, "fused linear attention: needs the merged-context buffer");
     DMN_REQUIRE(a.slices <= 65535 && a.splits <= 65535, DMN_ERR_LIMIT, "fused linear attention: image too large");
     if (a.tail.gran)
-        DMN_REQUIRE(a.slices <= kHandoffMaxSlots && a.out && a.tail.epoch && a.tail.giveups && a.tail_gamma && a.tail_beta,
+        DMN_REQUIRE(4 * a.slices <= kHandoffMaxSlots && a.out && a.tail.epoch && a.tail.giveups && a.tail_gamma && a.tail_beta,
                     DMN_ERR_INVALID, "fused linear attention: closing GroupNorm needs <= %d pixel slices, parameters and an output",
                     kHandoffMaxSlots);
     else DMN_REQUIRE(a.y && a.y_stats, DMN_ERR_INVALID, "fused linear attention: needs y and its statistics buffer");

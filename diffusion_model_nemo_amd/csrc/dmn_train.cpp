@@ -317,7 +317,7 @@ struct Ten {
     int adt = 0;              // 0 float32, 1 bfloat16 storage (value and gradient alike)
     int C = 0, H = 0, W = 0;
     bool gset = false;
-    float* stats = nullptr;   // {sum, sum of squares} per (image, group) left by the producing kernel
+    double* stats = nullptr;  // float64 {sum, sum of squares} per (image, group) left by the producing kernel
     int statsG = 0;
 };
 
@@ -368,6 +368,7 @@ struct Run {
         if (!p) fail_ws();
         return p;
     }
+    double* zalloc_stats(size_t pairs) { return reinterpret_cast<double*>(zalloc(pairs * 4)); }   // float64 {sum, sum of squares}
     size_t numel(const Ten* t) const { return (size_t)B * t->H * t->W * t->C; }
     void* alloc_elems(size_t n, int adt) {
         void* p = a.alloc(n * (adt == 1 ? 2 : 4));
@@ -436,7 +437,7 @@ Ten* conv(Run& r, Ten* x, const ConvP& w, bool need_dx = true, const float* bias
     a.adt = x->adt;
     a.statsG = statsG;
     if (statsG > 0 && pgemm_stats_supported(a)) {
-        y->stats = a.stats = r.zalloc((size_t)r.B * statsG * 2);
+        y->stats = a.stats = r.zalloc_stats((size_t)r.B * statsG);
         y->statsG = statsG;
     }
     RUN(r, launch_pgemm(a, r.s));
@@ -513,9 +514,9 @@ Ten* gnorm(Run& r, Ten* x, const NormP& n, int G, int act, const float* tb, floa
            bool ystats = false) {
     Ten* y = r.nt(x->C, x->H, x->W, x->adt);
     const bool have = x->stats && x->statsG == G;
-    float* stats = have ? x->stats : r.zalloc((size_t)r.B * G * 2);
+    double* stats = have ? x->stats : r.zalloc_stats((size_t)r.B * G);
     if (ystats) {
-        y->stats = r.zalloc((size_t)r.B * 2);
+        y->stats = r.zalloc_stats((size_t)r.B);
         y->statsG = 1;
     }
     GnArgs a;

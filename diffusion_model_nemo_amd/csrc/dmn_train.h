@@ -23,7 +23,7 @@ struct PGemmArgs {
     int ldout, N;
     int accumulate;
     int bf16;               // 1: operands rounded to bf16 for the matrix cores (fp32 accumulate)
-    float* stats;           // optional [B][statsG][2], zeroed: += {sum, sum of squares} of the output per GroupNorm group
+    double* stats;          // optional [B][statsG][2] float64, zeroed: += {sum, sum of squares} of the output per GroupNorm group
     int statsG;
     int adt;                // type of in / out
 };
@@ -47,18 +47,21 @@ struct WGemmArgs {
 };
 int launch_wgemm(const WGemmArgs& a, hipStream_t s);
 
-// GroupNorm over NHWC: stats[b][g] = {sum, sum of squares} (atomic into zeroed memory)
-int launch_gn_stats(const void* x, int adt, int B, int HW, int C, int G, float* stats, hipStream_t s);
+// GroupNorm over NHWC: stats[b][g] = {sum, sum of squares} (atomic into zeroed memory). The sums are float64: the
+// variance is E[x^2] - E[x]^2, which in float32 loses log10(mean^2 / var) of its 7 digits (a group 50 standard deviations
+// off zero keeps 3); float64 atomics cost nothing measurable here and keep 12. Workgroup-level partials of a few
+// elements are formed in float32 and widened before they meet.
+int launch_gn_stats(const void* x, int adt, int B, int HW, int C, int G, double* stats, hipStream_t s);
 // y = act(gn(x) * gamma + beta) + tb[b][c] + res   (act: 0 none, 1 SiLU; tb optional with row stride tb_ld)
 struct GnArgs {
     const void* x;
-    const float* stats;
+    const double* stats;    // [B][G][2] float64 {sum, sum of squares}
     const float *gamma, *beta;
     const float* tb;
     int tb_ld;
     const void* res;        // optional residual added after the activation (same shape as y)
     void* y;
-    float* ystats;          // optional [B][2], zeroed: += {sum, sum of squares} of y per image (a following GroupNorm(1))
+    double* ystats;         // optional [B][2] float64, zeroed: += {sum, sum of squares} of y per image (a following GroupNorm(1))
     int B, HW, C, G, act;
     int adt;                // type of x, res, y, dy, dx
     // backward

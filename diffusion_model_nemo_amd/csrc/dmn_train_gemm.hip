@@ -68,7 +68,7 @@ __device__ __forceinline__ bf16x8 pack_bf16(const float* v) {
 // nothing reads any more), then one atomic pair per group the tile touches.
 template <int BN>
 __device__ __forceinline__ void tile_stats(const float (&s1)[BN / 16], const float (&s2)[BN / 16], float* red, int n0, int N, int Cg,
-                                           float* stats_b) {
+                                           double* stats_b) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
 #pragma unroll
     for (int j = 0; j < BN / 16; ++j) {
@@ -86,13 +86,13 @@ __device__ __forceinline__ void tile_stats(const float (&s1)[BN / 16], const flo
     if (tid < BN) {
         const int n = n0 + tid;
         if (n < N && (tid == 0 || n % Cg == 0)) {
-            float a = 0.f, b = 0.f;
+            double a = 0.0, b = 0.0;   // 16-pixel partials in float32 so far; from here on float64 (dmn_train.h)
             const int g = n / Cg;
             for (int t = tid; t < BN && n0 + t < N && (n0 + t) / Cg == g; ++t)
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
-                    a += red[(w * BN + t) * 2];
-                    b += red[(w * BN + t) * 2 + 1];
+                    a += (double)red[(w * BN + t) * 2];
+                    b += (double)red[(w * BN + t) * 2 + 1];
                 }
             unsafeAtomicAdd(stats_b + 2 * g, a);
             unsafeAtomicAdd(stats_b + 2 * g + 1, b);

@@ -29,6 +29,15 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
     return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// the same in float64 (GroupNorm statistics); sh: >= 4 doubles
+__device__ __forceinline__ double block_sum_d(double v, double* sh) {
+    for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
 __device__ __forceinline__ float sigmoid_f(float z) { return 1.0f / (1.0f + expf(-z)); }
 __device__ __forceinline__ float silu_grad(float z) {
     const float sg = sigmoid_f(z);
@@ -41,33 +50,34 @@ __device__ __forceinline__ float gelu_grad(float x) {
 
 // ---- GroupNorm ----------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, int HW, int C, int G, float* __restrict__ stats) {
-    __shared__ float sh[4];
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, int HW, int C, int G, double* __restrict__ stats) {
+    __shared__ double sh[4];
     const int bg = blockIdx.x, b = bg / G, g = bg - b * G;
     const int cg4 = (C / G) >> 2;
     const long long total = (long long)HW * cg4;
     const T* base = x + (size_t)b * HW * C + g * (C / G);
-    float s = 0.f, ss = 0.f;
+    double s = 0.0, ss = 0.0;   // four elements at a time in float32, the running sums in float64 (dmn_train.h)
     for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < total; i += (long long)gridDim.y * 256) {
         const long long p = i / cg4;
         const int c4 = (int)(i - p * cg4);
         const f32x4 v = Io<T>::ld4(base + p * C + 4 * c4);
-        s += (v[0] + v[1]) + (v[2] + v[3]);
-        ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        s += (double)((v[0] + v[1]) + (v[2] + v[3]));
+        ss += (double)((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
     }
-    s = block_sum(s, sh);
-    ss = block_sum(ss, sh);
+    s = block_sum_d(s, sh);
+    ss = block_sum_d(ss, sh);
     if (threadIdx.x == 0) {
         unsafeAtomicAdd(stats + 2 * bg, s);
         unsafeAtomicAdd(stats + 2 * bg + 1, ss);
     }
 }
 
-__device__ __forceinline__ void gn_mean_rstd(const float* stats, int bg, float inv_cnt, float& mean, float& rstd) {
-    const float s = stats[2 * bg], ss = stats[2 * bg + 1];
-    mean = s * inv_cnt;
-    const float var = fmaxf(ss * inv_cnt - mean * mean, 0.f);
-    rstd = 1.0f / sqrtf(var + kGnEps);
+__device__ __forceinline__ void gn_mean_rstd(const double* stats, int bg, float inv_cnt, float& mean, float& rstd) {
+    const double s = stats[2 * bg], ss = stats[2 * bg + 1];
+    const double m = s * (double)inv_cnt;
+    const double var = fmax(ss * (double)inv_cnt - m * m, 0.0);   // float64: the cancellation costs digits it can spare
+    mean = (float)m;
+    rstd = 1.0f / sqrtf((float)var + kGnEps);
 }
 
 // grid (blocks, B): a workgroup stays inside one image, so the statistics of its output need one atomic pair
@@ -75,13 +85,13 @@ template <typename T> __global__ __launch_bounds__(256) void gn_apply_kernel(con
     const T* x = reinterpret_cast<const T*>(a.x);
     const T* res = reinterpret_cast<const T*>(a.res);
     T* y = reinterpret_cast<T*>(a.y);
-    __shared__ float sh[4];
+    __shared__ double sh[4];
     const int c4n = a.C >> 2, b = blockIdx.y;
     const long long total = (long long)a.HW * c4n;
     const int Cg = a.C / a.G;
     const float inv_cnt = 1.0f / ((float)Cg * (float)a.HW);
     const size_t img = (size_t)b * a.HW * a.C;
-    float s1 = 0.f, s2 = 0.f;
+    double s1 = 0.0, s2 = 0.0;
     if (256 % c4n == 0) {
         // A thread keeps its four channels (the stride of the walk is a multiple of the channel vectors per pixel): the
         // group's mean / rstd and the channel parameters are fetched once, and four pixels' loads are in flight together.
@@ -103,8 +113,8 @@ template <typename T> __global__ __launch_bounds__(256) void gn_apply_kernel(con
                 o[e] = z + tbv[e] + rv[e];
             }
             Io<T>::st4(yp + (size_t)p * a.C, o);
-            s1 += (o[0] + o[1]) + (o[2] + o[3]);
-            s2 += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+            s1 += (double)((o[0] + o[1]) + (o[2] + o[3]));
+            s2 += (double)((o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]));
         };
         const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
         int p = blockIdx.x * ppb + threadIdx.x / c4n;
@@ -143,12 +153,12 @@ template <typename T> __global__ __launch_bounds__(256) void gn_apply_kernel(con
             for (int e = 0; e < 4; ++e) o[e] += rv[e];
         }
         Io<T>::st4(y + off, o);
-        s1 += (o[0] + o[1]) + (o[2] + o[3]);
-        s2 += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+        s1 += (double)((o[0] + o[1]) + (o[2] + o[3]));
+        s2 += (double)((o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]));
     }
     if (a.ystats) {
-        s1 = block_sum(s1, sh);
-        s2 = block_sum(s2, sh);
+        s1 = block_sum_d(s1, sh);
+        s2 = block_sum_d(s2, sh);
         if (threadIdx.x == 0) {
             unsafeAtomicAdd(a.ystats + 2 * b, s1);
             unsafeAtomicAdd(a.ystats + 2 * b + 1, s2);
@@ -1243,7 +1253,7 @@ inline int grid_for(long long n, int per_block = 256, int cap = 8192) {
 
 }   // namespace
 
-int launch_gn_stats(const void* x, int adt, int B, int HW, int C, int G, float* stats, hipStream_t s) {
+int launch_gn_stats(const void* x, int adt, int B, int HW, int C, int G, double* stats, hipStream_t s) {
     DMN_REQUIRE(C % G == 0 && (C / G) % 4 == 0, DMN_ERR_INVALID, "gn: C=%d G=%d", C, G);
     const long long per = (long long)HW * (C / G) / 4;
     int split = (int)((per + 2047) / 2048);

@@ -254,7 +254,7 @@ struct Fwd {
         a.p = alloc((size_t)B * H * W * C * esz());
         return a;
     }
-    float* new_stats(int G, int slots) { return (float*)alloc((size_t)B * G * slots * 2 * 4); }
+    float* new_stats(int G, int slots) { return (float*)alloc((size_t)B * G * slots * 4 * sizeof(float)); }   // {sum, m2, n, -} per slot
     void free_act(Act& a) {
         ar.release(a.p);
         ar.release(a.stats);
@@ -468,7 +468,7 @@ static Act resblock(Fwd& f, const ResBlockW& w, Act& x, Act* x2, const float* tb
         a.pro = n1;
         a.epi.G = G;
         if (conv_tail_fits(a)) {
-            unsigned long long* gran = f.handoff_take((size_t)f.B * G * conv_epi_slots(a) * 2 * sizeof(unsigned long long));
+            unsigned long long* gran = f.handoff_take((size_t)f.B * G * conv_epi_slots(a) * kHandoffGranulesPerSlot * sizeof(unsigned long long));
             if (gran || f.dry) {
                 Act out = f.new_act(w.c2.Cout, a.out_H, a.out_W);
                 if (f.dry) {   // plan for the two-launch form as well (its peak is the larger one)
@@ -547,7 +547,7 @@ static bool block_tail_is_local(Fwd& f, const ResBlockW& w, int H, int W) {
     a.plan_B = f.planB();
     a.C0 = w.c2.Cin;
     a.epi.G = f.u->cfg.groups;
-    return conv_tail_fits(a) && (conv_epi_slots(a) == 1 || !(f.u->path_mask & 16384));
+    return conv_tail_fits(a) && (conv_epi_wgs(a) == 1 || !(f.u->path_mask & 16384));
 }
 
 // A linear attention whose closing `GroupNorm(y) + x` has not been applied: the resampling convolution that consumes it
@@ -605,14 +605,14 @@ static Act lin_attn(Fwd& f, const AttnW& w, Act& x, LazyAttn* defer = nullptr) {
         fa.separate_merge = (f.u->path_mask & 1024) != 0;
         if (!defer && f.ho_enabled && !(f.u->path_mask & 256) && linattn_tail_fits(fa.n, f.planB(), fa.C, c.dtype)) {
             // the second launch closes the attention itself (GroupNorm(1)(y) + x, partial sums exchanged inside the launch)
-            unsigned long long* gran = f.handoff_take((size_t)f.B * fa.slices * 2 * sizeof(unsigned long long));
+            unsigned long long* gran = f.handoff_take((size_t)f.B * 4 * fa.slices * kHandoffGranulesPerSlot * sizeof(unsigned long long));   // a partial per wave
             if (gran || f.dry) {
                 Act out = f.new_act(x.C, x.H, x.W);
                 float* part = (float*)f.alloc((size_t)f.B * 4 * fa.splits * (32 * 32 + 64) * 4);
                 void* ctxT = f.alloc((size_t)f.B * 4 * 32 * 32 * f.esz());
                 if (f.dry) {   // plan for the three-launch form as well (its peak is the larger one)
                     Act y = f.new_act(x.C, x.H, x.W);
-                    float* st = f.new_stats(1, fa.slices);
+                    float* st = f.new_stats(1, 4 * fa.slices);
                     f.ar.release(st);
                     f.free_act(y);
                 }
@@ -631,8 +631,8 @@ static Act lin_attn(Fwd& f, const AttnW& w, Act& x, LazyAttn* defer = nullptr) {
         }
         Act y = f.new_act(x.C, x.H, x.W);
         y.sG = 1;
-        y.sSlots = fa.slices;
-        y.stats = f.new_stats(1, fa.slices);
+        y.sSlots = 4 * fa.slices;   // a partial per wave of every pixel slice
+        y.stats = f.new_stats(1, y.sSlots);
         float* part = (float*)f.alloc((size_t)f.B * 4 * fa.splits * (32 * 32 + 64) * 4);
         void* ctxT = f.alloc((size_t)f.B * 4 * 32 * 32 * f.esz());
         fa.ctxT = ctxT;
@@ -1025,7 +1025,7 @@ static int test_linattn_impl(int dtype, const void* x, const float* x_stats, int
     }
     fa.ctx_part = (float*)scratch;
     fa.y_stats = y_stats;
-    if (slices_out) *slices_out = fa.slices;
+    if (slices_out) *slices_out = 4 * fa.slices;   // statistic slots per image: one per wave of every pixel slice
     fa.ctxT = ctxT;
     if (giveups) *giveups = 0;
     if (closing == 1) {
@@ -1034,7 +1034,7 @@ static int test_linattn_impl(int dtype, const void* x, const float* x_stats, int
             dmn_set_error("dmn_test_linattn_block: shape outside the in-launch exchange's limits");
             return DMN_ERR_LIMIT;
         }
-        const size_t bytes = kHandoffHeaderBytes + (size_t)B * fa.slices * 16;
+        const size_t bytes = kHandoffHeaderBytes + (size_t)B * 4 * fa.slices * kHandoffGranulesPerSlot * sizeof(unsigned long long);
         unsigned hdr[2] = {1u, 0u};   // epoch 1 over a zeroed area
         if (hipMalloc(&area, bytes) != hipSuccess || hipMemset(area, 0, bytes) != hipSuccess ||
             hipMemcpy(area, hdr, sizeof(hdr), hipMemcpyHostToDevice) != hipSuccess) {
@@ -1062,7 +1062,7 @@ static int test_linattn_impl(int dtype, const void* x, const float* x_stats, int
         na.C = C;
         na.norm.stats = y_stats;
         na.norm.G = 1;
-        na.norm.slots = fa.slices;
+        na.norm.slots = 4 * fa.slices;
         na.norm.inv_count = 1.0f / ((float)C * n);
         na.norm.gamma = og;
         na.norm.beta = ob;
@@ -1122,10 +1122,12 @@ extern "C" int dmn_bench_dominant_kernel(DmnUnet* u, int B, int H, int W, int it
     // zero activations with statistics {sum 0, sum of squares = count}: mean 0, variance 1
     DMN_HIP_CHECK(hipMemsetAsync(x.p, 0, (size_t)B * H * W * C * f.esz(), s));
     DMN_HIP_CHECK(hipMemsetAsync(tb, 0, (size_t)u->tb_total * 4, s));
-    std::vector<float> st((size_t)B * G * 2);
-    for (size_t i = 0; i < st.size(); i += 2) {
+    std::vector<float> st((size_t)B * G * 4);
+    for (size_t i = 0; i < st.size(); i += 4) {   // one partial per group: sum 0, squared deviations = count
         st[i] = 0.f;
         st[i + 1] = (float)(C / G) * H * W;
+        st[i + 2] = (float)(C / G) * H * W;
+        st[i + 3] = 0.f;
     }
     DMN_HIP_CHECK(hipMemcpyAsync(x.stats, st.data(), st.size() * 4, hipMemcpyHostToDevice, s));
     DMN_HIP_CHECK(hipStreamSynchronize(s));

@@ -254,8 +254,10 @@ int dmn_fill_normal(float* x, int B, int per, uint64_t seed, uint32_t step, int6
  * Activations NHWC in the internal dtype (float32 or bfloat16 bit patterns). Weights HOST float32 in PyTorch layout;
  * these helpers pack + upload them per call (synchronous, test use only). */
 /* Fused LinearAttention core (parts/mha.py:44-58 up to and including to_out.0) on x [B][n][C] normalised with
- * GroupNorm(1) from x_stats = {sum, sum of squares} per image: y [B][n][C] = to_out.0(attention) + bias, and the
- * per-slice {sum, sum of squares} of y in y_stats [B][*slices_out][2]. wqkv [384][C], wout [C][128] HOST float32.
+ * GroupNorm(1) from x_stats = one partial {sum, sum of squared deviations from the mean, element count, 0} per image:
+ * y [B][n][C] = to_out.0(attention) + bias, and the partials of y in the same format in y_stats
+ * [B][*slices_out][4] (*slices_out = partials per image: one per wave of every pixel slice). wqkv [384][C], wout [C][128]
+ * HOST float32.
  * scratch: device, >= B * 4 * ceil(n / 32) * 1088 * 4 bytes. */
 int dmn_test_linattn(int dtype, const void* x, const float* x_stats, int B, int n, int C, const float* gamma_host,
                      const float* beta_host, const float* wqkv_host, const float* wout_host, const float* bout_host,
@@ -288,6 +290,10 @@ const char* dmn_test_unet_trace_name(const DmnUnet* u, int k);
  * 8 per workgroup; the second linear-attention kernel writes at workgroup offset 65536) to `dev`, device memory of
  * at least 2 * 65536 * 8 int64; NULL switches it off. */
 int dmn_test_set_conv_debug(long long* dev);
+/* One convolution launch on caller tensors. pro_stats_dev / epi_stats_dev: GroupNorm statistics as partial moments
+ * [B][G][slots][4] float32 = {sum, sum of squared deviations from the partial's own mean, element count, 0} per slot
+ * (what the kernels hand each other; a consumer combines the slots of a group without the cancellation of
+ * sum / sum-of-squares pairs). */
 int dmn_test_conv2d(int dtype, const void* in0, const void* in1, int C0, int C1, int B, int H, int W, const float* w_host,
                     const float* bias_host, int Cout, int kh, int kw, int stride, int pad, int transposed, void* out,
                     const void* res, const float* pro_gamma_host, const float* pro_beta_host, const float* pro_tbias_dev,

@@ -32,6 +32,25 @@ def from_dev_nhwc(t):
     return t.float().cpu().permute(0, 3, 1, 2).contiguous()
 
 
+def moments(g):
+    """Partial moments of the last axis in the kernels' slot format: {sum, squared deviations from the own mean, count, 0}."""
+    s = g.sum(-1)
+    n = torch.full_like(s, g.shape[-1])
+    m2 = ((g - (s / n).unsqueeze(-1)) ** 2).sum(-1)
+    return torch.stack([s, m2, n, torch.zeros_like(s)], -1).float()
+
+
+def combine_moments(slots):
+    """[..., slots, 4] partial moments -> [..., 3] = {sum, squared deviations from the mean of the union, count} (float64)."""
+    slots = slots.double()
+    s, m2, n = slots[..., 0], slots[..., 1], slots[..., 2]
+    S, N = s.sum(-1), n.sum(-1)
+    mean = (S / N).unsqueeze(-1)
+    own = torch.where(n > 0, s / n.clamp(min=1), mean.expand_as(s))   # a slot of a row outside the image counts nothing
+    M2 = (m2 + n * (own - mean) ** 2).sum(-1)
+    return torch.stack([S, M2, N], -1)
+
+
 def run_conv(dtype, x0, x1, w, b, stride, pad, transposed, res=None, pro=None, epi_G=0, tile=0, bn=0):
     N = _N()
     lib = N.lib()
@@ -60,7 +79,7 @@ def run_conv(dtype, x0, x1, w, b, stride, pad, transposed, res=None, pro=None, e
         pG, pslots, psilu = pro["G"], pro["slots"], pro["silu"]
     est = None
     if epi_G:
-        est = torch.full((B * epi_G * 1024 * 2,), float("nan"), device="cuda", dtype=torch.float32)
+        est = torch.full((B * epi_G * 1024 * 4,), float("nan"), device="cuda", dtype=torch.float32)
     slots = C.c_int(0)
     torch.cuda.synchronize()
     N.check(lib.dmn_test_conv2d(
@@ -73,7 +92,7 @@ def run_conv(dtype, x0, x1, w, b, stride, pad, transposed, res=None, pro=None, e
     torch.cuda.synchronize()
     stats = None
     if epi_G:
-        stats = est[: B * epi_G * slots.value * 2].cpu().reshape(B, epi_G, slots.value, 2).sum(2)
+        stats = combine_moments(est[: B * epi_G * slots.value * 4].cpu().reshape(B, epi_G, slots.value, 4))
     return from_dev_nhwc(out), stats
 
 
@@ -114,9 +133,11 @@ def test_conv3x3_tile_configs_and_ragged_edges(dtype, tile, bn, H, W):
     ref = F.conv2d(q(x, dtype), q(w, dtype), b, padding=1)
     got, stats = run_conv(dtype, x, None, w, b, 1, 1, False, epi_G=8, tile=tile, bn=bn)
     assert (got - ref).abs().max() <= tol(dtype, ref)
-    g = ref.reshape(B, 8, -1)
-    ref_stats = torch.stack([g.sum(-1), (g * g).sum(-1)], dim=-1)
-    assert (stats - ref_stats).abs().max() <= 2e-3 * max(1.0, float(ref_stats.abs().max())) * (1 if dtype == 0 else 10)
+    # groups are 8 consecutive channels: [B, 64, H, W] -> [B, 8, 8 * H * W]
+    ref_stats = combine_moments(moments(ref.reshape(B, 8, -1).double()).unsqueeze(2))
+    assert torch.equal(stats[..., 2], ref_stats[..., 2])                      # every element counted once
+    for k in (0, 1):
+        assert (stats[..., k] - ref_stats[..., k]).abs().max() <= 2e-3 * max(1.0, float(ref_stats[..., k].abs().max())) * (1 if dtype == 0 else 10)
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
@@ -173,8 +194,7 @@ def test_conv_with_groupnorm_prologue_and_residual(dtype, G, silu, use_tb):
     g = xq.reshape(B, G, -1)
     # two slots per group: the consumer must add them
     half = g.shape[-1] // 2
-    stats = torch.stack([torch.stack([g[..., :half].sum(-1), (g[..., :half] ** 2).sum(-1)], -1),
-                         torch.stack([g[..., half:].sum(-1), (g[..., half:] ** 2).sum(-1)], -1)], dim=2)
+    stats = torch.stack([moments(g[..., :half]), moments(g[..., half:])], dim=2)
     pro = dict(gamma=gamma, beta=beta, tbias=tb, stats=stats.contiguous(), G=G, slots=2, silu=silu)
     got, _ = run_conv(dtype, x, None, w, b, 1, 1, False, res=res, pro=pro)
     assert (got - ref).abs().max() <= tol(dtype, ref) * (1 if dtype == 0 else 2)
@@ -217,9 +237,9 @@ def test_fused_linear_attention_matches_oracle(dtype, n_side, cch):
     assert torch.allclose(F.group_norm(ref, 1), R.linear_attention({k: (q(v, dtype) if "weight" in k and v.ndim == 4 else v)
                                                                    for k, v in p.items()}, "a", xn), atol=1e-4)
     xd = to_dev_nhwc(x, dtype)
-    xs = torch.stack([xq.sum((1, 2, 3)), (xq * xq).sum((1, 2, 3))], 1).contiguous().cuda()
+    xs = moments(xq.reshape(B, -1)).contiguous().cuda()
     y = torch.zeros((B, n_side, n_side, cch), device="cuda", dtype=torch.bfloat16 if dtype == 1 else torch.float32)
-    ystats = torch.full((B * 1024 * 2,), float("nan"), device="cuda")
+    ystats = torch.full((B * 1024 * 4,), float("nan"), device="cuda")
     scratch = torch.zeros((B * 4 * ((n + 31) // 32) * 1088,), device="cuda")
     slices = C.c_int(0)
     wqkv = np.ascontiguousarray(p["a.to_qkv.weight"].reshape(384, cch).numpy())
@@ -232,13 +252,13 @@ def test_fused_linear_attention_matches_oracle(dtype, n_side, cch):
     torch.cuda.synchronize()
     got = from_dev_nhwc(y)
     assert (got - ref).abs().max() <= (5e-5 if dtype == 0 else 4e-2) * max(1.0, float(ref.abs().max()))
-    st = ystats[: B * slices.value * 2].reshape(B, slices.value, 2).sum(1).cpu()
-    gq = got.double()
-    want = torch.stack([gq.sum((1, 2, 3)), (gq * gq).sum((1, 2, 3))], 1)
+    st = combine_moments(ystats[: B * slices.value * 4].reshape(B, slices.value, 4).cpu())
+    want = combine_moments(moments(got.double().reshape(B, -1)).unsqueeze(1))
+    assert torch.equal(st[:, 2], want[:, 2])
     if dtype == 0:
-        assert torch.allclose(st.double(), want, rtol=1e-4, atol=1e-2)
+        assert torch.allclose(st, want, rtol=1e-4, atol=1e-2)
     else:   # statistics are taken from the fp32 values before rounding to bf16
-        assert torch.allclose(st.double(), want, rtol=3e-2, atol=1.0)
+        assert torch.allclose(st, want, rtol=3e-2, atol=1.0)
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
@@ -296,23 +316,24 @@ def test_training_attention_core_forward_and_backward_match_autograd(n, adt, bf1
         assert err <= tol * scale, (name, n, adt, bf16, err, scale)
 
 
-def _block_tail(dtype, B, H, W, C_, G, out_G, fused, plan_B=64, tile=0, bn=0, seed=3):
+def _block_tail(dtype, B, H, W, C_, G, out_G, fused, plan_B=64, tile=0, bn=0, seed=3, offset=0.0, want_ref=False):
     """block2.proj + closing SiLU(GroupNorm(h)) + res through the C-ABI hook; returns (out NCHW fp32, statistics of out
-    summed over the partial slots [B][out_G][2], give-ups of the hand-off)."""
+    combined over the partial slots [B][out_G][{sum, squared deviations, count}], give-ups of the hand-off)."""
     N = _N()
     lib = N.lib()
     tdt = torch.bfloat16 if dtype == 1 else torch.float32
-    x, res = rnd((B, C_, H, W), seed), rnd((B, C_, H, W), seed + 1)
+    # offset: the input of the block and the output of its convolution sit `offset` standard deviations off zero
+    x, res = rnd((B, C_, H, W), seed) + offset, rnd((B, C_, H, W), seed + 1)
     w = rnd((C_, C_, 3, 3), seed + 2, (1.0 / (9 * C_)) ** 0.5).numpy().astype(np.float32)
-    bias = rnd((C_,), seed + 3).numpy().astype(np.float32)
+    bias = (rnd((C_,), seed + 3) + offset).numpy().astype(np.float32)
     pg, pb = (1.0 + 0.1 * rnd((C_,), seed + 4)).numpy().astype(np.float32), (0.1 * rnd((C_,), seed + 5)).numpy().astype(np.float32)
     tg, tb = (1.0 + 0.1 * rnd((C_,), seed + 6)).numpy().astype(np.float32), (0.1 * rnd((C_,), seed + 7)).numpy().astype(np.float32)
     dx, dres = to_dev_nhwc(x, dtype), to_dev_nhwc(res, dtype)
     xs = dx.float().view(B, H * W, G, C_ // G)
-    pst = torch.stack([xs.sum((1, 3)), (xs * xs).sum((1, 3))], -1).view(B, G, 1, 2).contiguous()   # statistics of the input, one slot
+    pst = moments(xs.permute(0, 2, 1, 3).reshape(B, G, -1)).view(B, G, 1, 4).contiguous()   # statistics of the input, one slot
     out = torch.zeros((B, H, W, C_), device="cuda", dtype=tdt)
     h2 = torch.zeros_like(out)
-    ost = torch.zeros((B * out_G * 4096 * 2,), device="cuda")
+    ost = torch.zeros((B * out_G * 4096 * 4,), device="cuda")
     slots, give = C.c_int(0), C.c_uint(0)
     N.check(lib.dmn_test_conv_block_tail(
         dtype, dx.data_ptr(), C_, B, H, W, w.ctypes.data, bias.ctypes.data, C_, pg.ctypes.data, pb.ctypes.data, pst.data_ptr(), G, 1,
@@ -320,7 +341,33 @@ def _block_tail(dtype, B, H, W, C_, G, out_G, fused, plan_B=64, tile=0, bn=0, se
         fused, plan_B, tile, bn, C.byref(give), None))
     torch.cuda.synchronize()
     n = slots.value
-    return out, ost[:B * out_G * n * 2].view(B, out_G, n, 2).sum(2).cpu(), give.value
+    if want_ref:   # the same block in float64 on the CPU, from the inputs as the kernel sees them
+        xr, rr = from_dev_nhwc(dx).double(), from_dev_nhwc(dres).double()
+        wq = torch.from_numpy(w).to(tdt).double()
+        h = F.silu(F.group_norm(xr, G, torch.from_numpy(pg).double(), torch.from_numpy(pb).double(), eps=1e-5))
+        h2 = F.conv2d(h, wq, torch.from_numpy(bias).double(), padding=1)
+        ref = F.silu(F.group_norm(h2, G, torch.from_numpy(tg).double(), torch.from_numpy(tb).double(), eps=1e-5)) + rr
+        return out, ref
+    return out, combine_moments(ost[:B * out_G * n * 4].view(B, out_G, n, 4).cpu()), give.value
+
+
+@pytest.mark.parametrize("B,H,W,C_,fused", [
+    (3, 16, 16, 128, 1),    # partial moments exchanged inside the launch (8 workgroups per image)
+    (3, 16, 16, 128, 0),    # the same through the statistics buffer and the separate closing pass
+    (3, 32, 32, 64, 0),     # 16x16-pixel tiles
+    (3, 8, 8, 256, 1),      # one workgroup holds whole groups
+    (2, 64, 64, 32, 0),     # full resolution: 16 partials per group
+    (2, 24, 40, 64, 0),     # ragged tiles: partials of unequal counts
+])
+def test_block_tail_keeps_parity_when_group_means_dwarf_the_spread(B, H, W, C_, fused):
+    """GroupNorm statistics travel as partial moments (sum, squared deviations from the partial's own mean, count), so a
+    group whose mean lies 50 standard deviations off zero -- which a sum / sum-of-squares pair resolves to three digits --
+    is normalised as accurately as one centred on zero: the fp32 block against float64 at the same tolerance (2e-4 of the
+    output's scale) with and without the offset, through the prologue, both closing forms and the output statistics."""
+    for offset in (0.0, 50.0):
+        out, ref = _block_tail(0, B, H, W, C_, 8, 1, fused, offset=offset, want_ref=True)
+        err = float((from_dev_nhwc(out).double() - ref).abs().max())
+        assert err <= 2e-4 * max(1.0, float(ref.abs().max())), (offset, err)
 
 
 @pytest.mark.parametrize("dtype", [1, 0])
@@ -352,7 +399,10 @@ def test_block_tail_inside_the_convolution_equals_the_two_launch_form(dtype, B, 
     assert give == 0
     assert torch.equal(a, b), float((a.float() - b.float()).abs().max())
     assert float((sa - sb).abs().max()) <= 1e-5 * float(sb.abs().max())
-    want = torch.stack([a.float().sum((1, 2)).view(B, out_G, -1).sum(2), (a.float() ** 2).sum((1, 2)).view(B, out_G, -1).sum(2)], -1).cpu()
+    # out is [B, H, W, C]: group g holds channels g * C/out_G .. of every pixel
+    grouped = a.double().cpu().view(B, H * W, out_G, C_ // out_G).permute(0, 2, 1, 3).reshape(B, out_G, -1)
+    want = combine_moments(moments(grouped).unsqueeze(2))
+    assert torch.equal(sa[..., 2], want[..., 2])
     assert float((sa - want).abs().max()) <= 1e-4 * float(want.abs().max())
     for _ in range(5):
         again, _, give = _block_tail(dtype, B, H, W, C_, G, out_G, 1, tile=tile, bn=bn)
@@ -391,13 +441,13 @@ def test_linear_attention_closed_inside_its_second_launch_equals_the_separate_pa
     wqkv, wout, bout = arr(rnd((384, cch), 26, cch ** -0.5) * 2.0), arr(rnd((cch, 128), 27, 128 ** -0.5)), arr(0.1 * rnd((cch,), 28))
     xd = to_dev_nhwc(x, dtype)
     xq = xd.float()
-    xs = torch.stack([xq.sum((1, 2, 3)), (xq * xq).sum((1, 2, 3))], 1).contiguous()
+    xs = moments(xq.reshape(B, -1)).contiguous()
     scratch = torch.zeros((B * 4 * ((n + 31) // 32) * 1088,), device="cuda")
 
     def run(fused):
         y = torch.zeros_like(xd)
         out = torch.zeros_like(xd)
-        ystats = torch.zeros((B * 1024 * 2,), device="cuda")
+        ystats = torch.zeros((B * 1024 * 4,), device="cuda")
         give = C.c_uint(0)
         N.check(lib.dmn_test_linattn_block(dtype, xd.data_ptr(), xs.data_ptr(), B, n, cch, gamma.ctypes.data, beta.ctypes.data,
                                            wqkv.ctypes.data, wout.ctypes.data, bout.ctypes.data, og.ctypes.data, ob.ctypes.data,

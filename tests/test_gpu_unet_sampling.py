@@ -953,3 +953,26 @@ def test_exchange_areas_are_zeroed_before_the_epoch_can_wrap(monkeypatch):
         y = v(x, t)
     assert torch.equal(y, want_fwd)
     assert v.handoff_giveups() == 0
+
+
+@pytest.mark.parametrize("paths", [0, 128])
+def test_forward_keeps_parity_when_group_means_dwarf_the_spread(monkeypatch, paths):
+    """Every convolution that feeds a GroupNorm gets 30 added to its bias: the groups then sit 26 to 450 standard deviations
+    off zero (median 29, measured on the oracle), where E[x^2] - E[x]^2 in float32 keeps three digits or none (the fp32
+    handle was 1.9e-2 off the oracle with such statistics). With partial moments the forward holds the tolerance of the
+    centred case, 2e-4, with the in-launch exchanges and with every closing as its own pass (DMN_UNET_PATHS=128)."""
+    from diffusion_model_nemo_amd.modules import Unet
+    sd = make_state_dict(unet_param_shapes())
+    for k in sd:
+        if k.endswith(".proj.bias") or k.endswith("to_out.0.bias"):
+            sd[k] = (sd[k] + np.float32(30.0)).astype(np.float32)
+    x = T(philox.normal_like((2, 3, 64, 64), 5, 0, 7))
+    t = torch.tensor([17, 803])
+    with torch.no_grad():
+        ref = R.unet_forward(R.to_torch(sd), x, t)
+    if paths:
+        monkeypatch.setenv("DMN_UNET_PATHS", str(paths))
+    u = Unet(input_dim=64, dim=32, dim_mults=[1, 2, 4, 8], use_convnext=False, dropout=0.0, compute_dtype="fp32")
+    u.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    got = u.cuda().eval()(x.cuda(), t.cuda())
+    assert err(got, ref.numpy())[0] <= 2e-4, err(got, ref.numpy())

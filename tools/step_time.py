@@ -7,10 +7,6 @@ import torch
 
 sys.path.insert(0, ".")
 from diffusion_model_nemo_amd import _native as N  # noqa: E402
-import os as _os
-from diffusion_model_nemo_amd import _native as _N
-if _os.environ.get("DMN_LIB_VARIANT"):
-    _N.LIB_PATH = _N.LIB_PATH.replace("libdmn_hip.so", f"libdmn_hip_{_os.environ['DMN_LIB_VARIANT']}.so")
 from diffusion_model_nemo_amd.modules import GaussianDiffusion, LearnedGaussianDiffusion, Unet  # noqa: E402
 
 ap = argparse.ArgumentParser()
