@@ -210,9 +210,13 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
             if constexpr (PRO == 3) sr2[j] = *reinterpret_cast<const V*>(resp3 + off);
         }
     };
+    // the statistics and channel parameters of the normalising prologue are requested AHEAD of the halo tile: vector loads
+    // return in order, so the coefficient round trip (load, cross-lane combination, LDS, barrier) runs while the halo
+    // pixels are still on their way instead of behind them
+    NormLoads nl;
+    if (PRO) norm_issue(a.pro, b, Cin, nl);
     stage_issue(0, 0);
-
-    if (PRO) norm_coefs_to_lds(a.pro, b, Cin, sCoef, sTmp);
+    if (PRO) norm_finish(a.pro, b, Cin, nl, sCoef, sTmp);
     DMN_STAMP(1)
 
     f32x4 acc[MT][NT];
