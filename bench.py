@@ -30,6 +30,7 @@ GFLOP_PER_IMG_EVAL = 2.6634
 ALG_BYTES_PER_IMG_EVAL = 17.3e6
 WEIGHT_BYTES = 16.2e6
 HBM_PEAK_GBS = 8000.0
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense matrix peaks of the two compute types
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_dominant_kernel_traffic.json")
 
 
@@ -323,6 +324,22 @@ def main(argv=None):
         gdp.p_sample_loop(unet, shape, device=dev, seed=7, keep="last", return_device_tensor=True, use_graph=not a.no_graph)
         N.check(N.lib().dmn_unet_probe_result(h, C.byref(one_ms), C.byref(mark_ms), C.byref(one_n), C.byref(one_bytes)))
         unet.set_sample_chains(2)
+    # (a'') the matrix-bound kernel: the 256 -> 256 channel 3x3 convolution at 8x8 (the network runs several per
+    #       evaluation), clocked the same way where it runs; priced against the dense bf16 / f32 MFMA peak
+    mfma_sites = []
+    want_flops = 2.0 * (B // max(chains_default, 1)) * 8 * 8 * 256 * 256 * 9
+    if S == 64:
+        for site in range(10, 30):
+            N.check(N.lib().dmn_test_probe_site(h, site, None))
+            N.check(N.lib().dmn_unet_probe_dominant(h, 2))
+            gdp.p_sample_loop(unet, shape, device=dev, seed=7, keep="last", return_device_tensor=True, use_graph=not a.no_graph)
+            s_ms, s_n, s_fl = C.c_float(), C.c_int(), (C.c_double * 5)()
+            if N.lib().dmn_unet_probe_result(h, C.byref(s_ms), C.byref(mark_ms), C.byref(s_n), None) != 0:
+                continue   # no stamping launch at this number
+            N.check(N.lib().dmn_test_probe_site(h, site, s_fl))
+            if list(s_fl) == [want_flops, 256.0, 256.0, 8.0, 9.0]:
+                mfma_sites.append((site, s_ms.value * 1e3, s_n.value))
+        N.check(N.lib().dmn_test_probe_site(h, -1, None))
     # (b) HIP events around the launch inside an eager replay of the same steps (markers cannot be timed inside a graph)
     N.check(N.lib().dmn_unet_probe_dominant(h, 1))
     gdp.p_sample_loop(unet, shape, device=dev, seed=7, keep="last", return_device_tensor=True, use_graph=False)
@@ -399,6 +416,17 @@ def main(argv=None):
                      "frac_of_hbm_peak": alg_bytes / sec_per_eval / 1e9 / HBM_PEAK_GBS,
                      "tflops": B * GFLOP_PER_IMG_EVAL / sec_per_eval / 1e3},
         }
+        if mfma_sites:
+            peak_tf = MFMA_PEAK_TFLOPS[a.dtype]
+            us = sum(m[1] for m in mfma_sites) / len(mfma_sites)
+            res["roofline"]["mfma"] = {
+                "bound": "mfma", "kernel": f"conv_igemm_kernel<{a.dtype}, 3x3, 8x8 px, 32 cout> [{Bl},8,8,256] -> [{Bl},8,8,256] per launch",
+                "flops_per_launch": want_flops, "launch_us": us, "achieved": want_flops / (us * 1e-6) / 1e12, "peak": peak_tf,
+                "unit": "TFLOP/s", "frac": want_flops / (us * 1e-6) / 1e12 / peak_tf,
+                "launches_per_evaluation": len(mfma_sites),
+                "launch_us_by_site": {str(m[0]): round(m[1], 2) for m in mfma_sites},
+                "launch_us_measured": f"device clock stamps as above, {mfma_sites[0][2]} launches per site inside graph-replayed "
+                                      f"denoising steps with {chains} launch chain{'s' if chains > 1 else ''} in flight"}
         if peaks is not None:
             res["measured_peaks"] = peaks
             res["roofline"]["frac_of_measured_hbm_copy"] = res["roofline"]["achieved"] / peaks["hbm_copy_GBs"]

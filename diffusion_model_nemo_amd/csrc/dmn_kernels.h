@@ -201,6 +201,7 @@ struct LinAttnFusedArgs {
     int b_first, b_count;      // images of the second launch (set by the launcher)
     int merge_splits;          // > 0: the second launch merges that many split partials itself (set by the launcher)
     int separate_merge;        // 1: always merge in a launch of its own (diagnosis)
+    int separate_ctx;          // 1: always run the first pass as a launch of its own, also where one workgroup holds the image (diagnosis)
 };
 bool linattn_tail_fits(int n, int B, int C, int dtype);   // the closing GroupNorm fits the in-launch exchange's limits
 bool linattn_fused_supported(int C, int heads, int dim_head);

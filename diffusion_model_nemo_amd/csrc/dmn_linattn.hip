@@ -124,16 +124,190 @@ struct XStager {
 };
 
 // ------------------------------------------------------------------------------------------------------------
+// The context of one head over a pixel slice staged in LDS, held by one wave: K and V projections, the per-channel
+// maximum of k (sweep 1), then P = exp(k - max), Z = sum P and ctx += P^T V (sweep 2). Shared by the first pass and by
+// the single-launch form for images that one workgroup holds.
+// ------------------------------------------------------------------------------------------------------------
+template <typename T, int C>
+struct HeadContext {
+    static constexpr int KCH = ElemTraits<T>::kChunk;
+    static constexpr int SUB = Sub<T>::N;
+    static constexpr int KS = C / KCH;
+    static constexpr bool WREG = KS <= 4;          // projection weights of the head stay in registers
+    static constexpr int WR = WREG ? KS : 1;
+    using V = decltype(Vec16<T>::v);
+    const T *wk, *wv;                              // fragment order [ct 0..7][ks][lane][PER]; head h owns ct 2h, 2h+1
+    int h, lane;
+    Vec16<T> wkr[2][WR], wvr[2][WR];
+    float mx[2];
+    f32x4 ctx[2][2];                               // [d tile][e tile], rows d = 16 * dt + 4 * (lane >> 4) + r, column e = lane & 15
+    f32x4 zacc[2];                                 // Z[d] in the same lanes and registers as row d of the ctx tiles
+
+    // the requests that depend on nothing: issue before the pixels are staged
+    __device__ __forceinline__ void preload(const void* wk_, const void* wv_, int h_, int lane_) {
+        wk = static_cast<const T*>(wk_);
+        wv = static_cast<const T*>(wv_);
+        h = h_;
+        lane = lane_;
+        if constexpr (WREG) {
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    wkr[ct][ks].v = load_frag<T>(wk, (2 * h + ct) * KS + ks, lane);
+                    wvr[ct][ks].v = load_frag<T>(wv, (2 * h + ct) * KS + ks, lane);
+                }
+        }
+    }
+    __device__ __forceinline__ Vec16<T> kfrag(int ct, int ks) const {
+        if constexpr (WREG) return wkr[ct][ks];
+        Vec16<T> f;
+        f.v = load_frag<T>(wk, (2 * h + ct) * KS + ks, lane);
+        return f;
+    }
+    __device__ __forceinline__ Vec16<T> vfrag(int ct, int ks) const {
+        if constexpr (WREG) return wvr[ct][ks];
+        Vec16<T> f;
+        f.v = load_frag<T>(wv, (2 * h + ct) * KS + ks, lane);
+        return f;
+    }
+
+    // sX: `slice` rows (multiple of 32) of row_bytes, pixel p0 + row; rows beyond the image (n) hold zeros and are masked
+    __device__ __forceinline__ void run(const char* sX, int row_bytes, int slice, int p0, int n, long long* dbg) {
+        const int l15 = lane & 15, lq = lane >> 4;
+        const int npt = slice / 16;                  // pixel tiles in the slice (even)
+        // ---- sweep 1: per-channel maximum of k over the slice ------------------------------------------------
+        // A slice that lies wholly inside the image (every size the network produces) takes the unmasked bodies.
+        const bool full = p0 + slice <= n;
+        mx[0] = mx[1] = -INFINITY;
+        auto sweep1 = [&](auto masked_t) {
+            constexpr bool MASKED = decltype(masked_t)::value;
+#pragma unroll 2
+            for (int pp = 0; pp < npt; pp += 2) {
+                f32x4 kacc[2][2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) kacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const Vec16<T> k0 = kfrag(0, ks), k1 = kfrag(1, ks);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        Vec16<T> xf;
+                        xf.v = *reinterpret_cast<const V*>(sX + (size_t)((pp + i) * 16 + l15) * row_bytes + lq * 16 + ks * 64);
+                        mma_step(xf, k0, kacc[i][0]);     // D[px][cout]
+                        mma_step(xf, k1, kacc[i][1]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const bool valid = !MASKED || p0 + (pp + i) * 16 + lq * 4 + r < n;
+                            mx[ct] = valid ? fmaxf(mx[ct], kacc[i][ct][r]) : mx[ct];
+                        }
+            }
+        };
+        if (full) sweep1(std::false_type{});
+        else sweep1(std::true_type{});
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            mx[ct] = fmaxf(mx[ct], __shfl_xor(mx[ct], 16, 64));
+            mx[ct] = fmaxf(mx[ct], __shfl_xor(mx[ct], 32, 64));
+        }
+
+        LA_STAMP(dbg, 3)
+        // ---- sweep 2: P = exp(k - max), Z = sum P, ctx += P^T V ------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) ctx[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // The softmax denominators come from the matrix pipe too (P against a matrix of ones): row d of zacc holds Z[d]
+        // in the same lanes and registers as row d of the ctx tiles.
+        zacc[0] = zacc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        Vec16<T> ones;
+#pragma unroll
+        for (int e = 0; e < ElemTraits<T>::kPer16B; ++e) ones.set(e, 1.0f);
+        // exp(k - max) as exp2(k * log2(e) - max * log2(e)): one fused multiply-add ahead of the transcendental
+        constexpr float kLog2e = 1.4426950408889634f;
+        const float mxl[2] = {mx[0] * kLog2e, mx[1] * kLog2e};
+        auto sweep2 = [&](auto masked_t) {
+            constexpr bool MASKED = decltype(masked_t)::value;
+#pragma unroll 2
+            for (int pp = 0; pp < npt; pp += 2) {        // 32 pixels = one bf16 k-step (two f32 k-steps)
+                f32x4 kacc[2][2], vacc[2][2];             // [pixel tile of the pair][channel tile]
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) kacc[i][j] = vacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const Vec16<T> k0 = kfrag(0, ks), k1 = kfrag(1, ks), v0 = vfrag(0, ks), v1 = vfrag(1, ks);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        Vec16<T> xf;
+                        xf.v = *reinterpret_cast<const V*>(sX + (size_t)((pp + i) * 16 + l15) * row_bytes + lq * 16 + ks * 64);
+                        mma_step(xf, k0, kacc[i][0]);
+                        mma_step(xf, k1, kacc[i][1]);
+                        mma_step(xf, v0, vacc[i][0]);
+                        mma_step(xf, v1, vacc[i][1]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const bool valid = !MASKED || p0 + (pp + i) * 16 + lq * 4 + r < n;
+                            float e;
+                            if constexpr (sizeof(T) == 4) e = expf(kacc[i][ct][r] - mx[ct]);
+                            else e = __builtin_amdgcn_exp2f(__builtin_fmaf(kacc[i][ct][r], kLog2e, -mxl[ct]));
+                            kacc[i][ct][r] = valid ? e : 0.f;
+                        }
+#pragma unroll
+                for (int sub = 0; sub < SUB; ++sub)
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const Vec16<T> pa = acc_operand(kacc[0][dt], kacc[1][dt], sub, (T*)nullptr);   // A[d][k = px]
+                        mma_step(pa, ones, zacc[dt]);     // Z[d] = sum_px P[px][d], in every column of row d
+#pragma unroll
+                        for (int et = 0; et < 2; ++et) {
+                            const Vec16<T> vb = acc_operand(vacc[0][et], vacc[1][et], sub, (T*)nullptr);   // B[k = px][e]
+                            mma_step(pa, vb, ctx[dt][et]);
+                        }
+                    }
+            }
+        };
+        if (full) sweep2(std::false_type{});
+        else sweep2(std::true_type{});
+    }
+
+    // The slice was the whole image: normalise, scale by d^-1/2 and write ctx^T in operand order (row e, position pos
+    // holds ctx[d = perm32(pos)][e]); `row_elems` elements of T between the rows of `out` (this head's 32 rows).
+    __device__ __forceinline__ void write_transposed(T* out, int row_elems) const {
+        const int l15 = lane & 15, lq = lane >> 4;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int d = dt * 16 + lq * 4 + r;
+                const float inv = 0.17677669529663687f / zacc[dt][r];
+                const int pos = sizeof(T) == 4 ? d : ((d & 15) >> 2) * 8 + (d >> 4) * 4 + (d & 3);   // inverse of perm32
+#pragma unroll
+                for (int et = 0; et < 2; ++et) out[(et * 16 + l15) * row_elems + pos] = from_f32<T>(ctx[dt][et][r] * inv);
+            }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------------
 // pass 1: grid (splits, B); slice = a.slice1 pixels (multiple of 32); wave h owns head h
 // ------------------------------------------------------------------------------------------------------------
 template <typename T, int C>
 __global__ void __launch_bounds__(256) la_fused_ctx_kernel(const LinAttnFusedArgs a) {
-    constexpr int KCH = ElemTraits<T>::kChunk;
-    constexpr int SUB = Sub<T>::N;
-    constexpr int KS = C / KCH;
-    constexpr bool WREG = KS <= 4;                 // projection weights of the head stay in registers
-    constexpr int WR = WREG ? KS : 1;
-    using V = decltype(Vec16<T>::v);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int row_bytes = C * (int)sizeof(T) + 32;
     const int slice = a.slice1;
@@ -145,18 +319,8 @@ __global__ void __launch_bounds__(256) la_fused_ctx_kernel(const LinAttnFusedArg
     const int p0 = split * slice;
 
     LA_STAMP(a.dbg, 0)
-    const T* wk = static_cast<const T*>(a.wk);   // fragment order [ct 0..7][ks][lane][PER]; head h owns ct 2h, 2h+1
-    const T* wv = static_cast<const T*>(a.wv);
-    Vec16<T> wkr[2][WR], wvr[2][WR];
-    if constexpr (WREG) {
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                wkr[ct][ks].v = load_frag<T>(wk, (2 * h + ct) * KS + ks, lane);
-                wvr[ct][ks].v = load_frag<T>(wv, (2 * h + ct) * KS + ks, lane);
-            }
-    }
+    HeadContext<T, C> hc;
+    hc.preload(a.wk, a.wv, h, lane);
     XStager<T, C> st;
     st.begin(a.x, b, a.n, p0, slice);
     norm_coefs_to_lds(a.norm, b, C, sCoef, sCoef + 3 * C);
@@ -164,143 +328,9 @@ __global__ void __launch_bounds__(256) la_fused_ctx_kernel(const LinAttnFusedArg
     st.finish(sX, row_bytes, sCoef);
     __syncthreads();
     LA_STAMP(a.dbg, 2)
-
-    const int npt = slice / 16;                  // pixel tiles in the slice (even)
-    auto kfrag = [&](int ct, int ks) {
-        if constexpr (WREG) return wkr[ct][ks];
-        Vec16<T> f;
-        f.v = load_frag<T>(wk, (2 * h + ct) * KS + ks, lane);
-        return f;
-    };
-    auto vfrag = [&](int ct, int ks) {
-        if constexpr (WREG) return wvr[ct][ks];
-        Vec16<T> f;
-        f.v = load_frag<T>(wv, (2 * h + ct) * KS + ks, lane);
-        return f;
-    };
-
-    // ---- sweep 1: per-channel maximum of k over the slice ------------------------------------------------
-    // A slice that lies wholly inside the image (every size the network produces) takes the unmasked bodies.
-    const bool full = p0 + slice <= a.n;
-    float mx[2] = {-INFINITY, -INFINITY};
-    auto sweep1 = [&](auto masked_t) {
-        constexpr bool MASKED = decltype(masked_t)::value;
-#pragma unroll 2
-        for (int pp = 0; pp < npt; pp += 2) {
-            f32x4 kacc[2][2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) kacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const Vec16<T> k0 = kfrag(0, ks), k1 = kfrag(1, ks);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    Vec16<T> xf;
-                    xf.v = *reinterpret_cast<const V*>(sX + (size_t)((pp + i) * 16 + l15) * row_bytes + lq * 16 + ks * 64);
-                    mma_step(xf, k0, kacc[i][0]);     // D[px][cout]
-                    mma_step(xf, k1, kacc[i][1]);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const bool valid = !MASKED || p0 + (pp + i) * 16 + lq * 4 + r < a.n;
-                        mx[ct] = valid ? fmaxf(mx[ct], kacc[i][ct][r]) : mx[ct];
-                    }
-        }
-    };
-    if (full) sweep1(std::false_type{});
-    else sweep1(std::true_type{});
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-        mx[ct] = fmaxf(mx[ct], __shfl_xor(mx[ct], 16, 64));
-        mx[ct] = fmaxf(mx[ct], __shfl_xor(mx[ct], 32, 64));
-    }
-
-    LA_STAMP(a.dbg, 3)
-    // ---- sweep 2: P = exp(k - max), Z = sum P, ctx += P^T V ------------------------------------------------
-    f32x4 ctx[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) ctx[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // The softmax denominators come from the matrix pipe too (P against a matrix of ones): row d of zacc holds Z[d]
-    // in the same lanes and registers as row d of the ctx tiles.
-    f32x4 zacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    Vec16<T> ones;
-#pragma unroll
-    for (int e = 0; e < ElemTraits<T>::kPer16B; ++e) ones.set(e, 1.0f);
-    // exp(k - max) as exp2(k * log2(e) - max * log2(e)): one fused multiply-add ahead of the transcendental
-    constexpr float kLog2e = 1.4426950408889634f;
-    const float mxl[2] = {mx[0] * kLog2e, mx[1] * kLog2e};
-    auto sweep2 = [&](auto masked_t) {
-        constexpr bool MASKED = decltype(masked_t)::value;
-#pragma unroll 2
-        for (int pp = 0; pp < npt; pp += 2) {        // 32 pixels = one bf16 k-step (two f32 k-steps)
-            f32x4 kacc[2][2], vacc[2][2];             // [pixel tile of the pair][channel tile]
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) kacc[i][j] = vacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const Vec16<T> k0 = kfrag(0, ks), k1 = kfrag(1, ks), v0 = vfrag(0, ks), v1 = vfrag(1, ks);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    Vec16<T> xf;
-                    xf.v = *reinterpret_cast<const V*>(sX + (size_t)((pp + i) * 16 + l15) * row_bytes + lq * 16 + ks * 64);
-                    mma_step(xf, k0, kacc[i][0]);
-                    mma_step(xf, k1, kacc[i][1]);
-                    mma_step(xf, v0, vacc[i][0]);
-                    mma_step(xf, v1, vacc[i][1]);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const bool valid = !MASKED || p0 + (pp + i) * 16 + lq * 4 + r < a.n;
-                        float e;
-                        if constexpr (sizeof(T) == 4) e = expf(kacc[i][ct][r] - mx[ct]);
-                        else e = __builtin_amdgcn_exp2f(__builtin_fmaf(kacc[i][ct][r], kLog2e, -mxl[ct]));
-                        kacc[i][ct][r] = valid ? e : 0.f;
-                    }
-#pragma unroll
-            for (int sub = 0; sub < SUB; ++sub)
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const Vec16<T> pa = acc_operand(kacc[0][dt], kacc[1][dt], sub, (T*)nullptr);   // A[d][k = px]
-                    mma_step(pa, ones, zacc[dt]);     // Z[d] = sum_px P[px][d], in every column of row d
-#pragma unroll
-                    for (int et = 0; et < 2; ++et) {
-                        const Vec16<T> vb = acc_operand(vacc[0][et], vacc[1][et], sub, (T*)nullptr);   // B[k = px][e]
-                        mma_step(pa, vb, ctx[dt][et]);
-                    }
-                }
-        }
-    };
-    if (full) sweep2(std::false_type{});
-    else sweep2(std::true_type{});
+    hc.run(sX, row_bytes, slice, p0, a.n, a.dbg);
     if (a.splits == 1) {
-        // the slice is the whole image: normalise, scale and transpose here
-        T* out = static_cast<T*>(a.ctxT) + ((size_t)b * kHeads + h) * kD * kD;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int d = dt * 16 + lq * 4 + r;
-                const float inv = 0.17677669529663687f / zacc[dt][r];
-                const int pos = sizeof(T) == 4 ? d : ((d & 15) >> 2) * 8 + (d >> 4) * 4 + (d & 3);   // inverse of perm32
-#pragma unroll
-                for (int et = 0; et < 2; ++et) out[(et * 16 + l15) * kD + pos] = from_f32<T>(ctx[dt][et][r] * inv);
-            }
+        hc.write_transposed(static_cast<T*>(a.ctxT) + ((size_t)b * kHeads + h) * kD * kD, kD);
     } else {
         float* dst = a.ctx_part + (((size_t)b * kHeads + h) * a.splits + split) * kPartStride;
 #pragma unroll
@@ -308,16 +338,16 @@ __global__ void __launch_bounds__(256) la_fused_ctx_kernel(const LinAttnFusedArg
 #pragma unroll
             for (int et = 0; et < 2; ++et)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dst[(dt * 16 + lq * 4 + r) * kD + et * 16 + l15] = ctx[dt][et][r];
+                for (int r = 0; r < 4; ++r) dst[(dt * 16 + lq * 4 + r) * kD + et * 16 + l15] = hc.ctx[dt][et][r];
         if (lq == 0) {
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct) dst[kD * kD + ct * 16 + l15] = mx[ct];
+            for (int ct = 0; ct < 2; ++ct) dst[kD * kD + ct * 16 + l15] = hc.mx[ct];
         }
         if (l15 == 0) {
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dst[kD * kD + kD + dt * 16 + lq * 4 + r] = zacc[dt][r];
+                for (int r = 0; r < 4; ++r) dst[kD * kD + kD + dt * 16 + lq * 4 + r] = hc.zacc[dt][r];
         }
     }
     LA_STAMP(a.dbg, 4)
@@ -374,7 +404,10 @@ __global__ void __launch_bounds__(256) la_merge_kernel(const LinAttnFusedArgs a)
 // TAIL: the launch also closes the attention -- out = GroupNorm(1)(y) + x (parts/mha.py:41-42, utils.py:73-74). y stays
 //   in the workgroup's LDS (in the rows of the staged pixels it was computed from) while the image's workgroups exchange
 //   their partial sums inside the launch (dmn_handoff.h); neither y nor a closing pass over it exists.
-template <typename T, int C, bool TAIL>
+// ONE: the workgroup's slice is the whole image (grid (1, B)) and no first pass ran: after staging, wave h computes the
+//   context of head h itself (HeadContext, the arithmetic of the first pass) and leaves ctx^T in LDS where the merged
+//   context would have been copied to. The pixels are staged once and the whole attention is one launch.
+template <typename T, int C, bool TAIL, bool ONE>
 __global__ void __launch_bounds__(256) la_fused_out_kernel(const LinAttnFusedArgs a) {
     constexpr int PER = ElemTraits<T>::kPer16B;
     constexpr int KCH = ElemTraits<T>::kChunk;
@@ -417,22 +450,27 @@ __global__ void __launch_bounds__(256) la_fused_out_kernel(const LinAttnFusedArg
     const int yt0 = YT >= 4 ? wave : wave % YT;    // this wave's tiles: yt0 + 4*i
     const int ptb = YT >= 4 ? 0 : (wave / YT) * PTW;
     Vec16<T> wor[YPW][KO];
-#pragma unroll
-    for (int i = 0; i < YPW; ++i)
-#pragma unroll
-        for (int ko = 0; ko < KO; ++ko) wor[i][ko].v = load_frag<T>(wo, (yt0 + 4 * i) * KO + ko, lane);
     f32x4 bias[YPW];
+    auto load_out_weights = [&]() {
 #pragma unroll
-    for (int i = 0; i < YPW; ++i) bias[i] = *reinterpret_cast<const f32x4*>(a.bias + (yt0 + 4 * i) * 16 + lq * 4);
+        for (int i = 0; i < YPW; ++i)
+#pragma unroll
+            for (int ko = 0; ko < KO; ++ko) wor[i][ko].v = load_frag<T>(wo, (yt0 + 4 * i) * KO + ko, lane);
+#pragma unroll
+        for (int i = 0; i < YPW; ++i) bias[i] = *reinterpret_cast<const f32x4*>(a.bias + (yt0 + 4 * i) * 16 + lq * 4);
+    };
+    HeadContext<T, C> hc;                          // ONE only
+    if constexpr (ONE) hc.preload(a.wk, a.wv, wave, lane);   // to_out's weights are requested after the context: fewer live registers
+    else load_out_weights();
     constexpr int CU = kHeads * kD * kD / PER / 256;   // 16-byte units of ctx^T per thread
     V cr[CU];
     // merge_splits > 0: the first pass left that many split partials per image and no merge launch ran; this workgroup
     // merges them itself (the arithmetic of la_merge_kernel, every workgroup of the image redundantly; worth it for a few
     // splits, where the partials of an image are a few tens of KB from the L2)
-    const int S = a.merge_splits;
+    const int S = ONE ? 0 : a.merge_splits;
     const float* part_b = a.ctx_part + (size_t)b * kHeads * (S > 0 ? S : 1) * kPartStride;
     float* sFac = reinterpret_cast<float*>(sO);    // [128][S] (sO is first written in phase A)
-    if (S == 0) {
+    if (!ONE && S == 0) {
         const T* cT = static_cast<const T*>(a.ctxT) + (size_t)b * kHeads * kD * kD;
 #pragma unroll
         for (int j = 0; j < CU; ++j) cr[j] = *reinterpret_cast<const V*>(cT + (size_t)(tid + 256 * j) * PER);
@@ -456,7 +494,12 @@ __global__ void __launch_bounds__(256) la_fused_out_kernel(const LinAttnFusedArg
     norm_coefs_to_lds(a.norm, b, C, sCoef, sCoef + 3 * C);   // its barriers also publish sFac
     LA_STAMP(dbg2, 1)
     st.finish(sX, row_bytes, sCoef);
-    if (S == 0) {
+    if constexpr (ONE) {
+        __syncthreads();
+        hc.run(sX, row_bytes, slice, 0, a.n, nullptr);
+        load_out_weights();
+        hc.write_transposed(reinterpret_cast<T*>(sCtx + (size_t)wave * kD * CTX_ROW), CTX_ROW / (int)sizeof(T));
+    } else if (S == 0) {
 #pragma unroll
         for (int j = 0; j < CU; ++j) {
             const int u = tid + 256 * j;               // unit -> row (h*32 + e), 16-byte column
@@ -751,11 +794,26 @@ int launch_pair(const LinAttnFusedArgs& a, hipStream_t s) {
     if (!attr) {
         DMN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&la_fused_ctx_kernel<T, C>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        DMN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&la_fused_out_kernel<T, C, false>),
+        DMN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&la_fused_out_kernel<T, C, false, false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        DMN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&la_fused_out_kernel<T, C, true>),
+        DMN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&la_fused_out_kernel<T, C, true, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DMN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&la_fused_out_kernel<T, C, false, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DMN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&la_fused_out_kernel<T, C, true, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
+    }
+    // an image that one workgroup holds in both passes: one launch for the whole attention
+    if (a.splits == 1 && a.slices == 1 && !a.separate_ctx) {
+        LinAttnFusedArgs c = a;
+        c.merge_splits = 0;
+        c.b_first = 0;
+        c.b_count = a.B;
+        if (a.tail.gran) hipLaunchKernelGGL((la_fused_out_kernel<T, C, true, true>), dim3(1, a.B), dim3(256), lds2, s, c);
+        else hipLaunchKernelGGL((la_fused_out_kernel<T, C, false, true>), dim3(1, a.B), dim3(256), lds2, s, c);
+        DMN_HIP_CHECK(hipGetLastError());
+        return DMN_OK;
     }
     hipLaunchKernelGGL((la_fused_ctx_kernel<T, C>), dim3(a.splits, a.B), dim3(256), lds1, s, a);
     DMN_HIP_CHECK(hipGetLastError());
@@ -776,8 +834,8 @@ int launch_pair(const LinAttnFusedArgs& a, hipStream_t s) {
     for (int b0 = 0; b0 < a.B; b0 += per_launch) {
         c.b_first = b0;
         c.b_count = a.B - b0 < per_launch ? a.B - b0 : per_launch;
-        if (a.tail.gran) hipLaunchKernelGGL((la_fused_out_kernel<T, C, true>), dim3(a.slices, c.b_count), dim3(256), lds2, s, c);
-        else hipLaunchKernelGGL((la_fused_out_kernel<T, C, false>), dim3(a.slices, c.b_count), dim3(256), lds2, s, c);
+        if (a.tail.gran) hipLaunchKernelGGL((la_fused_out_kernel<T, C, true, false>), dim3(a.slices, c.b_count), dim3(256), lds2, s, c);
+        else hipLaunchKernelGGL((la_fused_out_kernel<T, C, false, false>), dim3(a.slices, c.b_count), dim3(256), lds2, s, c);
         DMN_HIP_CHECK(hipGetLastError());
     }
     return DMN_OK;

@@ -363,8 +363,9 @@ static Act do_conv(Fwd& f, const PackedConv& pc, const Act& in0, const Act* in1,
     if (f.ok() && !f.dry) {
         // measurement hook: events around the dominant launch as it runs inside the step (block2.proj of downs.0.0)
         DmnUnet* u = f.u;
-        if (long long* st = f.site_stamps()) a.dbg = st;
-        const bool target = u->probe_on && u->probe_site < 0 && &pc == &u->downs[0].rb[0].c2;
+        long long* const site = f.site_stamps();   // non-null: this launch is the one a probe site selects
+        if (site) a.dbg = site;
+        const bool target = u->probe_on && (u->probe_site < 0 ? &pc == &u->downs[0].rb[0].c2 : site != nullptr);
         bool probe = target && u->probe_on == 1 && u->probe_n < kProbePairs;
         if (probe) {   // never inside a stream capture: a captured event record carries no time
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -389,8 +390,14 @@ static Act do_conv(Fwd& f, const PackedConv& pc, const Act& in0, const Act* in1,
             if (wgs > kProbeMaxWgs) wgs = kProbeMaxWgs;
             f.run(launch_stamp_span(stamps, wgs, u->probe_acc + 2 * u->chain_id, f.s), "probe: span of the stamps");
         }
-        if (probe || clocked)
+        if (probe || clocked) {
             u->probe_bytes = (double)f.B * in0.H * in0.W * (pc.Cin + pc.Cout) * f.esz() + (double)pc.Cin * pc.Cout * pc.ntaps * f.esz();
+            u->probe_shape[0] = 2.0 * f.B * a.out_H * a.out_W * pc.Cin * pc.Cout * pc.ntaps;
+            u->probe_shape[1] = pc.Cin;
+            u->probe_shape[2] = pc.Cout;
+            u->probe_shape[3] = a.out_H;
+            u->probe_shape[4] = pc.ntaps;
+        }
         if (probe) {
             (void)hipEventRecord(u->probe_ev[3 * u->probe_n + 2], f.s);
             ++u->probe_n;
@@ -603,6 +610,7 @@ static Act lin_attn(Fwd& f, const AttnW& w, Act& x, LazyAttn* defer = nullptr) {
         fa.C = x.C;
         linattn_fused_plan(fa.n, f.planB(), fa.C, c.dtype, &fa.slice1, &fa.splits, &fa.tpw, &fa.slices);
         fa.separate_merge = (f.u->path_mask & 1024) != 0;
+        fa.separate_ctx = (f.u->path_mask & 512) != 0;
         if (!defer && f.ho_enabled && !(f.u->path_mask & 256) && linattn_tail_fits(fa.n, f.planB(), fa.C, c.dtype)) {
             // the second launch closes the attention itself (GroupNorm(1)(y) + x, partial sums exchanged inside the launch)
             unsigned long long* gran = f.handoff_take((size_t)f.B * 4 * fa.slices * kHandoffGranulesPerSlot * sizeof(unsigned long long));   // a partial per wave
@@ -985,9 +993,11 @@ static int pack_fragments(int dtype, const float* W, int rows, int K, bool acc_o
 static int test_linattn_impl(int dtype, const void* x, const float* x_stats, int B, int n, int C, const float* gamma_host,
                              const float* beta_host, const float* wqkv_host, const float* wout_host, const float* bout_host,
                              void* y, float* y_stats, int* slices_out, void* scratch, size_t scratch_bytes, int closing,
-                             const float* og_host, const float* ob_host, void* out, unsigned* giveups, int plan_B, hipStream_t stream) {
+                             const float* og_host, const float* ob_host, void* out, unsigned* giveups, int plan_B, hipStream_t stream,
+                             int separate_ctx = 0) {
     LinAttnFusedArgs fa;
     memset(&fa, 0, sizeof(fa));
+    fa.separate_ctx = separate_ctx;
     void *fq = nullptr, *fk = nullptr, *fv = nullptr, *fo = nullptr, *ctxT = nullptr, *area = nullptr;
     float *g = nullptr, *bt = nullptr, *bo = nullptr, *og = nullptr, *ob = nullptr;
     auto cleanup = [&]() {
@@ -1085,7 +1095,8 @@ extern "C" int dmn_test_linattn(int dtype, const void* x, const float* x_stats, 
 }
 
 // The whole Residual(PreNorm(LinearAttention)) block (utils.py:68-93, parts/mha.py:44-59): out = GroupNorm(1)(y) + x behind
-// the fused attention, fused = 1 inside its second launch, fused = 0 as a separate closing pass over y (same bits).
+// the fused attention, fused = 1 inside its second launch, fused = 0 as a separate closing pass over y (same bits);
+// + 2: the first pass always as a launch of its own, also where one workgroup holds an image and one launch would do.
 extern "C" int dmn_test_linattn_block(int dtype, const void* x, const float* x_stats, int B, int n, int C, const float* gamma_host,
                                       const float* beta_host, const float* wqkv_host, const float* wout_host,
                                       const float* bout_host, const float* out_gamma_host, const float* out_beta_host, void* y,
@@ -1095,7 +1106,8 @@ extern "C" int dmn_test_linattn_block(int dtype, const void* x, const float* x_s
                 "dmn_test_linattn_block: null argument");
     DMN_REQUIRE(linattn_fused_supported(C, 4, 32), DMN_ERR_INVALID, "dmn_test_linattn_block: C=%d unsupported", C);
     return test_linattn_impl(dtype, x, x_stats, B, n, C, gamma_host, beta_host, wqkv_host, wout_host, bout_host, y, y_stats, nullptr,
-                             scratch, scratch_bytes, fused ? 1 : 2, out_gamma_host, out_beta_host, out, giveups, plan_B, (hipStream_t)stream);
+                             scratch, scratch_bytes, (fused & 1) ? 1 : 2, out_gamma_host, out_beta_host, out, giveups, plan_B,
+                             (hipStream_t)stream, (fused & 2) != 0);
 }
 
 // Times the kernel that dominates a denoising step -- the level-0 3x3 convolution with the fused GroupNorm +
@@ -1639,6 +1651,23 @@ extern "C" int dmn_test_probe_read(DmnUnet* u, int chain, long long* host, int n
     DMN_HIP_CHECK(hipDeviceSynchronize());
     DMN_HIP_CHECK(hipMemcpy(host, u->probe_stamps + (size_t)chain * kProbeMaxWgs * 8, (size_t)nwgs * 8 * sizeof(long long),
                             hipMemcpyDeviceToHost));
+    return DMN_OK;
+}
+
+// Tuning / measurement aid: choose the convolution launch (its number among an evaluation's convolution launches, -1 =
+// the dominant level-0 one) that dmn_unet_probe_dominant(u, 2) clocks, and read what the launch clocked last was:
+// shape[5] = {multiply-add work 2 * images * output pixels * Cin * Cout * taps, Cin, Cout, output height, taps}.
+// Captured steps are dropped: they hold the old choice.
+extern "C" int dmn_test_probe_site(DmnUnet* u, int site, double* shape) {
+    DMN_REQUIRE(u, DMN_ERR_INVALID, "dmn_test_probe_site: null handle");
+    if (shape)
+        for (int i = 0; i < 5; ++i) shape[i] = u->probe_shape[i];
+    if (site == u->probe_site) return DMN_OK;
+    DMN_HIP_CHECK(hipDeviceSynchronize());
+    if (u->graph_exec) (void)hipGraphExecDestroy(u->graph_exec);
+    if (u->graph_exec2) (void)hipGraphExecDestroy(u->graph_exec2);
+    u->graph_exec = u->graph_exec2 = nullptr;
+    u->probe_site = site;
     return DMN_OK;
 }
 

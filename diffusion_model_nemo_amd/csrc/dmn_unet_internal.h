@@ -111,6 +111,7 @@ struct DmnUnet {
     long long* probe_stamps = nullptr;   // [2 chains][kProbeMaxWgs][8] per-workgroup stamps of the probed launch
     unsigned long long* probe_acc = nullptr;   // per chain {sum of spans in 10 ns ticks, launches}
     double probe_bytes = 0.0;            // algorithmic bytes of one probed launch
+    double probe_shape[5] = {0, 0, 0, 0, 0};   // its multiply-add work (2 * images * output pixels * Cin * Cout * taps), Cin, Cout, output height, taps
     // Granule areas of the in-launch statistics hand-off (dmn_handoff.h), one per launch chain, owned by the handle:
     // [256 B header: epoch, give-ups][granules of every fused launch of an evaluation, in launch order]. Sized by
     // dmn_unet_workspace_bytes for the largest shape asked about; an evaluation whose fused launches do not fit

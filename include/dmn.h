@@ -89,6 +89,10 @@ int dmn_unet_handoff_giveups(DmnUnet* u, unsigned* count);
  * environment variable DMN_PROBE_SITE (its number among an evaluation's convolution launches), taken inside the sampling
  * loops while dmn_unet_probe_dominant(u, 2) is on. host: [nwgs][8] 64-bit words. */
 int dmn_test_probe_read(DmnUnet* u, int chain, long long* host, int nwgs);
+/* Measurement aid, no counterpart in the reference: choose that launch at run time (site = -1: the dominant level-0
+ * convolution again); dmn_unet_probe_dominant(u, 2) / dmn_unet_probe_result then clock it. shape (optional, 5 doubles)
+ * receives what the launch clocked last was: {2 * images * output pixels * Cin * Cout * taps, Cin, Cout, output height, taps}. */
+int dmn_test_probe_site(DmnUnet* u, int site, double* shape);
 
 /* eps = Unet(x, t).  t: [B] int64 (t_is_float = 0) or float32 (1), device memory. out: [B][out_dim][H][W]. */
 int dmn_unet_forward(DmnUnet* u, const float* x, const void* t, int t_is_float, float* out, int B, int H, int W,
@@ -264,7 +268,8 @@ int dmn_test_linattn(int dtype, const void* x, const float* x_stats, int B, int 
                      void* y, float* y_stats, int* slices_out, void* scratch, size_t scratch_bytes, void* stream);
 /* The whole Residual(PreNorm(LinearAttention)) block (utils.py:68-93, parts/mha.py:44-59): out = GroupNorm(1)(y) + x
  * behind the fused attention; fused = 1 inside the attention's second launch (partial sums exchanged within it),
- * fused = 0 as a separate pass over y. Both forms give the same bits in `out`. plan_B: batch the pixel slices are
+ * fused = 0 as a separate pass over y; + 2: the context pass always as a launch of its own (an image that one
+ * workgroup holds is otherwise one launch for the whole attention). All forms give the same bits in `out`. plan_B: batch the pixel slices are
  * planned for (0: B). Shapes outside the exchange's limits (more than 8 slices per image) return an error for fused = 1. */
 int dmn_test_linattn_block(int dtype, const void* x, const float* x_stats, int B, int n, int C, const float* gamma_host,
                            const float* beta_host, const float* wqkv_host, const float* wout_host, const float* bout_host,

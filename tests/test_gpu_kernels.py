@@ -424,7 +424,10 @@ def test_block_tail_with_too_many_workgroups_per_image_is_refused():
     (6, 32, 32, 64),     # 8 pixel slices per image exchange their sums (the maximum)
     (40, 32, 32, 32),    # more images than one launch of 256 workgroups takes: two launches
     (7, 16, 16, 128),
-    (9, 8, 8, 256),      # one workgroup per image: no exchange
+    (9, 8, 8, 256),      # one workgroup per image: no exchange, the whole attention in one launch
+    (5, 8, 8, 128),
+    (4, 7, 7, 64),       # one workgroup per image, ragged (49 of 64 staged rows)
+    (4, 4, 4, 32),
     (3, 24, 40, 64),     # last slice ragged
 ])
 def test_linear_attention_closed_inside_its_second_launch_equals_the_separate_pass(dtype, B, side_h, side_w, cch):
@@ -465,5 +468,7 @@ def test_linear_attention_closed_inside_its_second_launch_equals_the_separate_pa
     b = run(0)
     assert torch.isfinite(a.float()).all() and float(a.float().abs().max()) > 0.5
     assert torch.equal(a, b), float((a.float() - b.float()).abs().max())
+    # where one workgroup holds an image the whole attention is one launch: same bits as context pass + second launch
+    assert torch.equal(run(3), a) and torch.equal(run(2), a)
     for _ in range(5):
         assert torch.equal(run(1), a)
