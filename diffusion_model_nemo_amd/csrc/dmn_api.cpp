@@ -94,6 +94,14 @@ struct LoopBufs {
 
 static size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
+// Langevin scratch of one launch chain of B images inside a sampling workspace: 256 bytes (the chain's step size), then
+// either the plain partials of its images or -- in the first chain's region, when the batch runs as two chains -- the
+// granules of BOTH chains' images, [2 buffers][2 B][slots][2] of 8 bytes (LangevinArgs::gran).
+static size_t loop_granule_bytes(int B_all, int C, int H, int W) {
+    return (size_t)2 * B_all * langevin_slots(C * H * W) * 2 * sizeof(unsigned long long);
+}
+static size_t loop_partials_bytes(int B, int C, int H, int W) { return 256 + loop_granule_bytes(2 * B, C, H, W); }
+
 static int carve(DmnUnet* u, int B, int H, int W, void* ws, size_t ws_bytes, LoopBufs& lb, size_t* need) {
     const size_t img = (size_t)B * u->cfg.channels * H * W * 4;
     const size_t net = (size_t)B * u->cfg.out_dim * H * W * 4;
@@ -106,7 +114,7 @@ static int carve(DmnUnet* u, int B, int H, int W, void* ws, size_t ws_bytes, Loo
     const size_t o_mean = off;
     off += align256(img);
     const size_t o_part = off;
-    off += align256(dmn_sde_scratch_bytes(B, u->cfg.channels, H, W));
+    off += align256(loop_partials_bytes(B, u->cfg.channels, H, W));
     const size_t o_arena = off;
     off += unet_bytes;
     if (need) *need = off;
@@ -151,17 +159,86 @@ extern "C" int dmn_sample_workspace_bytes(DmnUnet* u, int B, int H, int W, size_
 }
 
 // Runs `body(chain, stream)` nsteps times per chain; when allowed, captures one step per chain into a graph (cached on
-// the handle) and replays it. Two chains run on the caller's stream and on a stream of the handle, forked and joined
-// with events, the second chain `sample_skew_us` behind the first.
+// the handle) and replays it. Two chains run on the handle's pair of chain streams, forked from and joined to the
+// caller's stream with events, the second chain `sample_skew_us` behind the first.
 template <typename Body>
 static int run_loop_inner(DmnUnet* u, const SampleKey& key, int nsteps, hipStream_t s, int use_graph, int nchains, Body body);
 
-static int ensure_side_stream(DmnUnet* u) {
-    if (!u->side_stream) {
-        DMN_HIP_CHECK(hipStreamCreateWithFlags(&u->side_stream, hipStreamNonBlocking));
-        DMN_HIP_CHECK(hipEventCreateWithFlags(&u->ev_fork, hipEventDisableTiming));
-        DMN_HIP_CHECK(hipEventCreateWithFlags(&u->ev_join, hipEventDisableTiming));
+// The handle's pair of chain streams. HIP spreads the streams of a process over a few hardware queues, and two streams
+// on one queue run their kernels one behind the other: the chains would gain nothing, and chains that wait for each
+// other on the device (the Langevin corrector's meetings) would wait for nothing. So the pair is probed when it is made
+// (launch_probe_wait / launch_probe_set), the second stream is made again while the probe fails (the rejected ones are
+// kept until the search ends, or the next one would land on the same queue), and the outcome is kept in
+// chains_concurrent.
+static int ensure_chain_streams(DmnUnet* u) {
+    if (u->chain_stream[0]) return DMN_OK;
+    hipStream_t a = nullptr, b = nullptr;
+    std::vector<hipStream_t> rejected;
+    unsigned* d = nullptr;
+    bool ok = false;
+    int rc = DMN_OK;
+    auto fail = [&](int code) {
+        for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+        if (a) (void)hipStreamDestroy(a);
+        if (b) (void)hipStreamDestroy(b);
+        if (d) (void)hipFree(d);
+        return code;
+    };
+    if (hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess || hipMalloc(&d, 2 * sizeof(unsigned)) != hipSuccess) {
+        dmn_set_error("sampling loop: cannot create the chain streams");
+        return fail(DMN_ERR_HIP);
     }
+    for (int attempt = 0; attempt < 8 && !ok; ++attempt) {
+        hipStream_t c = nullptr;
+        unsigned seen = 0;
+        if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess || hipMemset(d, 0, 2 * sizeof(unsigned)) != hipSuccess ||
+            hipDeviceSynchronize() != hipSuccess) {
+            if (c) rejected.push_back(c);
+            dmn_set_error("sampling loop: cannot create the chain streams");
+            return fail(DMN_ERR_HIP);
+        }
+        if ((rc = launch_probe_wait(d, d + 1, 20000, a)) || (rc = launch_probe_set(d, c))) {
+            rejected.push_back(c);
+            return fail(rc);
+        }
+        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(c) != hipSuccess ||
+            hipMemcpy(&seen, d + 1, sizeof(seen), hipMemcpyDeviceToHost) != hipSuccess) {
+            rejected.push_back(c);
+            dmn_set_error("sampling loop: probe of the chain streams failed");
+            return fail(DMN_ERR_HIP);
+        }
+        if (seen) {
+            b = c;
+            ok = true;
+        } else {
+            rejected.push_back(c);
+        }
+    }
+    if (!ok) {   // no pair runs side by side (one hardware queue?): two chains still give the right bits, one behind the other
+        b = rejected.back();
+        rejected.pop_back();
+    }
+    for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+    rejected.clear();
+    (void)hipFree(d);
+    d = nullptr;
+    if (hipEventCreateWithFlags(&u->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&u->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&u->ev_join0, hipEventDisableTiming) != hipSuccess) {
+        dmn_set_error("sampling loop: cannot create the fork / join events");
+        return fail(DMN_ERR_HIP);
+    }
+    u->chain_stream[0] = a;
+    u->chain_stream[1] = b;
+    u->chains_concurrent = ok;
+    return DMN_OK;
+}
+
+extern "C" int dmn_unet_chains_concurrent(DmnUnet* u, int* concurrent) {
+    DMN_REQUIRE(u && concurrent, DMN_ERR_INVALID, "dmn_unet_chains_concurrent: null argument");
+    int rc = ensure_chain_streams(u);
+    if (rc) return rc;
+    *concurrent = u->chains_concurrent ? 1 : 0;
     return DMN_OK;
 }
 
@@ -200,8 +277,9 @@ static int run_loop_inner(DmnUnet* u, const SampleKey& key, int nsteps, hipStrea
     int rc;
     hipStream_t cs[2] = {s, s};
     if (nchains == 2) {
-        if ((rc = ensure_side_stream(u))) return rc;
-        cs[1] = u->side_stream;
+        if ((rc = ensure_chain_streams(u))) return rc;
+        cs[0] = u->chain_stream[0];
+        cs[1] = u->chain_stream[1];
     }
     const bool graph = use_graph && s != nullptr;
     if (graph && !(u->graph_exec && u->graph_key == key)) {
@@ -226,18 +304,21 @@ static int run_loop_inner(DmnUnet* u, const SampleKey& key, int nsteps, hipStrea
         }
         u->graph_key = key;
     }
-    if (nchains == 2) {   // the side stream starts behind everything queued on the caller's stream so far
+    if (nchains == 2) {   // the chain streams start behind everything queued on the caller's stream so far
         DMN_HIP_CHECK(hipEventRecord(u->ev_fork, s));
-        DMN_HIP_CHECK(hipStreamWaitEvent(u->side_stream, u->ev_fork, 0));
-        if (u->sample_skew_us > 0 && (rc = launch_delay(u->sample_skew_us, u->side_stream))) return rc;
+        DMN_HIP_CHECK(hipStreamWaitEvent(cs[0], u->ev_fork, 0));
+        DMN_HIP_CHECK(hipStreamWaitEvent(cs[1], u->ev_fork, 0));
+        if (u->sample_skew_us > 0 && (rc = launch_delay(u->sample_skew_us, cs[1]))) return rc;
     }
     for (int i = 0; i < nsteps; ++i)
         for (int c = 0; c < nchains; ++c) {
             if (graph) DMN_HIP_CHECK(hipGraphLaunch(c ? u->graph_exec2 : u->graph_exec, cs[c]));
             else if ((rc = body(c, cs[c]))) return rc;
         }
-    if (nchains == 2) {
-        DMN_HIP_CHECK(hipEventRecord(u->ev_join, u->side_stream));
+    if (nchains == 2) {   // and the caller's stream goes on behind both
+        DMN_HIP_CHECK(hipEventRecord(u->ev_join0, cs[0]));
+        DMN_HIP_CHECK(hipStreamWaitEvent(s, u->ev_join0, 0));
+        DMN_HIP_CHECK(hipEventRecord(u->ev_join, cs[1]));
         DMN_HIP_CHECK(hipStreamWaitEvent(s, u->ev_join, 0));
     }
     return DMN_OK;
@@ -315,10 +396,21 @@ extern "C" int dmn_pc_sample_loop(DmnUnet* u, const float* table, int nsteps, fl
                     n_corrector_steps <= 64, DMN_ERR_INVALID, "dmn_pc_sample_loop: bad predictor/corrector selection");
     hipStream_t s = (hipStream_t)stream;
     const int C = u->cfg.channels;
-    // Only the Langevin corrector couples the images of a batch (its step size is a batch mean; the predictors and the
-    // fixed-step annealed Langevin dynamics are per element): every other configuration runs as two half-batch launch
-    // chains like the DDPM loop, with the same bits.
-    const int nchains = (s && corrector != 1) ? ddpm_chains(u, B) : 1;
+    // Two half-batch launch chains like the DDPM loop, with the bits of one chain. Only the Langevin corrector couples
+    // the images of a batch (its step size is a batch mean; the predictors and the fixed-step annealed Langevin
+    // dynamics are per element): there the chains meet once per corrector step and exchange their images' norms on the
+    // device (LangevinArgs::gran). The waits of those meetings are bounded and counted like the in-launch exchanges',
+    // in the handle's counter: without one (exchanges disabled) the Langevin corrector keeps to one chain.
+    int nchains = s ? ddpm_chains(u, B) : 1;
+    if (corrector == 1 && n_corrector_steps > 0 && nchains == 2) {
+        size_t unused = 0;
+        int rcw = dmn_unet_workspace_bytes(u, B / 2, H, W, &unused);   // reserves the handle's exchange areas
+        if (rcw) return rcw;
+        if ((rcw = ensure_chain_streams(u))) return rcw;
+        // chains that cannot run side by side would wait for each other in vain at every meeting
+        if (!u->handoff_mem[0] || !u->chains_concurrent) nchains = 1;
+    }
+    const bool meet = corrector == 1 && nchains == 2;
     const int Bc = B / nchains;
     LoopBufs lb[2];
     int rc;
@@ -334,6 +426,11 @@ extern "C" int dmn_pc_sample_loop(DmnUnet* u, const float* table, int nsteps, fl
     for (int c = 0; c < nchains; ++c) {
         if ((rc = carve(u, Bc, H, W, (char*)workspace + c * per_chain, per_chain, lb[c], nullptr))) return rc;
         DMN_HIP_CHECK(hipMemsetAsync(lb[c].step_idx, 0, 256, s));
+    }
+    unsigned long long* gran = nullptr;
+    if (meet) {   // tags of an earlier loop must not survive: the area starts every loop zeroed
+        gran = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(lb[0].partials) + 256);
+        DMN_HIP_CHECK(hipMemsetAsync(gran, 0, loop_granule_bytes(B, C, H, W), s));
     }
     if (draw_prior && (rc = launch_prior(x, B, C * H * W, seed, (unsigned)nsteps, img_offset, prior_scale, s))) return rc;
     SampleKey key = {x, table, workspace, keep, x_mean_out, 2 | (nchains << 8), B, H, W,
@@ -367,10 +464,18 @@ extern "C" int dmn_pc_sample_loop(DmnUnet* u, const float* table, int nsteps, fl
                 a.c = step_common(table, lb[c].step_idx, 0, xc, lb[c].net, nullptr, xc, Bc, C, H * W, seed, img_offset + b0,
                                   (!predictor && k == n_corrector_steps - 1) ? keepc : nullptr);
                 a.c.keep_stride = keep_stride;
-                a.partials = lb[c].partials;
+                a.partials = lb[c].partials + 64;   // behind the 256 bytes of the chain's step size
                 a.inner = k;
                 a.use_norms = corrector == 1;
                 a.snr = snr;
+                if (meet) {
+                    a.gran = gran;
+                    a.step_io = lb[c].partials;
+                    a.giveups = reinterpret_cast<unsigned*>(u->handoff_mem[0]) + 1;
+                    a.B_all = B;
+                    a.b_first = b0;
+                    a.n_inner = n_corrector_steps;
+                }
                 if ((r = launch_langevin(a, cs))) return done(r);
             }
         }

@@ -48,6 +48,17 @@ struct LangevinArgs {
     int inner;            // corrector inner step index (noise stream 2 + inner)
     int use_norms;        // 1: Langevin, 0: annealed Langevin dynamics (fixed step)
     float snr;
+    // A batch sampled as several launch chains (each with c.B of the B_all images, the first one b_first): the step size
+    // is a mean over ALL images, so the chains meet here. The norms of a chain's images go to `gran` (shared by the
+    // chains) as tagged 8-byte granules, [2 buffers][B_all][slots][2]; a one-workgroup launch per chain then waits until
+    // the granules of every image carry the tag of this (step, inner step), forms the step size with the arithmetic and
+    // summation order of the single-chain kernel (same bits) and leaves it in `step_io` for the chain's update launch.
+    // gran == nullptr: one chain, plain partials, the update launch forms the step size itself.
+    unsigned long long* gran;
+    float* step_io;       // one float per chain
+    unsigned* giveups;    // counts waits that ran into their time limit (the handle's counter)
+    int B_all, b_first;
+    int n_inner;          // corrector steps per iteration (buffer parity of a meeting = its running number & 1)
 };
 // One element of the DDPM / improved-DDPM / DDIM update (gaussian_diffusion.py:118-123,91-101,157-167;
 // learned_gaussian_diffusion.py:35-48; generalized_gaussian_diffusion.py:43-46,84-97): x, eps (and v, the variance
@@ -96,6 +107,9 @@ int launch_prior(float* x, int B, int per, unsigned long long seed, unsigned pst
                  hipStream_t s);
 int launch_advance(int* step_idx, hipStream_t s);
 int launch_delay(int us, hipStream_t s);   // holds the stream for `us` microseconds
+// *seen = 1 if the flag was raised (launch_probe_set on another stream) within `us` microseconds of the waiter's start
+int launch_probe_wait(unsigned* flag, unsigned* seen, int us, hipStream_t s);
+int launch_probe_set(unsigned* flag, hipStream_t s);
 
 // Bits-per-dimension evaluation (models/abstract_diffusion_model.py:137-197), one timestep per table row.
 struct BpdArgs {

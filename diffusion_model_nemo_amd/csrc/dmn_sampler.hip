@@ -12,6 +12,7 @@
 #include <mutex>
 
 #include "../../include/dmn.h"
+#include "dmn_handoff.h"
 #include "dmn_sampler.h"
 
 namespace {
@@ -65,6 +66,13 @@ __global__ void __launch_bounds__(256) affine_step_kernel(const AffineStepArgs a
     }
 }
 
+// Tag and buffer of the meeting of the launch chains at (table row, corrector inner step): tags grow along a loop (the
+// area is zeroed when the loop starts), and consecutive meetings alternate between two buffers, so a chain that has
+// passed a meeting can publish for the next one while the other chain still reads this one's granules (it cannot get
+// two ahead: the next meeting needs the other chain's granules too).
+__device__ __forceinline__ unsigned langevin_tag(int row, int inner) { return (unsigned)row * 65u + (unsigned)inner + 1u; }
+__device__ __forceinline__ int langevin_buffer(int row, int inner, int n_inner) { return (row * n_inner + inner) & 1; }
+
 // Langevin pass 1: per-sample partial sums of net^2 and z^2. grid (slots, B); partials [B][slots][2]
 __global__ void __launch_bounds__(256) langevin_norms_kernel(const LangevinArgs a) {
     __shared__ float sred[8];
@@ -95,9 +103,81 @@ __global__ void __launch_bounds__(256) langevin_norms_kernel(const LangevinArgs 
     if (threadIdx.x == 0) {
         float tg = 0.f, tz = 0.f;
         for (int w = 0; w < 4; ++w) { tg += sred[2 * w]; tz += sred[2 * w + 1]; }
-        float* dst = a.partials + ((size_t)b * gridDim.x + blockIdx.x) * 2;
-        dst[0] = tg;
-        dst[1] = tz;
+        if (a.gran) {   // several chains: the partial travels as tagged granules to the meeting of the chains
+            const unsigned tag = langevin_tag(row, a.inner);
+            unsigned long long* dst = a.gran + ((((size_t)langevin_buffer(row, a.inner, a.n_inner) * a.B_all + a.b_first + b) * gridDim.x) + blockIdx.x) * 2;
+            granule_store(dst, tag, tg);
+            granule_store(dst + 1, tag, tz);
+        } else {
+            float* dst = a.partials + ((size_t)b * gridDim.x + blockIdx.x) * 2;
+            dst[0] = tg;
+            dst[1] = tz;
+        }
+    }
+}
+
+// The meeting of the launch chains of one batch: grid (1), 64 threads. Lane i takes images i, i + 64, ...: it waits for
+// the image's granules, sums its slots in slot order and takes the roots; thread 0 then adds the images in image order
+// -- the arithmetic and order of the single-chain update kernel below, so the step size has the same bits.
+__global__ void __launch_bounds__(64) langevin_meet_kernel(const LangevinArgs a) {
+    extern __shared__ float sN[];   // [B_all][2]
+    const StepCommon& c = a.c;
+    const int row = c.step_idx ? *c.step_idx : c.step;
+    const float* tr = c.table + (size_t)row * DMN_TABLE_COLS;
+    const float sscale = tr[4];
+    const unsigned tag = langevin_tag(row, a.inner);
+    const unsigned long long* base = a.gran + (size_t)langevin_buffer(row, a.inner, a.n_inner) * a.B_all * a.slots * 2;
+    const long long t0 = wall_clock64();
+    bool gave_up = false;
+    for (int i = threadIdx.x; i < a.B_all; i += 64) {
+        float tg = 0.f, tz = 0.f;
+        for (int s = 0; s < a.slots; ++s) {
+            const unsigned long long* p = base + ((size_t)i * a.slots + s) * 2;
+            unsigned long long g, z;
+            for (;;) {
+                g = granule_load(p);
+                z = granule_load(p + 1);
+                if (((unsigned)(g >> 32) == tag && (unsigned)(z >> 32) == tag) || gave_up) break;
+                if (wall_clock64() - t0 > kHandoffSpinTicks) {
+                    gave_up = true;
+                    if (a.giveups) {
+                        atomicAdd(a.giveups, 1u);
+                        // diagnosis, as the in-launch exchanges leave it: the first lane that misses a granule describes it
+                        if (atomicCAS(a.giveups + 1, 0u, 1u) == 0u) {
+                            unsigned* d = a.giveups + 2;
+                            d[0] = tag;
+                            d[1] = (unsigned)(g >> 32);
+                            d[2] = (unsigned)(z >> 32);
+                            d[3] = (unsigned)i;
+                            d[4] = (unsigned)a.b_first;
+                            d[5] = (unsigned)s;
+                            d[6] = (unsigned)a.slots;
+                            d[7] = (unsigned)row;
+                            d[8] = (unsigned)a.inner;
+                            d[9] = (unsigned)a.n_inner;
+                        }
+                    }
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(32);
+            }
+            tg += __uint_as_float((unsigned)g);
+            tz += __uint_as_float((unsigned)z);
+        }
+        sN[2 * i] = sqrtf(tg) * fabsf(sscale);
+        sN[2 * i + 1] = sqrtf(tz);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float gn = 0.f, zn = 0.f;
+        for (int i = 0; i < a.B_all; ++i) {
+            gn += sN[2 * i];
+            zn += sN[2 * i + 1];
+        }
+        gn /= (float)a.B_all;
+        zn /= (float)a.B_all;
+        const float ratio = a.snr * zn / gn;
+        *a.step_io = ratio * ratio * 2.0f * tr[5];
     }
 }
 
@@ -113,7 +193,9 @@ __global__ void __launch_bounds__(256) langevin_apply_kernel(const LangevinArgs 
     const float sscale = tr[4];   // score = sscale * net
     if (threadIdx.x == 0) {
         float step;
-        if (a.use_norms) {
+        if (a.use_norms && a.gran) {
+            step = *a.step_io;   // formed by this chain's meeting launch
+        } else if (a.use_norms) {
             float gn = 0.f, zn = 0.f;
             for (int i = 0; i < c.B; ++i) {
                 float tg = 0.f, tz = 0.f;
@@ -284,6 +366,13 @@ int launch_langevin(LangevinArgs& a, hipStream_t s) {
     if (a.use_norms) {
         hipLaunchKernelGGL(langevin_norms_kernel, dim3(a.slots, a.c.B), dim3(256), 0, s, a);
         DMN_HIP_CHECK(hipGetLastError());
+        if (a.gran) {
+            DMN_REQUIRE(a.step_io && a.B_all >= a.c.B && a.b_first >= 0 && a.b_first + a.c.B <= a.B_all && a.n_inner >= 1 &&
+                            a.inner < a.n_inner && a.B_all <= 4096,
+                        DMN_ERR_INVALID, "Langevin corrector: inconsistent description of the launch chains");
+            hipLaunchKernelGGL(langevin_meet_kernel, dim3(1), dim3(64), (size_t)a.B_all * 2 * sizeof(float), s, a);
+            DMN_HIP_CHECK(hipGetLastError());
+        }
     }
     hipLaunchKernelGGL(langevin_apply_kernel, step_grid(a.c), dim3(256), 0, s, a);
     DMN_HIP_CHECK(hipGetLastError());
@@ -330,6 +419,34 @@ __global__ void delay_kernel(unsigned ticks) {
     const unsigned long long t0 = wall_clock64();
     for (int i = 0; i < 200000 && wall_clock64() - t0 < ticks; ++i) __builtin_amdgcn_s_sleep(32);
 }
+// Do two streams run side by side? `wait` (on one stream) spins until `set` (on the other) has raised the flag or `us`
+// microseconds have passed, and reports which: streams that share a hardware queue run their kernels one behind the
+// other, so the flag cannot rise while the waiter is still on the queue.
+__global__ void probe_wait_kernel(unsigned* flag, unsigned* seen, unsigned ticks) {
+    if (threadIdx.x) return;
+    const unsigned long long t0 = wall_clock64();
+    unsigned v = 0;
+    for (int i = 0; i < 2000000; ++i) {
+        v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v || wall_clock64() - t0 > ticks) break;
+        __builtin_amdgcn_s_sleep(16);
+    }
+    *seen = v;
+}
+__global__ void probe_set_kernel(unsigned* flag) {
+    if (threadIdx.x == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+int launch_probe_wait(unsigned* flag, unsigned* seen, int us, hipStream_t s) {
+    hipLaunchKernelGGL(probe_wait_kernel, dim3(1), dim3(64), 0, s, flag, seen, (unsigned)us * 100u);
+    DMN_HIP_CHECK(hipGetLastError());
+    return DMN_OK;
+}
+int launch_probe_set(unsigned* flag, hipStream_t s) {
+    hipLaunchKernelGGL(probe_set_kernel, dim3(1), dim3(64), 0, s, flag);
+    DMN_HIP_CHECK(hipGetLastError());
+    return DMN_OK;
+}
+
 int launch_delay(int us, hipStream_t s) {
     if (us <= 0) return DMN_OK;
     if (us > 5000) us = 5000;

@@ -1485,9 +1485,11 @@ extern "C" void dmn_unet_destroy(DmnUnet* u) {
     exchange_guard_forget(u);
     if (u->graph_exec) (void)hipGraphExecDestroy(u->graph_exec);
     if (u->graph_exec2) (void)hipGraphExecDestroy(u->graph_exec2);
-    if (u->side_stream) (void)hipStreamDestroy(u->side_stream);
+    for (hipStream_t cs : u->chain_stream)
+        if (cs) (void)hipStreamDestroy(cs);
     if (u->ev_fork) (void)hipEventDestroy(u->ev_fork);
     if (u->ev_join) (void)hipEventDestroy(u->ev_join);
+    if (u->ev_join0) (void)hipEventDestroy(u->ev_join0);
     if (u->ev_start) (void)hipEventDestroy(u->ev_start);
     if (u->ev_stop) (void)hipEventDestroy(u->ev_stop);
     for (auto e : u->probe_ev)

@@ -95,8 +95,12 @@ struct DmnUnet {
     // same bits as in one chain. Environment DMN_SAMPLE_CHAINS (1 or 2) / DMN_SAMPLE_SKEW_US at handle creation.
     int sample_chains = 2;
     int sample_skew_us = 0;
-    hipStream_t side_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // The two launch chains of a sampling loop run on two streams of the handle (never on the caller's: whether two
+    // streams share a hardware queue -- and then run one behind the other -- depends on every stream the process has
+    // made, so the pair is probed once, when it is made, and kept).
+    hipStream_t chain_stream[2] = {nullptr, nullptr};
+    bool chains_concurrent = false;      // the probe saw the two streams run side by side
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join0 = nullptr;
     int label_offset = 0;                   // first image of the chain that is being launched (class labels)
     int chain_id = 0;                       // which chain is being launched (probe buffers)
     // HIP events bracketing the last sampling loop on its stream (device time of the loop)

@@ -154,14 +154,20 @@ int dmn_pc_sample_loop(DmnUnet* u, const float* table, int nsteps, float* x, int
                        int corrector, int n_corrector_steps, float snr, int denoise, int draw_prior, float prior_scale,
                        uint64_t seed, int64_t img_offset, float* keep, float* x_mean_out, void* workspace,
                        size_t workspace_bytes, void* stream, int use_graph);
-/* The DDPM loop runs a batch of B >= 16 (even) images as two half-batch launch chains on two streams (the caller's and
- * one of the handle), which fills the gaps a single chain of ~85 dependent launches leaves; every image gets the bits
- * it gets in one chain. No counterpart in the reference (gaussian_diffusion.py:171-189 is one Python loop).
+/* The sampling loops run a batch of B >= 16 (even) images as two half-batch launch chains on two streams of the handle
+ * (forked from and joined to the caller's stream), which fills the gaps a single chain of ~70 dependent launches
+ * leaves; every image gets the bits it gets in one chain. No counterpart in the reference (gaussian_diffusion.py:171-189
+ * is one Python loop). The Langevin corrector's step size is a mean over the whole batch (langevin_corrector.py:26-33):
+ * there the chains meet on the device once per corrector step and exchange their images' norms.
  * dmn_unet_set_sample_chains: chains 1 or 2 (default 2, environment DMN_SAMPLE_CHAINS), skew_us = head start of the
  * first chain (default 0, DMN_SAMPLE_SKEW_US). dmn_ddpm_loop_chains: chains a loop over B images will use. Workspaces
- * sized by dmn_sample_workspace_bytes hold either form. */
+ * sized by dmn_sample_workspace_bytes hold either form.
+ * dmn_unet_chains_concurrent: makes the handle's two chain streams if need be and reports whether a probe saw them run
+ * side by side (1) or one behind the other on a shared hardware queue (0: two chains still give the right bits, but no
+ * speed, and the Langevin corrector keeps to one chain). */
 int dmn_unet_set_sample_chains(DmnUnet* u, int chains, int skew_us);
 int dmn_ddpm_loop_chains(const DmnUnet* u, int B);
+int dmn_unet_chains_concurrent(DmnUnet* u, int* concurrent);
 
 /* AbstractDiffusionModel.calculate_bits_per_dimension (models/abstract_diffusion_model.py:137-197) for the
  * 'pred_noise' objective: for every row of `table` (BPD row layout, csrc/dmn_sampler.h; normally t = T-1 .. 0)

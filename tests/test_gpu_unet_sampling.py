@@ -634,8 +634,8 @@ def test_predictor_only_sde_loop_in_two_launch_chains_gives_the_bits_of_one_chai
     mean; the predictors and the fixed-step annealed Langevin dynamics, annealed_langevin_dynamics_corrector.py:34-39, are
     per element), so the predictor-corrector loop runs every other configuration -- among them the shipped default
     euler_maruyama + no corrector -- as two half-batch launch chains like the DDPM loop. Every kept image and the final
-    denoised mean must equal the single chain bit for bit; with the Langevin corrector the loop keeps one chain whatever
-    the setting."""
+    denoised mean must equal the single chain bit for bit (the Langevin corrector, whose chains meet on the device once
+    per corrector step, has a test of its own below)."""
     from diffusion_model_nemo_amd.modules import VESDE, VPSDE, PredictorCorrectorSampler
     u = build_unet(dtype, groups=4)
     N = 12
@@ -656,6 +656,41 @@ def test_predictor_only_sde_loop_in_two_launch_chains_gives_the_bits_of_one_chai
                 assert torch.isfinite(a).all() and torch.equal(a, b), (kind, pred, corr, i, rep)
         last = s.forward(u, [18, 3, 32, 32], "cuda", return_nfe=False, seed=5, keep="last")
         assert torch.equal(last[0], one[-1]), (kind, pred, corr)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_langevin_corrector_in_two_launch_chains_gives_the_bits_of_one_chain(dtype):
+    """The Langevin corrector's step size is a mean over the whole batch (langevin_corrector.py:26-33), so two half-batch
+    launch chains meet once per corrector step: each publishes its images' norms, a one-workgroup launch per chain waits
+    for all of them and forms the step size in the order of the single-chain kernel. Kept images and final means must
+    equal the single chain bit for bit, captured and eager, for odd and even numbers of corrector steps (consecutive
+    meetings alternate between two buffers), with and without a predictor; no wait may run into its time limit."""
+    import ctypes as C
+    from diffusion_model_nemo_amd import _native as N
+    from diffusion_model_nemo_amd.modules import VESDE, VPSDE, PredictorCorrectorSampler
+    u = build_unet(dtype, groups=4)
+    steps = 8
+    cases = [("ve", "reverse_diffusion", 1, {}), ("ve", None, 2, {}), ("ve", "ancestral_sampling", 3, {}),
+             ("ve", "euler_maruyama", 2, {"denoise": False})]
+    for kind, pred, n_inner, kw in cases:
+        sde = VESDE(0.01, 50.0, steps) if kind == "ve" else VPSDE(0.1, 20.0, steps)
+        s = PredictorCorrectorSampler(predictor=pred, corrector="langevin", snr=0.16, n_steps=n_inner, **kw)
+        s.update_sde(sde)
+        u.set_sample_chains(1)
+        one = s.forward(u, [18, 3, 32, 32], "cuda", return_nfe=False, seed=5)
+        u.set_sample_chains(2)
+        side_by_side = C.c_int(0)
+        N.check(N.lib().dmn_unet_chains_concurrent(u.native_handle(), C.byref(side_by_side)))
+        assert N.lib().dmn_ddpm_loop_chains(u.native_handle(), 18) == 2 and side_by_side.value == 1
+        for rep in range(3):
+            two = s.forward(u, [18, 3, 32, 32], "cuda", return_nfe=False, seed=5, **({"use_graph": False} if rep == 2 else {}))
+            assert len(one) == len(two) == steps
+            for i, (a, b) in enumerate(zip(one, two)):
+                assert torch.isfinite(a).all() and torch.equal(a, b), (kind, pred, n_inner, i, rep)
+        assert float(one[-1].abs().max()) > 0 and not torch.equal(one[-1][:9], one[-1][9:])
+    give = C.c_uint(0)
+    N.check(N.lib().dmn_unet_handoff_giveups(u.native_handle(), C.byref(give)))
+    assert give.value == 0
 
 
 @pytest.mark.parametrize("B", [15, 16, 18, 34])
