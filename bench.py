@@ -31,7 +31,7 @@ ALG_BYTES_PER_IMG_EVAL = 17.3e6
 WEIGHT_BYTES = 16.2e6
 HBM_PEAK_GBS = 8000.0
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense matrix peaks of the two compute types
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_dominant_kernel_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_dominant_kernel_traffic.json")
 
 
 def parse(argv=None):

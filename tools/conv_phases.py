@@ -31,11 +31,11 @@ def run(name, B, H, W, cin, cout, k, stride, pad, transposed, pro, epi_G, dtype=
         pG = 8
         pg = np.ones(cin, np.float32)
         pb = np.zeros(cin, np.float32)
-        st = torch.zeros((B, pG, 1, 2))
-        st[..., 0] = 0.0
+        st = torch.zeros((B, pG, 1, 4))   # one partial per group {sum 0, squared deviations = count, count, -}: mean 0, variance 1
         st[..., 1] = float(H * W * cin // pG)
+        st[..., 2] = float(H * W * cin // pG)
         pst = st.cuda()
-    est = torch.zeros((B * max(epi_G, 1) * 4096 * 2,), device="cuda") if epi_G else None
+    est = torch.zeros((B * max(epi_G, 1) * 4096 * 4,), device="cuda") if epi_G else None
     dbg = torch.zeros((1 << 16, 8), dtype=torch.int64, device="cuda")
     slots = C.c_int(0)
     N.check(lib.dmn_test_set_conv_debug(dbg.data_ptr()))

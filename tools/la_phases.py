@@ -31,7 +31,10 @@ def run(B, n, Cch, dtype=1):
     g = torch.Generator().manual_seed(3)
     tdt = torch.bfloat16 if dtype == 1 else torch.float32
     x = torch.randn((B, n, Cch), generator=g)
-    xs = torch.stack([x.sum((1, 2)), (x * x).sum((1, 2))], 1).contiguous().cuda()
+    s1 = x.sum((1, 2))
+    cnt = torch.full_like(s1, float(n * Cch))
+    m2 = ((x - (s1 / cnt)[:, None, None]) ** 2).sum((1, 2))
+    xs = torch.stack([s1, m2, cnt, torch.zeros_like(s1)], 1).contiguous().cuda()   # one partial per image {sum, squared deviations, count, -}
     xd = x.to(tdt).cuda()
     wqkv = (torch.randn((384, Cch), generator=g) * Cch ** -0.5).numpy().astype(np.float32)
     wout = (torch.randn((Cch, 128), generator=g) * 128 ** -0.5).numpy().astype(np.float32)
@@ -39,7 +42,7 @@ def run(B, n, Cch, dtype=1):
     gamma = np.ones(Cch, np.float32)
     beta = np.zeros(Cch, np.float32)
     y = torch.zeros((B, n, Cch), device="cuda", dtype=tdt)
-    ystats = torch.zeros((B, 1024, 2), device="cuda")
+    ystats = torch.zeros((B, 1024, 4), device="cuda")
     scratch = torch.zeros((B * 4 * ((n + 31) // 32) * 1088,), device="cuda")
     dbg = torch.zeros((2 * 65536, 8), dtype=torch.int64, device="cuda")
     slices = C.c_int(0)

@@ -25,15 +25,16 @@ def run(name, B, H, C_, G, dtype=1, out_G=1, plan_B=64):
     pg, pb = np.ones(C_, np.float32), np.zeros(C_, np.float32)
     tg = (1.0 + 0.1 * torch.randn((C_,), generator=g)).numpy().astype(np.float32)
     tb = (0.1 * torch.randn((C_,), generator=g)).numpy().astype(np.float32)
-    st = torch.zeros((B, G, 1, 2))
+    st = torch.zeros((B, G, 1, 4))   # one partial per group {sum 0, squared deviations = count, count, -}: mean 0, variance 1
     st[..., 1] = float(H * H * C_ // G)
+    st[..., 2] = float(H * H * C_ // G)
     pst = st.cuda()
     outs, stats, spans = [], [], []
     dbg = torch.zeros((1 << 16, 8), dtype=torch.int64, device="cuda")
     for fused in (1, 0):
         out = torch.zeros((B, H, H, C_), device="cuda", dtype=tdt)
         h2 = torch.zeros((B, H, H, C_), device="cuda", dtype=tdt)
-        ost = torch.zeros((B * out_G * 4096 * 2,), device="cuda")
+        ost = torch.zeros((B * out_G * 4096 * 4,), device="cuda")
         slots, give = C.c_int(0), C.c_uint(0)
         N.check(lib.dmn_test_set_conv_debug(dbg.data_ptr()))
         if fused:   # shapes outside the exchange's limits (workgroups per image, LDS per workgroup) are refused
@@ -68,7 +69,7 @@ def run(name, B, H, C_, G, dtype=1, out_G=1, plan_B=64):
         spans.append(span)
         outs.append(out)
         n = slots.value
-        stats.append(ost[:B * out_G * n * 2].view(B, out_G, n, 2).sum(2).cpu())
+        stats.append(ost[:B * out_G * n * 4].view(B, out_G, n, 4)[..., 0].sum(2).cpu())   # group sums (slot 0 of every partial)
     same = torch.equal(outs[0], outs[1])
     sd = float((stats[0] - stats[1]).abs().max() / stats[1].abs().max())
     print(f"{name:28s} out bit-equal {same}  out-stats rel diff {sd:.1e}  fused {txt}  | conv alone span {spans[1]:5.1f}us", flush=True)
