@@ -1,6 +1,6 @@
 """Experiment (GPU): error of the fp32 handle against the CPU oracle when every GroupNorm input carries a mean that is large
 against its spread (a constant added to the bias of every convolution that feeds a GroupNorm).
-usage: python tools/r3/gn_offset_probe.py [offsets ...]"""
+usage: python tools/gn_offset_probe.py [offsets ...]"""
 import sys
 
 import numpy as np

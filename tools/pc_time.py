@@ -1,5 +1,5 @@
 """Tuning aid (GPU): wall time per iteration of the predictor-corrector loop (64 images, 64x64, bf16, reverse diffusion +
-Langevin corrector) with one and with two launch chains: python tools/r3/pc_time.py [n_corrector_steps]"""
+Langevin corrector) with one and with two launch chains: python tools/pc_time.py [n_corrector_steps]"""
 import sys
 import time
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 experiment: does a third / fourth launch chain pay once the process owns more hardware queues?
+# Experiment: does a third / fourth launch chain pay once the process owns more hardware queues?
 # Independent single-chain handles side by side (eager launches, closing passes as their own launches so that no
 # in-launch exchange can starve), with 4 (default) and 8 hardware queues.
 set -e
