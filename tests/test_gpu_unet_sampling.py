@@ -693,6 +693,43 @@ def test_langevin_corrector_in_two_launch_chains_gives_the_bits_of_one_chain(dty
     assert give.value == 0
 
 
+def test_device_clock_probe_times_a_chosen_launch_inside_the_captured_steps():
+    """The measurement hooks behind bench.py's roofline blocks: the dominant level-0 convolution and any convolution
+    launch chosen by its number are clocked by their own workgroups inside graph-replayed steps (both chains in flight),
+    report the shape that was clocked, and leave the sampled images untouched."""
+    import ctypes as C
+    from diffusion_model_nemo_amd import _native as N
+    from diffusion_model_nemo_amd.modules import GaussianDiffusion
+    u = build_unet64("bf16")
+    h = u.native_handle()
+    gd = GaussianDiffusion(timesteps=6, schedule_name="cosine")
+    plain = gd.p_sample_loop(u, (32, 3, 64, 64), device="cuda", seed=4, return_device_tensor=True).clone()
+    ms, mark, n, nbytes = C.c_float(), C.c_float(), C.c_int(), C.c_double()
+    shape = (C.c_double * 5)()
+    N.check(N.lib().dmn_unet_probe_dominant(h, 2))
+    probed = gd.p_sample_loop(u, (32, 3, 64, 64), device="cuda", seed=4, return_device_tensor=True).clone()
+    N.check(N.lib().dmn_unet_probe_result(h, C.byref(ms), C.byref(mark), C.byref(n), C.byref(nbytes)))
+    assert torch.equal(plain, probed)
+    assert n.value == 2 * 6 and 1e-3 < ms.value < 0.2                 # one launch per chain and step, microseconds each
+    assert nbytes.value == 16 * 64 * 64 * (32 + 32) * 2 + 32 * 32 * 9 * 2   # 16 images per launch: in + out + weights, bf16
+    found = []
+    for site in range(8, 40):
+        N.check(N.lib().dmn_test_probe_site(h, site, None))
+        N.check(N.lib().dmn_unet_probe_dominant(h, 2))
+        out = gd.p_sample_loop(u, (32, 3, 64, 64), device="cuda", seed=4, return_device_tensor=True)
+        assert torch.equal(out, plain), site
+        if N.lib().dmn_unet_probe_result(h, C.byref(ms), C.byref(mark), C.byref(n), None) != 0:
+            continue
+        N.check(N.lib().dmn_test_probe_site(h, site, shape))
+        if list(shape)[1:] == [256.0, 256.0, 8.0, 9.0]:
+            assert shape[0] == 2.0 * 16 * 64 * 256 * 256 * 9 and n.value == 12 and 1e-3 < ms.value < 0.2
+            found.append(site)
+    assert len(found) >= 2                                             # the 256 -> 256 channel 3x3 launches at 8x8 pixels
+    N.check(N.lib().dmn_test_probe_site(h, -1, None))
+    N.check(N.lib().dmn_unet_probe_dominant(h, 0))
+    assert torch.equal(gd.p_sample_loop(u, (32, 3, 64, 64), device="cuda", seed=4, return_device_tensor=True), plain)
+
+
 @pytest.mark.parametrize("B", [15, 16, 18, 34])
 def test_two_launch_chains_at_ragged_batches(B):
     """Batches around the split rule (even and >= 16: two chains of B/2, else one) on a 32x32 network, DDIM steps with a
