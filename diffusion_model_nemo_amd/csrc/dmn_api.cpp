@@ -1,6 +1,10 @@
 // Sampler entry points of the C-ABI (include/dmn.h): single-step updates, the graph-replayed sampling
 // loops, and per-kernel test hooks.
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <chrono>
 
 #include <vector>
 
@@ -310,11 +314,40 @@ static int run_loop_inner(DmnUnet* u, const SampleKey& key, int nsteps, hipStrea
         DMN_HIP_CHECK(hipStreamWaitEvent(cs[1], u->ev_fork, 0));
         if (u->sample_skew_us > 0 && (rc = launch_delay(u->sample_skew_us, cs[1]))) return rc;
     }
-    for (int i = 0; i < nsteps; ++i)
+    // tuning aid (DMN_LOOP_HOST_TRACE): host time of the enqueue loop per block of 50 steps, to stderr
+    static const bool host_trace = getenv("DMN_LOOP_HOST_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t_block = std::chrono::steady_clock::now();
+    // Pacing: the host enqueues a step in a seventh of the time the device needs for it, and while it runs hundreds of
+    // steps ahead (until the hardware queue is full, about 300 steps) the device is measurably slower: 787 against 727 us
+    // per step over the first 300 steps of a loop on MI355X, and a profiler's kernel trace of the same loop shows no
+    // such trend in the kernels themselves -- the cost follows the host's burst of packet and kernel-argument writes.
+    // So the host waits, every `pace` steps, until the block before the last one has finished: at most two blocks are
+    // ever in flight, which is still tens of steps (milliseconds) ahead of the device.
+    const int pace = (s != nullptr && u->loop_pace > 0) ? u->loop_pace : 0;
+    if (pace)
+        for (auto& slot : u->ev_pace)
+            for (int c = 0; c < nchains; ++c)
+                if (!slot[c]) DMN_HIP_CHECK(hipEventCreateWithFlags(&slot[c], hipEventDisableTiming));
+    for (int i = 0; i < nsteps; ++i) {
+        if (pace && i % pace == 0 && i >= 2 * pace) {
+            const int slot = (i / pace) & 1;   // recorded two blocks ago
+            for (int c = 0; c < nchains; ++c) DMN_HIP_CHECK(hipEventSynchronize(u->ev_pace[slot][c]));
+        }
         for (int c = 0; c < nchains; ++c) {
             if (graph) DMN_HIP_CHECK(hipGraphLaunch(c ? u->graph_exec2 : u->graph_exec, cs[c]));
             else if ((rc = body(c, cs[c]))) return rc;
         }
+        if (pace && i % pace == pace - 1) {
+            const int slot = (i / pace) & 1;
+            for (int c = 0; c < nchains; ++c) DMN_HIP_CHECK(hipEventRecord(u->ev_pace[slot][c], cs[c]));
+        }
+        if (host_trace && (i % 50 == 49 || i == nsteps - 1)) {
+            const auto now = std::chrono::steady_clock::now();
+            fprintf(stderr, "%s%.0f", i < 50 ? "loop host us per step:" : "", std::chrono::duration<double, std::micro>(now - t_block).count() / (i % 50 + 1));
+            fprintf(stderr, i == nsteps - 1 ? "\n" : " ");
+            t_block = now;
+        }
+    }
     if (nchains == 2) {   // and the caller's stream goes on behind both
         DMN_HIP_CHECK(hipEventRecord(u->ev_join0, cs[0]));
         DMN_HIP_CHECK(hipStreamWaitEvent(s, u->ev_join0, 0));

@@ -1424,6 +1424,7 @@ extern "C" int dmn_unet_create(const DmnUnetCfg* cfg, DmnUnet** out) {
         const unsigned long long v = strtoull(e, nullptr, 0);
         if (v >= 1 && v <= 0xFFF00000ull) u->epoch_limit = v;
     }
+    if (const char* e = getenv("DMN_LOOP_PACE")) u->loop_pace = atoi(e) < 0 ? 0 : (atoi(e) > 4096 ? 4096 : atoi(e));
     if (const char* e = getenv("DMN_SAMPLE_SKEW_US")) u->sample_skew_us = atoi(e) < 0 ? 0 : (atoi(e) > 5000 ? 5000 : atoi(e));
     u->downs.resize(cfg->n_mults);
     u->ups.resize(cfg->n_mults - 1);
@@ -1490,6 +1491,9 @@ extern "C" void dmn_unet_destroy(DmnUnet* u) {
     if (u->ev_fork) (void)hipEventDestroy(u->ev_fork);
     if (u->ev_join) (void)hipEventDestroy(u->ev_join);
     if (u->ev_join0) (void)hipEventDestroy(u->ev_join0);
+    for (auto& slot : u->ev_pace)
+        for (hipEvent_t e : slot)
+            if (e) (void)hipEventDestroy(e);
     if (u->ev_start) (void)hipEventDestroy(u->ev_start);
     if (u->ev_stop) (void)hipEventDestroy(u->ev_stop);
     for (auto e : u->probe_ev)
