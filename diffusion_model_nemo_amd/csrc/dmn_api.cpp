@@ -324,13 +324,14 @@ static int run_loop_inner(DmnUnet* u, const SampleKey& key, int nsteps, hipStrea
     // So the host waits, every `pace` steps, until the block before the last one has finished: at most two blocks are
     // ever in flight, which is still tens of steps (milliseconds) ahead of the device.
     const int pace = (s != nullptr && u->loop_pace > 0) ? u->loop_pace : 0;
+    const int depth = u->loop_depth;
     if (pace)
-        for (auto& slot : u->ev_pace)
+        for (int k = 0; k < depth; ++k)
             for (int c = 0; c < nchains; ++c)
-                if (!slot[c]) DMN_HIP_CHECK(hipEventCreateWithFlags(&slot[c], hipEventDisableTiming));
+                if (!u->ev_pace[k][c]) DMN_HIP_CHECK(hipEventCreateWithFlags(&u->ev_pace[k][c], hipEventDisableTiming));
     for (int i = 0; i < nsteps; ++i) {
-        if (pace && i % pace == 0 && i >= 2 * pace) {
-            const int slot = (i / pace) & 1;   // recorded two blocks ago
+        if (pace && i % pace == 0 && i >= depth * pace) {
+            const int slot = (i / pace) % depth;   // recorded `depth` blocks ago
             for (int c = 0; c < nchains; ++c) DMN_HIP_CHECK(hipEventSynchronize(u->ev_pace[slot][c]));
         }
         for (int c = 0; c < nchains; ++c) {
@@ -338,7 +339,7 @@ static int run_loop_inner(DmnUnet* u, const SampleKey& key, int nsteps, hipStrea
             else if ((rc = body(c, cs[c]))) return rc;
         }
         if (pace && i % pace == pace - 1) {
-            const int slot = (i / pace) & 1;
+            const int slot = (i / pace) % depth;
             for (int c = 0; c < nchains; ++c) DMN_HIP_CHECK(hipEventRecord(u->ev_pace[slot][c], cs[c]));
         }
         if (host_trace && (i % 50 == 49 || i == nsteps - 1)) {

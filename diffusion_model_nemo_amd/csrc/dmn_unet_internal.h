@@ -106,8 +106,10 @@ struct DmnUnet {
     // HIP events bracketing the last sampling loop on its stream (device time of the loop)
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     // pacing of a loop's enqueue (dmn_api.cpp:run_loop_inner): [slot][chain], recorded every loop_pace steps
-    hipEvent_t ev_pace[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-    int loop_pace = 16;                  // steps between pacing events; at most two such blocks are in flight (0: unpaced; DMN_LOOP_PACE)
+    static constexpr int kPaceSlots = 64;
+    hipEvent_t ev_pace[kPaceSlots][2] = {};
+    int loop_pace = 16;                  // steps between pacing events (0: unpaced; DMN_LOOP_PACE)
+    int loop_depth = 2;                  // blocks of loop_pace steps in flight at most (2..kPaceSlots; DMN_LOOP_DEPTH)
     bool ev_valid = false;
     // measurement hook: HIP event pairs around the launches of the step's dominant convolution (eager launches only)
     std::vector<hipEvent_t> probe_ev;    // 3 * kProbePairs events once enabled
