@@ -307,6 +307,7 @@ static int run_loop_inner(DmnUnet* u, const SampleKey& key, int nsteps, hipStrea
             (void)hipGraphDestroy(g);
         }
         u->graph_key = key;
+        if (getenv("DMN_LOOP_HOST_TRACE")) fprintf(stderr, "loop: step graphs captured (x %p seed %llu)\n", (void*)key.x, (unsigned long long)key.seed);
     }
     if (nchains == 2) {   // the chain streams start behind everything queued on the caller's stream so far
         DMN_HIP_CHECK(hipEventRecord(u->ev_fork, s));
@@ -341,6 +342,14 @@ static int run_loop_inner(DmnUnet* u, const SampleKey& key, int nsteps, hipStrea
         if (pace && i % pace == pace - 1) {
             const int slot = (i / pace) % depth;
             for (int c = 0; c < nchains; ++c) DMN_HIP_CHECK(hipEventRecord(u->ev_pace[slot][c], cs[c]));
+            // Two chains run fastest in LOCKSTEP -- the same kernels side by side -- and slowest half a step apart
+            // (733 against 750 us per step, tools/chain_phase.py); left alone they drift apart in about every second
+            // loop. So each chain also waits, on the device, for the other one's end of the block: they start every
+            // block together (the drift inside a block of 16 steps is a few hundredths of a step).
+            if (nchains == 2 && u->loop_lockstep && i + 1 < nsteps) {
+                DMN_HIP_CHECK(hipStreamWaitEvent(cs[0], u->ev_pace[slot][1], 0));
+                DMN_HIP_CHECK(hipStreamWaitEvent(cs[1], u->ev_pace[slot][0], 0));
+            }
         }
         if (host_trace && (i % 50 == 49 || i == nsteps - 1)) {
             const auto now = std::chrono::steady_clock::now();

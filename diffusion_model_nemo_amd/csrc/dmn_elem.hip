@@ -225,6 +225,7 @@ __global__ void __launch_bounds__(256) ingest_kernel(const IngestArgs a) {
     if (a.epoch && blockIdx.x == 0 && b == 0 && threadIdx.x == 0) {   // a new network evaluation; 0 is "never written"
         const unsigned e = *a.epoch + 1u;
         *a.epoch = e ? e : 1u;
+        if (a.trace) a.trace[e & 8191u] = (long long)wall_clock64();
     }
     for (int i = threadIdx.x; i < a.Cin * IW * IW; i += 256) {
         const int c = i / (IW * IW), r = i % (IW * IW);
@@ -272,6 +273,7 @@ __device__ __forceinline__ void ingest_mfma_body(const IngestArgs& a, int bx, in
     if (a.epoch && bx == 0 && b == 0 && tid == 0) {   // a new network evaluation; 0 is "never written"
         const unsigned e = *a.epoch + 1u;
         *a.epoch = e ? e : 1u;
+        if (a.trace) a.trace[e & 8191u] = (long long)wall_clock64();
     }
     // weights first: 7 * NT fragments per wave, straight into registers
     bf16x8 wf[NT][7];

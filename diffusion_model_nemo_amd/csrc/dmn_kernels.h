@@ -142,6 +142,7 @@ struct IngestArgs {
     const long long* labels;    // [B] or nullptr (every image takes row num_classes)
     int num_classes;
     unsigned* epoch;            // optional: the hand-off epoch of the chain, incremented by one thread (dmn_handoff.h)
+    long long* trace;           // optional tuning aid: [8192] ring, slot epoch & 8191 receives the 100 MHz clock when the evaluation starts
 };
 int launch_ingest(IngestArgs& a, hipStream_t s);
 bool ingest_time_fusable(const IngestArgs& a, const TimeArgs& t);

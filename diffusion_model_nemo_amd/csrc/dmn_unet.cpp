@@ -881,6 +881,7 @@ int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float,
             ia.num_classes = c.num_classes;
         }
         if (f.ho_enabled && !dry) ia.epoch = reinterpret_cast<unsigned*>(f.ho_base);
+        if (f.ho_enabled && !dry && u->step_trace) ia.trace = u->step_trace + (size_t)u->chain_id * 8192;
         if (f.ok() && !dry) {
             if (c.with_time_emb && !(u->path_mask & 1) && ingest_time_fusable(ia, ta)) {
                 f.run(launch_ingest_time(ia, ta, s), "ingest + time");   // the two independent openers of the network in one launch
@@ -1425,6 +1426,7 @@ extern "C" int dmn_unet_create(const DmnUnetCfg* cfg, DmnUnet** out) {
         if (v >= 1 && v <= 0xFFF00000ull) u->epoch_limit = v;
     }
     if (const char* e = getenv("DMN_LOOP_PACE")) u->loop_pace = atoi(e) < 0 ? 0 : (atoi(e) > 4096 ? 4096 : atoi(e));
+    if (const char* e = getenv("DMN_LOOP_LOCKSTEP")) u->loop_lockstep = atoi(e) != 0;
     if (const char* e = getenv("DMN_LOOP_DEPTH")) u->loop_depth = atoi(e) < 2 ? 2 : (atoi(e) > DmnUnet::kPaceSlots ? DmnUnet::kPaceSlots : atoi(e));
     if (const char* e = getenv("DMN_SAMPLE_SKEW_US")) u->sample_skew_us = atoi(e) < 0 ? 0 : (atoi(e) > 5000 ? 5000 : atoi(e));
     u->downs.resize(cfg->n_mults);
@@ -1499,6 +1501,7 @@ extern "C" void dmn_unet_destroy(DmnUnet* u) {
     if (u->ev_stop) (void)hipEventDestroy(u->ev_stop);
     for (auto e : u->probe_ev)
         if (e) (void)hipEventDestroy(e);
+    if (u->step_trace) (void)hipFree(u->step_trace);
     if (u->probe_stamps) (void)hipFree(u->probe_stamps);
     if (u->probe_acc) (void)hipFree(u->probe_acc);
     for (int c = 0; c < 2; ++c)
@@ -1675,6 +1678,27 @@ extern "C" int dmn_test_probe_site(DmnUnet* u, int site, double* shape) {
     if (u->graph_exec2) (void)hipGraphExecDestroy(u->graph_exec2);
     u->graph_exec = u->graph_exec2 = nullptr;
     u->probe_site = site;
+    return DMN_OK;
+}
+
+// Tuning aid: the 100 MHz clock at the start of every network evaluation, per launch chain (a ring of 8192 entries indexed
+// by the chain's epoch). host == nullptr: switch the recording on (buffers zeroed; captured steps are dropped because they
+// hold the old choice); otherwise copy chain `chain`'s ring to host[8192].
+extern "C" int dmn_test_step_trace(DmnUnet* u, int chain, long long* host) {
+    DMN_REQUIRE(u && chain >= 0 && chain < 2, DMN_ERR_INVALID, "dmn_test_step_trace: bad argument");
+    DMN_HIP_CHECK(hipDeviceSynchronize());
+    if (!host) {
+        if (!u->step_trace) {
+            DMN_HIP_CHECK(hipMalloc(&u->step_trace, (size_t)2 * 8192 * sizeof(long long)));
+            if (u->graph_exec) (void)hipGraphExecDestroy(u->graph_exec);
+            if (u->graph_exec2) (void)hipGraphExecDestroy(u->graph_exec2);
+            u->graph_exec = u->graph_exec2 = nullptr;
+        }
+        DMN_HIP_CHECK(hipMemset(u->step_trace, 0, (size_t)2 * 8192 * sizeof(long long)));
+        return DMN_OK;
+    }
+    DMN_REQUIRE(u->step_trace, DMN_ERR_INVALID, "dmn_test_step_trace: recording was never switched on");
+    DMN_HIP_CHECK(hipMemcpy(host, u->step_trace + (size_t)chain * 8192, 8192 * sizeof(long long), hipMemcpyDeviceToHost));
     return DMN_OK;
 }
 

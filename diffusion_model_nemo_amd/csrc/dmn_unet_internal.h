@@ -109,6 +109,7 @@ struct DmnUnet {
     static constexpr int kPaceSlots = 64;
     hipEvent_t ev_pace[kPaceSlots][2] = {};
     int loop_pace = 16;                  // steps between pacing events (0: unpaced; DMN_LOOP_PACE)
+    bool loop_lockstep = true;           // the two chains start every pacing block together (DMN_LOOP_LOCKSTEP=0: left to drift)
     int loop_depth = 2;                  // blocks of loop_pace steps in flight at most (2..kPaceSlots; DMN_LOOP_DEPTH)
     bool ev_valid = false;
     // measurement hook: HIP event pairs around the launches of the step's dominant convolution (eager launches only)
@@ -119,6 +120,7 @@ struct DmnUnet {
                                          // of an evaluation stamps its phases instead of the dominant one (dmn_test_probe_read)
     long long* probe_stamps = nullptr;   // [2 chains][kProbeMaxWgs][8] per-workgroup stamps of the probed launch
     unsigned long long* probe_acc = nullptr;   // per chain {sum of spans in 10 ns ticks, launches}
+    long long* step_trace = nullptr;     // tuning aid (dmn_test_step_trace): [2 chains][8192] evaluation start clocks
     double probe_bytes = 0.0;            // algorithmic bytes of one probed launch
     double probe_shape[5] = {0, 0, 0, 0, 0};   // its multiply-add work (2 * images * output pixels * Cin * Cout * taps), Cin, Cout, output height, taps
     // Granule areas of the in-launch statistics hand-off (dmn_handoff.h), one per launch chain, owned by the handle:

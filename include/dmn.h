@@ -93,6 +93,10 @@ int dmn_test_probe_read(DmnUnet* u, int chain, long long* host, int nwgs);
  * convolution again); dmn_unet_probe_dominant(u, 2) / dmn_unet_probe_result then clock it. shape (optional, 5 doubles)
  * receives what the launch clocked last was: {2 * images * output pixels * Cin * Cout * taps, Cin, Cout, output height, taps}. */
 int dmn_test_probe_site(DmnUnet* u, int site, double* shape);
+/* Tuning aid, no counterpart in the reference: the 100 MHz device clock at the start of every network evaluation, per
+ * launch chain, in a ring of 8192 entries indexed by the chain's evaluation count. host == NULL switches the recording on
+ * and zeroes the rings; otherwise chain `chain`'s ring is copied to host[8192]. */
+int dmn_test_step_trace(DmnUnet* u, int chain, long long* host);
 
 /* eps = Unet(x, t).  t: [B] int64 (t_is_float = 0) or float32 (1), device memory. out: [B][out_dim][H][W]. */
 int dmn_unet_forward(DmnUnet* u, const float* x, const void* t, int t_is_float, float* out, int B, int H, int W,
