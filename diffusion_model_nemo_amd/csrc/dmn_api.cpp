@@ -349,6 +349,7 @@ static int run_loop_inner(DmnUnet* u, const SampleKey& key, int nsteps, hipStrea
             if (nchains == 2 && u->loop_lockstep && i + 1 < nsteps) {
                 DMN_HIP_CHECK(hipStreamWaitEvent(cs[0], u->ev_pace[slot][1], 0));
                 DMN_HIP_CHECK(hipStreamWaitEvent(cs[1], u->ev_pace[slot][0], 0));
+                if (u->sample_skew_us > 0 && (rc = launch_delay(u->sample_skew_us, cs[1]))) return rc;   // tuning: a fixed lag
             }
         }
         if (host_trace && (i % 50 == 49 || i == nsteps - 1)) {
