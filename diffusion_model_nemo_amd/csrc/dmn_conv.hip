@@ -396,6 +396,10 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
     }
     {
         DMN_STAMP(3)
+        // Waves that are about to finish go first: what a launch chain waits for is the END of every launch, and on a CU
+        // shared with the other chain's kernels the epilogue otherwise queues behind their staging arithmetic (-0.5 % step
+        // time; raising the priority in the matrix loop as well gains less).
+        __builtin_amdgcn_s_setprio(3);
         // ---- epilogue: bias, residual, statistics, NHWC store ---------------------------------------------
         T* outp = static_cast<T*>(a.out);
         const T* resp = static_cast<const T*>(a.res);
