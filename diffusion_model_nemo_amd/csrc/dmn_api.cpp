@@ -263,6 +263,8 @@ static int run_loop(DmnUnet* u, const SampleKey& key_in, int nsteps, int evals, 
     SampleKey key = key_in;
     if (u->exchange_off) key.kind |= 1 << 16;
     int rc = want_exchange ? unet_epoch_reserve(u, (unsigned long long)nsteps * (unsigned long long)evals, s) : DMN_OK;
+    if (rc == DMN_OK) rc = unet_time_hidden_table(u, static_cast<const float*>(key.table), nsteps, s);
+    key.h2 = u->h2_table_of ? u->h2_table : nullptr;
     if (rc == DMN_OK && hipEventRecord(u->ev_start, s) != hipSuccess) {
         dmn_set_error("hipEventRecord failed at the start of a sampling loop");
         rc = DMN_ERR_HIP;

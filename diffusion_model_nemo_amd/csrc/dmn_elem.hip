@@ -170,12 +170,26 @@ __device__ __forceinline__ void time_mlp_body(const TimeArgs& a, int bx, int b) 
     const int tid = threadIdx.x;
     const int dim = a.dim, hid = 4 * a.dim, half = a.dim / 2;
     float label;
-    if (a.t) {
+    if (a.h2_out) {            // tabulating: workgroup b takes table row b
+        label = a.table[(size_t)b * a.table_cols + a.label_col];
+    } else if (a.t) {
         label = a.t_is_float ? static_cast<const float*>(a.t)[b] : (float)static_cast<const long long*>(a.t)[b];
     } else {
         const int row = *a.step_idx;
         label = a.table[(size_t)row * a.table_cols + a.label_col];
         if (a.step_copy && bx == 0 && b == 0 && tid == 0) *a.step_copy = row;
+        if (a.h2) {            // the hidden vector of this row was tabulated before the loop
+            for (int o = tid; o < hid; o += 256) sT[o] = a.h2[(size_t)row * hid + o];
+            __syncthreads();
+            const int oo = bx * 256 + tid;
+            if (oo < a.nout) {
+                float acc = 0.f;
+#pragma unroll 16
+                for (int k = 0; k < hid; ++k) acc = fmaf(sT[k], a.wb[(size_t)k * a.nout + oo], acc);
+                a.out[(size_t)b * a.nout + oo] = acc + a.bb[oo];
+            }
+            return;
+        }
     }
     if (tid < half) {
         const float e = label * a.freqs[tid];
@@ -196,7 +210,9 @@ __device__ __forceinline__ void time_mlp_body(const TimeArgs& a, int bx, int b) 
 #pragma unroll 16
         for (int k = 0; k < hid; ++k) acc = fmaf(sH[k], a.w2[(size_t)k * hid + o], acc);
         sT[o] = silu_precise(acc + a.b2[o]);
+        if (a.h2_out) a.h2_out[(size_t)b * hid + o] = sT[o];
     }
+    if (a.h2_out) return;
     __syncthreads();
     const int o = bx * 256 + tid;
     if (o < a.nout) {
@@ -590,6 +606,14 @@ int launch_norm_apply(NormApplyArgs& a, hipStream_t s) {
 int launch_time_mlp(TimeArgs& a, hipStream_t s) {
     DMN_REQUIRE(a.dim <= 64 && a.dim % 2 == 0 && 4 * a.dim <= 512, DMN_ERR_LIMIT, "time_mlp: dim=%d exceeds 64", a.dim);
     hipLaunchKernelGGL(time_mlp_kernel, dim3((a.nout + 255) / 256, a.rows), dim3(256), 0, s, a);
+    DMN_HIP_CHECK(hipGetLastError());
+    return DMN_OK;
+}
+
+int launch_time_hidden(TimeArgs& a, int table_rows, hipStream_t s) {
+    DMN_REQUIRE(a.table && a.h2_out && table_rows > 0 && table_rows <= 65535, DMN_ERR_INVALID, "time path: nothing to tabulate");
+    DMN_REQUIRE(a.dim <= 64 && a.dim % 2 == 0 && 4 * a.dim <= 512, DMN_ERR_LIMIT, "time_mlp: dim=%d exceeds 64", a.dim);
+    hipLaunchKernelGGL(time_mlp_kernel, dim3(1, table_rows), dim3(256), 0, s, a);
     DMN_HIP_CHECK(hipGetLastError());
     return DMN_OK;
 }

@@ -126,8 +126,15 @@ struct TimeArgs {
     const float* wb; const float* bb;   // concatenated per-block linears, transposed [4dim][nout], [nout]
     int nout;
     float* out;             // [B][nout]
+    // The hidden vector behind the two dense layers depends on the label alone. A sampling loop knows all its labels
+    // beforehand: launch_time_hidden tabulates the vector for every table row (h2_out, [rows][4 dim]) before the loop,
+    // and the evaluations (h2 set, table mode) read their row instead of recomputing two dependent layers -- the same
+    // code produced the numbers, so the biases have the same bits.
+    const float* h2;
+    float* h2_out;
 };
 int launch_time_mlp(TimeArgs& a, hipStream_t s);
+int launch_time_hidden(TimeArgs& a, int table_rows, hipStream_t s);   // a.table, a.h2_out set; one workgroup per table row
 
 // 7x7 ingest: NCHW fp32 -> NHWC T, Cin <= 4
 struct IngestArgs {

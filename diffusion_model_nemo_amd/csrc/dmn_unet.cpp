@@ -861,6 +861,8 @@ int unet_forward_impl(DmnUnet* u, const float* x, const void* t, int t_is_float,
         ta.wb = u->twb; ta.bb = u->tbb;
         ta.nout = u->tb_total;
         ta.out = tb;
+        // a sampling loop has tabulated the hidden vectors of its table (unet_time_hidden_table)
+        if (t == nullptr && table != nullptr && table == u->h2_table_of) ta.h2 = u->h2_table;
     }
     const int tbs = tb_rows == 1 ? 0 : u->tb_total;
 
@@ -1502,6 +1504,7 @@ extern "C" void dmn_unet_destroy(DmnUnet* u) {
     for (auto e : u->probe_ev)
         if (e) (void)hipEventDestroy(e);
     if (u->step_trace) (void)hipFree(u->step_trace);
+    if (u->h2_table) (void)hipFree(u->h2_table);
     if (u->probe_stamps) (void)hipFree(u->probe_stamps);
     if (u->probe_acc) (void)hipFree(u->probe_acc);
     for (int c = 0; c < 2; ++c)
@@ -1679,6 +1682,36 @@ extern "C" int dmn_test_probe_site(DmnUnet* u, int site, double* shape) {
     u->graph_exec = u->graph_exec2 = nullptr;
     u->probe_site = site;
     return DMN_OK;
+}
+
+// The hidden vectors of the time path for every row of a sampling loop's table (TimeArgs::h2), computed by one launch
+// on `s` before the loop; the evaluations of the loop then skip the two dense layers. The buffer belongs to the handle
+// and only grows (never while a stream is capturing: the caller is a loop's entry). rows == 0 forgets the table.
+int unet_time_hidden_table(DmnUnet* u, const float* table, int rows, hipStream_t s) {
+    u->h2_table_of = nullptr;
+    if (!table || rows <= 0 || !u->cfg.with_time_emb || (u->path_mask & 32768) || rows > 65535) return DMN_OK;
+    const size_t need = (size_t)rows * 4 * u->cfg.dim;
+    if (need > u->h2_cap) {
+        DMN_HIP_CHECK(hipDeviceSynchronize());   // an earlier loop may still read the old buffer
+        if (u->h2_table) (void)hipFree(u->h2_table);
+        u->h2_table = nullptr;
+        u->h2_cap = 0;
+        DMN_HIP_CHECK(hipMalloc(&u->h2_table, need * sizeof(float)));
+        u->h2_cap = need;
+    }
+    TimeArgs ta;
+    memset(&ta, 0, sizeof(ta));
+    ta.table = table;
+    ta.table_cols = DMN_TABLE_COLS;
+    ta.label_col = 0;
+    ta.dim = u->cfg.dim;
+    ta.freqs = u->freqs;
+    ta.w1 = u->tw1; ta.b1 = u->tb1;
+    ta.w2 = u->tw2; ta.b2 = u->tb2;
+    ta.h2_out = u->h2_table;
+    int rc = launch_time_hidden(ta, rows, s);
+    if (rc == DMN_OK) u->h2_table_of = table;
+    return rc;
 }
 
 // Tuning aid: the 100 MHz clock at the start of every network evaluation, per launch chain (a ring of 8192 entries indexed

@@ -42,8 +42,9 @@ struct SampleKey {           // identifies a captured step graph
     long long img_offset;
     float snr;
     const void* labels;
+    const void* h2 = nullptr;   // the handle's table of time-path hidden vectors the captured evaluations read (or nullptr)
     bool operator==(const SampleKey& o) const {
-        return labels == o.labels && x == o.x && table == o.table && ws == o.ws && keep == o.keep && xmean == o.xmean && kind == o.kind &&
+        return labels == o.labels && h2 == o.h2 && x == o.x && table == o.table && ws == o.ws && keep == o.keep && xmean == o.xmean && kind == o.kind &&
                B == o.B && H == o.H && W == o.W && flags == o.flags && nsteps == o.nsteps && seed == o.seed &&
                img_offset == o.img_offset && snr == o.snr;
     }
@@ -120,6 +121,9 @@ struct DmnUnet {
                                          // of an evaluation stamps its phases instead of the dominant one (dmn_test_probe_read)
     long long* probe_stamps = nullptr;   // [2 chains][kProbeMaxWgs][8] per-workgroup stamps of the probed launch
     unsigned long long* probe_acc = nullptr;   // per chain {sum of spans in 10 ns ticks, launches}
+    float* h2_table = nullptr;           // hidden vectors of the time path for the rows of h2_table_of ([rows][4 dim])
+    size_t h2_cap = 0;                   // floats allocated
+    const float* h2_table_of = nullptr;  // the step table they were computed from (nullptr: none valid)
     long long* step_trace = nullptr;     // tuning aid (dmn_test_step_trace): [2 chains][8192] evaluation start clocks
     double probe_bytes = 0.0;            // algorithmic bytes of one probed launch
     double probe_shape[5] = {0, 0, 0, 0, 0};   // its multiply-add work (2 * images * output pixels * Cin * Cout * taps), Cin, Cout, output height, taps
@@ -160,6 +164,9 @@ int unet_reserve_handoff(DmnUnet* u, size_t bytes);
 // Accounts for `evals` coming network evaluations per chain; zeroes the granule areas on `s` first when the epoch bound
 // would pass the limit (see DmnUnet::epoch_used). Not inside a stream capture.
 int unet_epoch_reserve(DmnUnet* u, unsigned long long evals, hipStream_t s);
+// Tabulates the time path's hidden vectors for the `rows` rows of a sampling loop's step table (one launch on `s`); the
+// loop's evaluations then read their row. Called at every loop's entry (it also forgets the previous loop's table).
+int unet_time_hidden_table(DmnUnet* u, const float* table, int rows, hipStream_t s);
 // Process-wide registry of handles whose exchanging work (in-launch GroupNorm hand-offs) is being enqueued or still in
 // flight. enter: true when no OTHER handle has such work pending on the current device -- the caller may exchange and must
 // call leave(u, s) after its last launch on `s`; false: run without exchanges (set DmnUnet::exchange_off), no leave.

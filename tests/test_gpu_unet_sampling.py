@@ -916,6 +916,32 @@ def test_sampler_update_inside_the_last_kernel_gives_the_bits_of_its_own_launch(
     assert torch.equal(outs[0], outs[1])
 
 
+def test_time_path_tabulated_before_the_loop_gives_the_bits_of_the_in_step_form(monkeypatch):
+    """A sampling loop knows all its time labels beforehand: one launch before the loop tabulates the hidden vector of
+    the time MLP (modules/unet.py:74-79: sinusoid, two dense layers) for every table row, and the evaluations only apply
+    the per-block linears to their row. DMN_UNET_PATHS bit 15 keeps the whole path inside every evaluation. Same bits for
+    every kept image: DDPM (two chains and one, graph and eager), a loop with fewer steps behind one with more (the table
+    only grows), the predictor-corrector loop (two evaluations per row) and the bits-per-dimension evaluation."""
+    from diffusion_model_nemo_amd.modules import VESDE, GaussianDiffusion, PredictorCorrectorSampler
+    outs = []
+    for mask in (0, 32768):
+        if mask:
+            monkeypatch.setenv("DMN_UNET_PATHS", str(mask))
+        for dtype in ("bf16", "fp32"):
+            u = build_unet(dtype, groups=4)
+            for steps, shape, graph in ((12, (18, 3, 32, 32), True), (30, (18, 3, 32, 32), True), (12, (18, 3, 32, 32), False), (9, (3, 3, 32, 32), True)):
+                gd = GaussianDiffusion(timesteps=steps, schedule_name="cosine")
+                outs.append(torch.stack(gd.p_sample_loop(u, shape, device="cuda", seed=11, keep="all", use_graph=graph)))
+            s = PredictorCorrectorSampler(predictor="reverse_diffusion", corrector="langevin", snr=0.16, n_steps=1)
+            s.update_sde(VESDE(0.01, 50.0, 10))
+            outs.append(torch.stack(s.forward(u, [18, 3, 32, 32], "cuda", return_nfe=False, seed=5)))
+        if mask:
+            monkeypatch.delenv("DMN_UNET_PATHS")
+    n = len(outs) // 2
+    for i, (a, b) in enumerate(zip(outs[:n], outs[n:])):
+        assert torch.isfinite(a).all() and torch.equal(a, b), i
+
+
 def test_plan_batch_zero_plans_for_the_call_and_still_matches_oracle():
     """set_plan_batch(0): launch geometry chosen for the batch of each call (the small-batch tile and slice choices);
     same parity bar as the default."""
