@@ -279,8 +279,17 @@ static int run_loop(DmnUnet* u, const SampleKey& key_in, int nsteps, int evals, 
 }
 
 template <typename Body>
-static int run_loop_inner(DmnUnet* u, const SampleKey& key, int nsteps, hipStream_t s, int use_graph, int nchains, Body body) {
+static int run_loop_inner(DmnUnet* u, const SampleKey& key_in, int nsteps, hipStream_t s, int use_graph, int nchains, Body body) {
     int rc;
+    // steps per captured graph: a divisor of both the loop length and the pacing block
+    int K = 1;
+    if (use_graph && s != nullptr && u->loop_graph_steps > 1) {
+        const int blk = u->loop_pace > 0 ? u->loop_pace : 16;
+        for (int k = 1; k <= u->loop_graph_steps && k <= blk; ++k)
+            if (nsteps % k == 0 && blk % k == 0) K = k;
+    }
+    SampleKey key = key_in;
+    key.kind |= K << 20;
     hipStream_t cs[2] = {s, s};
     if (nchains == 2) {
         if ((rc = ensure_chain_streams(u))) return rc;
@@ -298,7 +307,8 @@ static int run_loop_inner(DmnUnet* u, const SampleKey& key, int nsteps, hipStrea
         for (int c = 0; c < nchains; ++c) {   // both steps are captured on the caller's stream; a graph runs on any stream
             hipGraph_t g = nullptr;
             DMN_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
-            rc = body(c, s);
+            rc = DMN_OK;
+            for (int k = 0; k < K && rc == DMN_OK; ++k) rc = body(c, s);
             hipError_t e = hipStreamEndCapture(s, &g);
             if (rc) {
                 if (g) (void)hipGraphDestroy(g);
@@ -332,7 +342,7 @@ static int run_loop_inner(DmnUnet* u, const SampleKey& key, int nsteps, hipStrea
         for (int k = 0; k < depth; ++k)
             for (int c = 0; c < nchains; ++c)
                 if (!u->ev_pace[k][c]) DMN_HIP_CHECK(hipEventCreateWithFlags(&u->ev_pace[k][c], hipEventDisableTiming));
-    for (int i = 0; i < nsteps; ++i) {
+    for (int i = 0; i < nsteps; i += K) {
         if (pace && i % pace == 0 && i >= depth * pace) {
             const int slot = (i / pace) % depth;   // recorded `depth` blocks ago
             for (int c = 0; c < nchains; ++c) DMN_HIP_CHECK(hipEventSynchronize(u->ev_pace[slot][c]));
@@ -341,20 +351,20 @@ static int run_loop_inner(DmnUnet* u, const SampleKey& key, int nsteps, hipStrea
             if (graph) DMN_HIP_CHECK(hipGraphLaunch(c ? u->graph_exec2 : u->graph_exec, cs[c]));
             else if ((rc = body(c, cs[c]))) return rc;
         }
-        if (pace && i % pace == pace - 1) {
+        if (pace && (i + K) % pace == 0) {
             const int slot = (i / pace) % depth;
             for (int c = 0; c < nchains; ++c) DMN_HIP_CHECK(hipEventRecord(u->ev_pace[slot][c], cs[c]));
             // Two chains run fastest in LOCKSTEP -- the same kernels side by side -- and slowest half a step apart
             // (733 against 750 us per step, tools/chain_phase.py); left alone they drift apart in about every second
             // loop. So each chain also waits, on the device, for the other one's end of the block: they start every
             // block together (the drift inside a block of 16 steps is a few hundredths of a step).
-            if (nchains == 2 && u->loop_lockstep && i + 1 < nsteps) {
+            if (nchains == 2 && u->loop_lockstep && i + K < nsteps) {
                 DMN_HIP_CHECK(hipStreamWaitEvent(cs[0], u->ev_pace[slot][1], 0));
                 DMN_HIP_CHECK(hipStreamWaitEvent(cs[1], u->ev_pace[slot][0], 0));
                 if (u->sample_skew_us > 0 && (rc = launch_delay(u->sample_skew_us, cs[1]))) return rc;   // tuning: a fixed lag
             }
         }
-        if (host_trace && (i % 50 == 49 || i == nsteps - 1)) {
+        if (K == 1 && host_trace && (i % 50 == 49 || i == nsteps - 1)) {
             const auto now = std::chrono::steady_clock::now();
             fprintf(stderr, "%s%.0f", i < 50 ? "loop host us per step:" : "", std::chrono::duration<double, std::micro>(now - t_block).count() / (i % 50 + 1));
             fprintf(stderr, i == nsteps - 1 ? "\n" : " ");
