@@ -46,6 +46,7 @@ SIGNATURES = {
     "dmn_test_probe_site": (_i, [_vp, _i, _vp]),
     "dmn_unet_chains_concurrent": (_i, [_vp, _vp]),
     "dmn_test_step_trace": (_i, [_vp, _i, _vp]),
+    "dmn_bench_launch_floor": (_i, [_i, _i, _i, _vp, _vp, _vp]),
     "dmn_unet_workspace_bytes": (_i, [_vp, _i, _i, _i, C.POINTER(_sz)]),
     "dmn_unet_forward": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "dmn_ddpm_step": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _u64, _i64, _vp]),

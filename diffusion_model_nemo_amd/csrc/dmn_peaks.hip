@@ -97,7 +97,33 @@ int timed(hipStream_t s, int iters, float* avg_ms, const F& launch) {
     return DMN_OK;
 }
 
+// one store per workgroup: what a dependent launch costs when it does nothing
+__global__ void __launch_bounds__(256) touch_kernel(float* sink) {
+    if (threadIdx.x == 0) sink[blockIdx.x] = (float)blockIdx.x;
+}
+
 }  // namespace
+
+// The floor under a launch chain: `launches` dependent launches of a kernel that does nothing (wgs workgroups of 256
+// threads, one store each), captured into one graph and replayed `iters` times on `stream` (not the legacy stream);
+// us_per_launch receives the average distance between two launches. sink: >= wgs floats.
+extern "C" int dmn_bench_launch_floor(int launches, int wgs, int iters, float* sink, void* stream, float* us_per_launch) {
+    DMN_REQUIRE(sink && us_per_launch && stream && launches > 0 && launches <= 4096 && wgs > 0 && wgs <= 65535 && iters > 0, DMN_ERR_INVALID,
+                "dmn_bench_launch_floor: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    DMN_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+    for (int i = 0; i < launches; ++i) touch_kernel<<<wgs, 256, 0, s>>>(sink);
+    DMN_HIP_CHECK(hipStreamEndCapture(s, &g));
+    DMN_HIP_CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(g);
+    float ms = 0.f;
+    int rc = timed(s, iters, &ms, [&] { (void)hipGraphLaunch(ge, s); });
+    (void)hipGraphExecDestroy(ge);
+    *us_per_launch = ms * 1e3f / launches;
+    return rc;
+}
 
 // mode 0: copy `bytes` from src to dst (traffic 2 x bytes per launch); mode 1: read `bytes` from src (dst: >= 4 bytes).
 extern "C" int dmn_bench_stream(int mode, void* dst, const void* src, size_t bytes, int iters, void* stream, float* avg_ms) {

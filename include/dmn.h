@@ -215,6 +215,10 @@ int dmn_unet_probe_result(DmnUnet* u, float* avg_ms, float* marker_ms, int* laun
  * No counterpart in the reference: measurement hooks used by bench.py. */
 int dmn_bench_stream(int mode, void* dst, const void* src, size_t bytes, int iters, void* stream, float* avg_ms);
 int dmn_bench_mfma(int kind, int wgs_per_cu, int n_outer, int iters, float* sink, void* stream, float* avg_ms, double* flops);
+/* The floor under a launch chain (no counterpart in the reference): `launches` dependent launches of a kernel that does
+ * nothing (wgs workgroups, one store each) captured into one graph and replayed `iters` times on `stream` (not the
+ * legacy stream); us_per_launch = average distance between two launches. sink: >= wgs floats. */
+int dmn_bench_launch_floor(int launches, int wgs, int iters, float* sink, void* stream, float* us_per_launch);
 
 /* Whether kernels launched on streams a and b run in turn because the runtime mapped both onto one hardware queue
  * (the device exposes few: four by default). A timing probe: two 300 us single-wave waits, twice; synchronises both
