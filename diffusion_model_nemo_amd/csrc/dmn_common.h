@@ -103,17 +103,20 @@ __device__ __forceinline__ float row16_max(float v) {
     v = fmaxf(v, dpp_move<0x140>(v));
     return v;
 }
+// Sum / max over the wave: the four row results are read as scalars (v_readlane, a few cycles each) and combined as
+// (r0 + r1) + (r2 + r3) -- the values and order of a butterfly over lanes xor 16, xor 32, without its two LDS-routed
+// permutes (~100 cycles each, one behind the other, at the very end of a kernel's epilogue).
 __device__ __forceinline__ float wave_sum(float v) {
-    v = row16_sum(v);
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
+    const int iv = __builtin_bit_cast(int, row16_sum(v));
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ float wave_max(float v) {
-    v = row16_max(v);
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    v = fmaxf(v, __shfl_xor(v, 32, 64));
-    return v;
+    const int iv = __builtin_bit_cast(int, row16_max(v));
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
 // ---- GroupNorm statistics as partial moments (layout, combination rule and rationale: dmn_norm.h) -----------------
