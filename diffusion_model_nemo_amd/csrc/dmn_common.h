@@ -147,10 +147,17 @@ __device__ __forceinline__ float moments_term(float s, float m2, float n, float 
 }
 
 // Sum over an aligned segment of `seg` lanes (16, 32 or 64), the same order-fixed result in every lane of the segment.
+// (seg is wave-uniform. Segments of 32 or 64 lanes combine the row results read as scalars, in the order of a butterfly
+// over lanes xor 16, xor 32.)
 __device__ __forceinline__ float seg_sum(float v, int seg) {
     v = row16_sum(v);
-    if (seg >= 32) v += __shfl_xor(v, 16, 64);
-    if (seg == 64) v += __shfl_xor(v, 32, 64);
+    if (seg >= 32) {
+        const int iv = __builtin_bit_cast(int, v);
+        const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+        const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+        const float lo = r0 + r1, hi = r2 + r3;
+        v = seg == 64 ? lo + hi : ((threadIdx.x & 32) ? hi : lo);
+    }
     return v;
 }
 
