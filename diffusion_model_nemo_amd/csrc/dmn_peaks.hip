@@ -102,6 +102,17 @@ __global__ void __launch_bounds__(256) touch_kernel(float* sink) {
     if (threadIdx.x == 0) sink[blockIdx.x] = (float)blockIdx.x;
 }
 
+// the same with 512 bytes of kernel arguments, of which the LAST word is needed before the store: what the size of an
+// argument block adds to a launch
+struct BigArgs {
+    float* sink;
+    int pad[125];
+    int last;
+};
+__global__ void __launch_bounds__(256) touch_big_kernel(const BigArgs a) {
+    if (threadIdx.x == 0) a.sink[blockIdx.x] = (float)(blockIdx.x + a.last);
+}
+
 }  // namespace
 
 // The floor under a launch chain: `launches` dependent launches of a kernel that does nothing (wgs workgroups of 256
@@ -114,7 +125,15 @@ extern "C" int dmn_bench_launch_floor(int launches, int wgs, int iters, float* s
     hipGraph_t g = nullptr;
     hipGraphExec_t ge = nullptr;
     DMN_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
-    for (int i = 0; i < launches; ++i) touch_kernel<<<wgs, 256, 0, s>>>(sink);
+    BigArgs big;
+    memset(&big, 0, sizeof(big));
+    big.sink = sink;
+    const bool use_big = getenv("DMN_FLOOR_BIG_ARGS") != nullptr;   // 512-byte argument block instead of one pointer
+    for (int i = 0; i < launches; ++i) {
+        big.last = i;
+        if (use_big) touch_big_kernel<<<wgs, 256, 0, s>>>(big);
+        else touch_kernel<<<wgs, 256, 0, s>>>(sink);
+    }
     DMN_HIP_CHECK(hipStreamEndCapture(s, &g));
     DMN_HIP_CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
     (void)hipGraphDestroy(g);
