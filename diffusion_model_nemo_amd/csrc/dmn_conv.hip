@@ -213,10 +213,21 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
     // the statistics and channel parameters of the normalising prologue are requested AHEAD of the halo tile: vector loads
     // return in order, so the coefficient round trip (load, cross-lane combination, LDS, barrier) runs while the halo
     // pixels are still on their way instead of behind them
+    // One staged channel group (the rule): a thread normalises the same PER channels of every pixel and keeps their
+    // coefficients in registers (norm_direct_*: one barrier less and no round trip through LDS at the head of the launch).
+    const bool direct = PRO && a.pro_direct;
     NormLoads nl;
-    if (PRO) norm_issue(a.pro, b, Cin, nl);
+    NormDirect<PER> nd;
+    float dca[PER], dcb[PER], dct[PER];
+    if (PRO) {
+        if (direct) norm_direct_issue<PER>(a.pro, b, part * PER, nd);
+        else norm_issue(a.pro, b, Cin, nl);
+    }
     stage_issue(0, 0);
-    if (PRO) norm_finish(a.pro, b, Cin, nl, sCoef, sTmp);
+    if (PRO) {
+        if (direct) norm_direct_finish<PER>(a.pro, b, Cin, part * PER, nd, sTmp, dca, dcb, dct);
+        else norm_finish(a.pro, b, Cin, nl, sCoef, sTmp);
+    }
     DMN_STAMP(1)
 
     f32x4 acc[MT][NT];
@@ -237,9 +248,9 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
             if (PRO) {
 #pragma unroll
                 for (int e = 0; e < PER; ++e) {
-                    ca[e] = sCoef[c + e];
-                    cb[e] = sCoef[Cin + c + e];
-                    ct[e] = sCoef[2 * Cin + c + e];
+                    ca[e] = direct ? dca[e] : sCoef[c + e];
+                    cb[e] = direct ? dcb[e] : sCoef[Cin + c + e];
+                    ct[e] = direct ? dct[e] : sCoef[2 * Cin + c + e];
                 }
             }
             for (int j0 = 0; j0 < nunits; j0 += SB) {
@@ -1031,6 +1042,10 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
     DMN_REQUIRE(a.cg == Cin || (a.cg / kch) % 4 == 0, DMN_ERR_INVALID, "conv: channel group %d too small for %d channels", a.cg, Cin);
     a.lg_upp = 0;
     while ((1 << a.lg_upp) < upp) ++a.lg_upp;
+    // coefficients per thread, without a barrier: one staged channel group, 16-byte aligned parameter vectors
+    static const bool lds_coefs = getenv("DMN_CONV_LDS_COEFS") != nullptr;   // A/B: the coefficients through LDS everywhere
+    a.pro_direct = a.pro.stats && a.cg == Cin && !lds_coefs && (Cin / a.pro.G) % 4 == 0 &&
+                   (((uintptr_t)a.pro.gamma | (uintptr_t)a.pro.beta | (uintptr_t)a.pro.tbias) & 15) == 0 && (a.pro.tb_stride & 3) == 0;
     DMN_REQUIRE((long long)a.B * a.H * a.W * (a.C0 > a.C1 ? a.C0 : a.C1) < (1ll << 31), DMN_ERR_LIMIT,
                 "conv: input tensor beyond 2^31 elements");
     DMN_REQUIRE((long long)a.B * a.out_H * a.out_W * a.Cout < (1ll << 31), DMN_ERR_LIMIT, "conv: output tensor beyond 2^31 elements");

@@ -60,6 +60,7 @@ struct ConvArgs {
     void* pro_out;        // optional with pro_res: receives the resulting tensor (same shape as in0)
     const void* res;      // optional residual added in the epilogue, same shape as out
     NormOut epi;          // statistics of the output after bias (taken before the residual add)
+    int pro_direct;          // set by the launcher: the prologue's coefficients are formed per thread (dmn_norm.h: norm_direct_*)
     int epi_wgs;          // workgroups that touch one group of an image (1: a workgroup holds whole groups); set by the launcher
     const void* w2;       // optional fused 1x1 convolution of the same input (3x3 kind, no input normalisation):
     const float* bias2;   //   weights packed like `w` with one tap, bias [Cout],

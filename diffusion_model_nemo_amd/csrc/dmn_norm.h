@@ -152,3 +152,57 @@ __device__ __forceinline__ void norm_coefs_to_lds(const NormIn& n, int b, int C,
     norm_issue(n, b, C, L);
     norm_finish(n, b, C, L, sCoef, sTmp);
 }
+
+// ---- the coefficients in registers -------------------------------------------------------------------------------------
+// A thread that normalises PER consecutive channels c0 .. c0 + PER - 1 of every pixel it stages (the convolution's
+// prologue) can keep their coefficients in registers: the groups are combined as in norm_finish (split over the waves),
+// and after ONE barrier every thread picks mean / rstd of the groups of its channels from sTmp. Against norm_finish this
+// removes the second barrier and the round trip of the coefficients through LDS. Same arithmetic: same bits.
+template <int PER>
+struct NormDirect {
+    f32x4 v[kCombineKeep];
+    f32x4 pg[PER / 4], pb[PER / 4], pt[PER / 4];
+};
+// gamma, beta and (when given) tbias + b * tb_stride must be 16-byte aligned, c0 a multiple of 4, c0 + PER <= C.
+template <int PER>
+__device__ __forceinline__ void norm_direct_issue(const NormIn& n, int b, int c0, NormDirect<PER>& L) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int seg = combine_seg(n.slots);
+    const int sl = lane & (seg - 1);
+    const int g = wave * (64 / seg) + lane / seg;
+    const f32x4* p = reinterpret_cast<const f32x4*>(n.stats) + ((size_t)b * n.G + (g < n.G ? g : n.G - 1)) * n.slots;
+#pragma unroll
+    for (int k = 0; k < kCombineKeep; ++k) {
+        const int i = sl + k * seg;
+        L.v[k] = p[i < n.slots ? i : n.slots - 1];
+    }
+    const float* tb = n.tbias ? n.tbias + (size_t)b * n.tb_stride : n.gamma;   // any mapped address when there is none
+#pragma unroll
+    for (int q = 0; q < PER / 4; ++q) {
+        L.pg[q] = *reinterpret_cast<const f32x4*>(n.gamma + c0 + 4 * q);
+        L.pb[q] = *reinterpret_cast<const f32x4*>(n.beta + c0 + 4 * q);
+        L.pt[q] = *reinterpret_cast<const f32x4*>(tb + c0 + 4 * q);
+    }
+}
+// sTmp: 2 * G floats. ca / cb / ct: y = x * ca + cb (then the activation, then + ct). Contains one __syncthreads().
+template <int PER>
+__device__ __forceinline__ void norm_direct_finish(const NormIn& n, int b, int C, int c0, const NormDirect<PER>& L, float* sTmp,
+                                                   float (&ca)[PER], float (&cb)[PER], float (&ct)[PER]) {
+    const int slots = n.slots;
+    const f32x4* base = reinterpret_cast<const f32x4*>(n.stats) + (size_t)b * n.G * slots;
+    combine_groups(n.G, slots, n.inv_count, sTmp, [&](int g, int i) { return base[(size_t)g * slots + i]; }, L.v);
+    __syncthreads();
+    const int cpg = C / n.G;
+#pragma unroll
+    for (int q = 0; q < PER / 4; ++q) {
+        const int g = (c0 + 4 * q) / cpg;   // a quad of channels never straddles a group (groups hold a multiple of 4)
+        const float mean = sTmp[2 * g], rstd = sTmp[2 * g + 1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float aa = rstd * L.pg[q][e];
+            ca[4 * q + e] = aa;
+            cb[4 * q + e] = L.pb[q][e] - mean * aa;
+            ct[4 * q + e] = n.tbias ? L.pt[q][e] : 0.f;
+        }
+    }
+}

@@ -1,6 +1,7 @@
 // Measured ceilings of the device the library runs on: a streaming copy (HBM read + write) and register-resident
 // matrix-core loops. They put the nominal 8 TB/s / 2.5 PFLOP/s figures next to what this part sustains, so that a
 // roofline fraction can be quoted against either. No counterpart in the reference: measurement hooks used by bench.py.
+#include <cstring>
 #include "dmn_common.h"
 
 namespace {
