@@ -271,7 +271,7 @@ static int run_loop(DmnUnet* u, const SampleKey& key_in, int nsteps, int evals, 
     }
     if (rc == DMN_OK) rc = run_loop_inner(u, key, nsteps, s, use_graph, nchains, body);
     u->exchange_off = false;
-    if (entered) exchange_guard_leave(u, s);   // behind the join: both chains have been enqueued on or joined to `s`
+    if (want_exchange) exchange_guard_leave(u, s, entered);   // behind the join: both chains have been enqueued on or joined to `s`
     if (rc) return rc;
     DMN_HIP_CHECK(hipEventRecord(u->ev_stop, s));
     u->ev_valid = true;

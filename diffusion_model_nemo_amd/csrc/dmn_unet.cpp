@@ -755,9 +755,11 @@ namespace {
 struct GuardEntry {
     DmnUnet* u;
     int device;
-    bool enqueuing;        // its host call is still issuing launches
+    bool in_call;          // a host call of the handle is issuing launches (and may be capturing its stream)
+    bool enqueuing;        // ... and those launches exchange
     bool pending;          // `done` has been recorded and not yet been seen complete
     hipEvent_t done;
+    hipStream_t done_on;   // the stream `done` was last recorded on
 };
 std::mutex g_guard_mu;
 std::vector<GuardEntry> g_guard;
@@ -775,27 +777,40 @@ bool exchange_guard_enter(DmnUnet* u) {
             continue;
         }
         if (e.device != dev) continue;
-        if (e.pending && hipEventQuery(e.done) == hipSuccess) e.pending = false;
+        // An event may not be queried while the stream it was last recorded on is being captured: the query fails, its
+        // error stays behind in this thread, and the other thread's capture is invalidated. A handle captures only
+        // inside its own calls (in_call); a caller's own capture around dmn_unet_forward shows in the stream's state.
+        // Either way the entry then counts as still pending.
+        if (e.pending && !e.in_call) {
+            hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(e.done_on, &st) == hipSuccess && st == hipStreamCaptureStatusNone && hipEventQuery(e.done) == hipSuccess)
+                e.pending = false;
+            (void)hipGetLastError();   // "not ready" is an answer, not a failure of this thread's next launch
+        }
         if (e.enqueuing || e.pending) busy = true;
     }
-    if (busy) return false;
     if (!mine) {
-        g_guard.push_back(GuardEntry{u, dev, false, false, nullptr});
+        g_guard.push_back(GuardEntry{u, dev, false, false, false, nullptr, nullptr});
         mine = &g_guard.back();
     }
     mine->device = dev;
-    mine->enqueuing = true;
-    return true;
+    mine->in_call = true;
+    mine->enqueuing = !busy;
+    return !busy;
 }
 
-void exchange_guard_leave(DmnUnet* u, hipStream_t s) {
+// `entered`: what exchange_guard_enter returned for this call (every enter is followed by one leave).
+void exchange_guard_leave(DmnUnet* u, hipStream_t s, bool entered) {
     std::lock_guard<std::mutex> lock(g_guard_mu);
     for (auto& e : g_guard)
         if (e.u == u) {
+            e.in_call = false;
             e.enqueuing = false;
+            if (!entered) return;   // nothing of this call exchanges; an earlier call's event stays as it is
             if (!e.done && hipEventCreateWithFlags(&e.done, hipEventDisableTiming) != hipSuccess) e.done = nullptr;
             // without an event the work cannot be followed: it then counts as finished (the spins stay bounded)
             e.pending = e.done && hipEventRecord(e.done, s) == hipSuccess;
+            e.done_on = s;
             return;
         }
 }
@@ -1771,12 +1786,12 @@ extern "C" int dmn_unet_forward(DmnUnet* u, const float* x, const void* t, int t
         const int rc = unet_epoch_reserve(u, 1, s);
         if (rc) {
             u->exchange_off = false;
-            if (entered) exchange_guard_leave(u, s);
+            exchange_guard_leave(u, s, entered);
             return rc;
         }
     }
     const int rc = unet_forward_impl(u, x, t, t_is_float, nullptr, nullptr, out, B, H, W, workspace, workspace_bytes, s, false, nullptr);
     u->exchange_off = false;
-    if (entered) exchange_guard_leave(u, s);
+    if (!capturing && !(u->path_mask & 128)) exchange_guard_leave(u, s, entered);
     return rc;
 }

@@ -172,5 +172,5 @@ int unet_time_hidden_table(DmnUnet* u, const float* table, int rows, hipStream_t
 // flight. enter: true when no OTHER handle has such work pending on the current device -- the caller may exchange and must
 // call leave(u, s) after its last launch on `s`; false: run without exchanges (set DmnUnet::exchange_off), no leave.
 bool exchange_guard_enter(DmnUnet* u);
-void exchange_guard_leave(DmnUnet* u, hipStream_t s);
+void exchange_guard_leave(DmnUnet* u, hipStream_t s, bool entered);
 void exchange_guard_forget(DmnUnet* u);   // handle destruction
