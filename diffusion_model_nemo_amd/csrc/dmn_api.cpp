@@ -673,7 +673,8 @@ extern "C" int dmn_test_conv2d(int dtype, const void* in0, const void* in1, int 
 
 // block2.proj of a ResnetBlock together with the block's closing SiLU(GroupNorm(h)) + res on caller-provided tensors
 // (unit parity tests, tuning): fused = 1 runs the one-launch form with the in-launch statistics hand-off, fused = 0 the
-// convolution followed by the stand-alone closing pass (h2 [B][H][W][Cout] is its intermediate). out_stats_dev receives
+// convolution followed by the stand-alone closing pass (h2 [B][H][W][Cout] is its intermediate); + 2 (either form):
+// full-resolution images take the 32x16-pixel tiles that bring them under the hand-off's limit, as the network does. out_stats_dev receives
 // [B][out_G][slots][2] partial statistics of `out` (slots returned in out_slots). The launch may stamp phase times
 // into the buffer set by dmn_test_set_conv_debug.
 extern "C" int dmn_test_conv_block_tail(int dtype, const void* in, int Cin, int B, int H, int W, const float* w_host,
@@ -682,7 +683,7 @@ extern "C" int dmn_test_conv_block_tail(int dtype, const void* in, int Cin, int 
                                         const float* tail_gamma_host, const float* tail_beta_host, int G, const void* res,
                                         void* h2, void* out, float* out_stats_dev, int out_G, int* out_slots, int fused,
                                         int plan_B, int cfg_tile, int cfg_bn, unsigned* giveups, void* stream) {
-    DMN_REQUIRE(in && w_host && pro_stats_dev && tail_gamma_host && tail_beta_host && res && out && (fused || h2), DMN_ERR_INVALID,
+    DMN_REQUIRE(in && w_host && pro_stats_dev && tail_gamma_host && tail_beta_host && res && out && ((fused & 1) || h2), DMN_ERR_INVALID,
                 "dmn_test_conv_block_tail: null argument");
     int rc = conv_init_attributes();
     if (rc) return rc;
@@ -713,6 +714,7 @@ extern "C" int dmn_test_conv_block_tail(int dtype, const void* in, int Cin, int 
     a.plan_B = plan_B;
     a.cfg_tile = cfg_tile;
     a.cfg_bn = cfg_bn;
+    a.tall_tail = (fused & 2) != 0;
     a.pro.stats = pro_stats_dev;
     a.pro.G = pro_G;
     a.pro.slots = pro_slots;
@@ -723,7 +725,7 @@ extern "C" int dmn_test_conv_block_tail(int dtype, const void* in, int Cin, int 
     a.epi.G = G;
     const float inv_count = 1.0f / ((float)(Cout / G) * H * W);
     if (giveups) *giveups = 0;
-    if (fused) {
+    if (fused & 1) {
         const size_t bytes = kHandoffHeaderBytes + (size_t)B * G * conv_epi_slots(a) * kHandoffGranulesPerSlot * sizeof(unsigned long long);
         unsigned hdr[2] = {1u, 0u};   // epoch 1 over a zeroed area
         if (!conv_tail_fits(a) || hipMalloc(&area, bytes) != hipSuccess || hipMemset(area, 0, bytes) != hipSuccess ||

@@ -42,9 +42,9 @@ constexpr int kLdsSlack = 512; // fragment reads of skipped k-steps may run past
 
 // 3x3 tap (dy * 3 + dx) of ring entry e = dx * 3 + i: dx outer; inside a column the 8-wide tiles take dy = 0, 2, 1
 // (both even rows pairs first), the 16-wide tiles dy = 0, 1, 2.
-template <int TH> __host__ __device__ constexpr int k3_tap(int e) {
+template <int TW> __host__ __device__ constexpr int k3_tap(int e) {
     const int dx = e / 3, i = e % 3;
-    const int dy = TH == 16 ? i : (i == 0 ? 0 : i == 1 ? 2 : 1);
+    const int dy = TW == 16 ? i : (i == 0 ? 0 : i == 1 ? 2 : 1);
     return dy * 3 + dx;
 }
 
@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
     // weight ring depth: the 16x16-pixel tiles run at high occupancy and only look RS fragments ahead (few
     // registers, latency hidden by the other waves); the 8x8 tiles of the wide layers run one workgroup per CU
     // and keep a whole iteration in flight
-    constexpr int RS = TH == 16 ? (NTAPS == 9 ? 3 : (E >= 4 ? 4 : E)) : E;
+    constexpr int RS = TW == 16 ? (NTAPS == 9 ? 3 : (E >= 4 ? 4 : E)) : E;
     static_assert(E % RS == 0, "ring depth must divide the iteration");
     constexpr int BM = TH * TW;
     constexpr int MT = BM / (16 * WM);
@@ -89,7 +89,8 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
     constexpr int IH = (TH - 1) * S + KT::EXT, IW = (TW - 1) * S + KT::EXT;
     constexpr int NPIX = IH * IW;
     constexpr int SB = TH == 8 ? 8 : 6;             // staging loads in flight per thread (8x8 tiles: 100 halo pixels of
-                                                    // 128 / 256 channels are 7 / 13 units per thread: one / two batches)
+                                                    // 128 / 256 channels are 7 / 13 units per thread: one / two batches;
+                                                    // the 10 units of a 32x16 tile in one batch measured 1 % slower per step)
     using V = decltype(Vec16<T>::v);
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -145,7 +146,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
     // 3x3: the taps of a k-step are visited column by column (dx outer) so that the pixel fragments read from LDS for
     // one dx serve all three dy (see the MFMA loop); ring entry e of a k-step is tap k3_tap(e).
     auto ring_fill3 = [&](int slot, int ks, int e) {   // e may run past 8 into the following k-steps
-        ring_fill(slot, (ks + e / 9) * 9 + k3_tap<TH>(e % 9));
+        ring_fill(slot, (ks + e / 9) * 9 + k3_tap<TW>(e % 9));
     };
 #pragma unroll
     for (int e = 0; e < RS; ++e) {
@@ -329,7 +330,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
                         const int e = dx * 3 + i;
-                        const int dy = k3_tap<TH>(e) / 3;
+                        const int dy = k3_tap<TW>(e) / 3;
                         Vec16<T> wv[NT];
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) wv[nt].v = w[e % RS][nt];
@@ -776,6 +777,13 @@ TileCfg pick_cfg(const ConvArgs& a) {
         (c.th == 16 || tiles8 == 1 || tiles8 * (a.Cout / 32) <= kHandoffMaxWgsPerImage))
         c.bn = 32;
     if (a.w2 && c.th == 16 && c.bn == 64) c.th = c.tw = 8;   // two accumulator sets: keep the per-wave tile small
+    // A launch that wants to close its ResnetBlock itself (tall_tail) but has too many 16x16 tiles per image for the
+    // in-launch exchange takes tiles of 32 rows x 16 columns when those fit: full-resolution images (64x64: 8
+    // workgroups per image instead of 16) then need no closing pass either.
+    if (a.tall_tail && a.kind == DMN_K3X3 && !a.w2 && c.th == 16 && c.bn == 32 && a.Cout == 32) {
+        const int t16 = ((a.Ho + 15) / 16) * ((a.Wo + 15) / 16), t32 = ((a.Ho + 31) / 32) * ((a.Wo + 15) / 16);
+        if (t16 > kHandoffMaxWgsPerImage && t32 <= kHandoffMaxWgsPerImage) c.th = 32;
+    }
     return c;
 }
 
@@ -808,6 +816,9 @@ int pick_cg(const ConvArgs& a, const TileCfg& c) {
 // pixels and split the output channels when there are 64 of them
 template <typename T, int KIND, int PRO>
 int dispatch_tile(const ConvArgs& a, const TileCfg& c, size_t lds, hipStream_t s) {
+    if constexpr (KIND == DMN_K3X3 && PRO == 2) {   // the tall tile without the tail: the two-launch form of the same partition
+        if (c.th == 32 && c.tw == 16 && c.bn == 32) return launch_cfg<T, KIND, 32, 16, 32, 4, 1, PRO>(a, lds, s);
+    }
     if constexpr (KIND != DMN_K4X4S2) {
         if (c.th == 16 && c.bn == 32) return launch_cfg<T, KIND, 16, 16, 32, 2, 2, PRO>(a, lds, s);
         if (c.th == 16 && c.bn == 64) return launch_cfg<T, KIND, 16, 16, 64, 2, 2, PRO>(a, lds, s);
@@ -836,6 +847,7 @@ int dispatch_fused_tail(const ConvArgs& a, const TileCfg& c, size_t lds, hipStre
         dmn_set_error("conv: no fused-tail kernel without prologue for tile %dx%d / %d", c.th, c.tw, c.bn);
         return DMN_ERR_INVALID;
     }
+    if (c.th == 32 && c.tw == 16 && c.bn == 32) return launch_cfg<T, DMN_K3X3, 32, 16, 32, 4, 1, 2, false, true>(a, lds, s);
     if (c.th == 16 && c.bn == 32) return launch_cfg<T, DMN_K3X3, 16, 16, 32, 2, 2, 2, false, true>(a, lds, s);
     if (c.th == 16 && c.bn == 64) return launch_cfg<T, DMN_K3X3, 16, 16, 64, 2, 2, 2, false, true>(a, lds, s);
     if (c.th == 8 && c.bn == 32) return launch_cfg<T, DMN_K3X3, 8, 8, 32, 2, 2, 2, false, true>(a, lds, s);
@@ -847,6 +859,10 @@ int dispatch_fused_tail(const ConvArgs& a, const TileCfg& c, size_t lds, hipStre
 template <typename T>
 int dispatch(const ConvArgs& a, const TileCfg& c, size_t lds, hipStream_t s) {
     const int pro = a.pro.stats ? (a.pro_res ? 3 : a.pro.silu ? 2 : 1) : 0;
+    if (c.th == 32 && !(pro == 2 && a.kind == DMN_K3X3 && !a.w2)) {
+        dmn_set_error("conv: the 32x16 tile only serves block2.proj (3x3 with the GroupNorm + SiLU prologue)");
+        return DMN_ERR_INVALID;
+    }
     if (a.tail.gran) {
         if (a.kind != DMN_K3X3 || (pro != 2 && pro != 0) || a.w2 || a.C1) {
             dmn_set_error("conv: the fused block tail needs a single-source 3x3 convolution with the GroupNorm + SiLU prologue "
@@ -931,6 +947,8 @@ int set_attr_all() {
     if ((rc = set_attr<T, DMN_K3X3, 16, 16, 32, 2, 2, 0, true>())) return rc;
     if ((rc = set_attr<T, DMN_K3X3, 8, 8, 32, 2, 2, 0, true>())) return rc;
     if ((rc = set_attr<T, DMN_K3X3, 8, 8, 64, 1, 4, 0, true>())) return rc;
+    if ((rc = set_attr<T, DMN_K3X3, 32, 16, 32, 4, 1, 2, false, true>())) return rc;
+    if ((rc = set_attr<T, DMN_K3X3, 32, 16, 32, 4, 1, 2>())) return rc;
     if ((rc = set_attr<T, DMN_K3X3, 16, 16, 32, 2, 2, 2, false, true>())) return rc;
     if ((rc = set_attr<T, DMN_K3X3, 16, 16, 64, 2, 2, 2, false, true>())) return rc;
     if ((rc = set_attr<T, DMN_K3X3, 8, 8, 32, 2, 2, 2, false, true>())) return rc;
@@ -957,7 +975,7 @@ int conv_init_attributes() {
 }
 
 // partials per (image, group): one per workgroup that touches the group, wave row and 4-channel quad of the group inside it
-static int rows_per_wg(const TileCfg& c) { return (c.th == 8 && c.bn == 64) ? 1 : 2; }   // WM of the kernel that serves the tile
+static int rows_per_wg(const TileCfg& c) { return c.th == 32 ? 4 : (c.th == 8 && c.bn == 64) ? 1 : 2; }   // WM of the kernel that serves the tile
 static int slots_for_groups(const ConvArgs& a, int G) {
     const TileCfg c = pick_cfg(a);
     const int tiles = ((a.Ho + c.th - 1) / c.th) * ((a.Wo + c.tw - 1) / c.tw);

@@ -84,6 +84,8 @@ struct ConvArgs {
     float act_inv_count;       // 1 / elements per (image, group)
     int cg, lg_upp;       // channels staged per group and log2 of its 16-byte units per pixel; set by the launcher
     long long* dbg;       // optional [workgroups][8] phase timestamps (tuning aid; nullptr in production)
+    int tall_tail;        // the launch is meant to close its ResnetBlock (tail): 32x16-pixel tiles where 16x16 leave an image
+                          // too many workgroups for the in-launch exchange
     int cfg_tile, cfg_bn; // 0 = choose automatically; otherwise force the pixel tile (8 or 16) / channel tile (32 or 64)
     int plan_B;           // batch the tile heuristic plans for (0: B). A fixed value makes the choice -- and with it the
                           // order in which GroupNorm partial sums are formed -- independent of how a batch is sharded

@@ -321,7 +321,8 @@ int dmn_test_conv2d(int dtype, const void* in0, const void* in1, int C0, int C1,
 /* block2.proj of a ResnetBlock with the block's closing SiLU(GroupNorm(h)) + res (parts/convnext.py:81-86) on
  * caller-provided device tensors: fused = 1 in one launch (partial sums exchanged inside it), fused = 0 as the
  * convolution followed by the separate closing pass (h2: its intermediate). Both forms give the same bits in `out`.
- * Shapes outside the exchange's limits (more than 8 workgroups per image) return an error for fused = 1. */
+ * Shapes outside the exchange's limits (more than 8 workgroups per image) return an error for fused = 1; + 2 (either
+ * form) lets 32-channel images of up to 8 tiles of 32 x 16 pixels (64x64) take those tiles, as the network does. */
 int dmn_test_conv_block_tail(int dtype, const void* in, int Cin, int B, int H, int W, const float* w_host,
                              const float* bias_host, int Cout, const float* pro_gamma_host, const float* pro_beta_host,
                              const float* pro_stats_dev, int pro_G, int pro_slots, const float* tail_gamma_host,

@@ -382,6 +382,11 @@ def test_block_tail_keeps_parity_when_group_means_dwarf_the_spread(B, H, W, C_, 
     (4, 8, 8, 256, 2, 1, 0, 0),       # groups of 128 channels: two workgroups per group
     (3, 24, 16, 64, 8, 1, 0, 0),      # ragged tiles
     (3, 32, 32, 32, 8, 1, 0, 0),      # the decoder's last level
+    (4, 64, 64, 32, 8, 1, -1, 0),     # full resolution (tile -1: 32x16-pixel tiles allowed): 8 workgroups per image
+    (3, 64, 64, 32, 8, 8, -1, 0),     # ... with the output's statistics in 8 groups (what the egress normalises with)
+    (40, 64, 64, 32, 4, 1, -1, 0),    # more images than one launch takes
+    (3, 48, 40, 32, 8, 1, -1, 0),     # ragged 32x16 tiles (2 x 3 per image)
+    (2, 40, 56, 32, 8, 8, -1, 0),
 ])
 def test_block_tail_inside_the_convolution_equals_the_two_launch_form(dtype, B, H, W, C_, G, out_G, tile, bn):
     """The ResnetBlock tail computed by block2.proj itself (GroupNorm partial sums exchanged between the workgroups of
@@ -389,13 +394,16 @@ def test_block_tail_inside_the_convolution_equals_the_two_launch_form(dtype, B, 
     that agree to summation order; repeated launches agree with themselves (no stale partial sum is ever read)."""
     # a waiting workgroup may need at most half a CU's LDS: an fp32 halo tile beyond that
     # (e.g. 64 channels at 16x16 pixels: 93 KB, 256 channels at 8x8: 105 KB) is refused where workgroups would have to wait
+    fused = 1
+    if tile < 0:
+        fused, tile = 3, 0
     try:
-        a, sa, give = _block_tail(dtype, B, H, W, C_, G, out_G, 1, tile=tile, bn=bn)
+        a, sa, give = _block_tail(dtype, B, H, W, C_, G, out_G, fused, tile=tile, bn=bn)
     except _N().DmnError:
-        halo = 324 if min(H, W) >= 32 else 100
+        halo = 612 if fused == 3 else 324 if min(H, W) >= 32 else 100
         assert dtype == 0 and halo * (C_ * 4 + 32) > 80 * 1024
         return
-    b, sb, _ = _block_tail(dtype, B, H, W, C_, G, out_G, 0, tile=tile, bn=bn)
+    b, sb, _ = _block_tail(dtype, B, H, W, C_, G, out_G, fused & 2, tile=tile, bn=bn)   # same tiles, separate closing pass
     assert give == 0
     assert torch.equal(a, b), float((a.float() - b.float()).abs().max())
     assert float((sa - sb).abs().max()) <= 1e-5 * float(sb.abs().max())
@@ -405,7 +413,7 @@ def test_block_tail_inside_the_convolution_equals_the_two_launch_form(dtype, B, 
     assert torch.equal(sa[..., 2], want[..., 2])
     assert float((sa - want).abs().max()) <= 1e-4 * float(want.abs().max())
     for _ in range(5):
-        again, _, give = _block_tail(dtype, B, H, W, C_, G, out_G, 1, tile=tile, bn=bn)
+        again, _, give = _block_tail(dtype, B, H, W, C_, G, out_G, fused, tile=tile, bn=bn)
         assert give == 0 and torch.equal(again, a)
 
 

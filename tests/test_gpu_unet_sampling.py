@@ -828,12 +828,14 @@ def test_alternative_launch_paths_give_the_same_bits(monkeypatch):
     4096 leaves block1's GroupNorm + SiLU + time bias at the 8x8 levels to the convolution behind it instead of
     block1.proj's epilogue: same statistics, coefficients and arithmetic. 8192 leaves the tail of a level's first block
     to the next block's first convolution instead of block2.proj's own epilogue (16384: only where that needs an exchange):
-    the consumer adds the residual inside the fused multiply-add of the SiLU, the producer after it -- bf16 noise."""
+    the consumer adds the residual inside the fused multiply-add of the SiLU, the producer after it -- bf16 noise.
+    131072 closes the full-resolution blocks by the separate pass over 16x16-pixel tiles instead of inside block2.proj
+    over 32x16-pixel tiles: the same partial sums combined in another order -- bf16 noise."""
     g = torch.Generator(device="cuda").manual_seed(4)
     x = torch.randn(4, 3, 64, 64, device="cuda", generator=g)
     t = torch.tensor([3, 500, 999, 40], device="cuda")
     ref = build_unet64("bf16")(x, t)
-    for mask, exact in ((1, True), (16, True), (16 | 32, True), (1024, True), (4096, True), (4, False), (8192, False), (16384, False), (2, False), (8, False), (128, False)):
+    for mask, exact in ((1, True), (16, True), (16 | 32, True), (1024, True), (4096, True), (4, False), (8192, False), (16384, False), (2, False), (8, False), (128, False), (131072, False)):
         monkeypatch.setenv("DMN_UNET_PATHS", str(mask))
         y = build_unet64("bf16")(x, t)
         monkeypatch.delenv("DMN_UNET_PATHS")
