@@ -14,7 +14,7 @@ sys.path.insert(0, ".")
 from diffusion_model_nemo_amd import _native as N  # noqa: E402
 
 
-def run(name, B, H, C_, G, dtype=1, out_G=1, plan_B=64):
+def run(name, B, H, C_, G, dtype=1, out_G=1, plan_B=64, tall=0):
     lib = N.lib()
     g = torch.Generator().manual_seed(1)
     tdt = torch.bfloat16 if dtype == 1 else torch.float32
@@ -31,13 +31,13 @@ def run(name, B, H, C_, G, dtype=1, out_G=1, plan_B=64):
     pst = st.cuda()
     outs, stats, spans = [], [], []
     dbg = torch.zeros((1 << 16, 8), dtype=torch.int64, device="cuda")
-    for fused in (1, 0):
+    for fused in (1 + tall, tall):   # tall = 2: 32x16-pixel tiles in both forms
         out = torch.zeros((B, H, H, C_), device="cuda", dtype=tdt)
         h2 = torch.zeros((B, H, H, C_), device="cuda", dtype=tdt)
         ost = torch.zeros((B * out_G * 4096 * 4,), device="cuda")
         slots, give = C.c_int(0), C.c_uint(0)
         N.check(lib.dmn_test_set_conv_debug(dbg.data_ptr()))
-        if fused:   # shapes outside the exchange's limits (workgroups per image, LDS per workgroup) are refused
+        if fused & 1:   # shapes outside the exchange's limits (workgroups per image, LDS per workgroup) are refused
             rc = lib.dmn_test_conv_block_tail(
                 dtype, x.data_ptr(), C_, B, H, H, w.ctypes.data, bias.ctypes.data, C_, pg.ctypes.data, pb.ctypes.data,
                 pst.data_ptr(), G, 1, tg.ctypes.data, tb.ctypes.data, G, res.data_ptr(), h2.data_ptr(), out.data_ptr(),
@@ -59,7 +59,7 @@ def run(name, B, H, C_, G, dtype=1, out_G=1, plan_B=64):
         d = dbg.cpu().numpy()
         d = d[d[:, 0] != 0]
         span = (d[:, 5].max() - d[:, 0].min()) / 100.0
-        if fused:
+        if fused & 1:
             ph = np.stack([d[:, 1] - d[:, 7], d[:, 2] - d[:, 1], d[:, 3] - d[:, 2], d[:, 6] - d[:, 3], d[:, 4] - d[:, 6]], 1)
             med = np.median(ph, 0)
             life = np.median((d[:, 5] - d[:, 0]) / 100.0)
@@ -86,3 +86,5 @@ if __name__ == "__main__":
         run("L3 256->256 8x8 groups 4", B, 8, 256, 4, dt)
         run("ragged 64->64 24x24", 3, 24, 64, 8, dt)
         run("decoder 32->32 32x32 (G_out 8)", B, 32, 32, 8, dt, out_G=8)
+        run("L0 32->32 64x64, 32x16 tiles", min(B, 32), 64, 32, 8, dt, tall=2)
+        run("final 32->32 64x64 (G_out 8), 32x16", min(B, 32), 64, 32, 8, dt, out_G=8, tall=2)
