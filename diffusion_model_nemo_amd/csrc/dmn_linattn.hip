@@ -880,6 +880,13 @@ void linattn_fused_plan(int n, int B, int C, int dtype, int* slice1, int* splits
     }
     int t = 4;
     while (t > 1 && ((long long)((n + 64 * t - 1) / (64 * t)) * B < 512 || 64 * t * row > 72 * 1024)) t /= 2;
+    // Images that would keep more pixel slices than the in-launch exchange admits take slices twice as long when that
+    // brings them under the limit (64x64 pixels of 32 channels: 8 slices of 512 pixels): the second launch then closes
+    // the attention itself and no pass over y remains.
+    static const bool long_slices = getenv("DMN_LA_SHORT_SLICES") == nullptr;
+    if (long_slices && t == 4 && (n + 255) / 256 > kHandoffMaxWgsPerImage && (n + 511) / 512 <= kHandoffMaxWgsPerImage &&
+        64 * 8 * row <= 56 * 1024)
+        t = 8;
     *tpw = t;
     *slices = (n + 64 * t - 1) / (64 * t);
 }

@@ -437,6 +437,8 @@ def test_block_tail_with_too_many_workgroups_per_image_is_refused():
     (4, 7, 7, 64),       # one workgroup per image, ragged (49 of 64 staged rows)
     (4, 4, 4, 32),
     (3, 24, 40, 64),     # last slice ragged
+    (3, 64, 64, 32),     # full resolution: 8 slices of 512 pixels (256-pixel slices would be 16, beyond the exchange)
+    (34, 64, 64, 32),    # ... and more images than one launch takes
 ])
 def test_linear_attention_closed_inside_its_second_launch_equals_the_separate_pass(dtype, B, side_h, side_w, cch):
     """Residual(PreNorm(LinearAttention)) with the closing GroupNorm(1)(y) + x computed by the attention's second launch
