@@ -392,8 +392,10 @@ def main(argv=None):
             "roofline": {"bound": "hbm", "achieved": k_bytes.value / (clk_ms.value / 1e3) / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": k_bytes.value / (clk_ms.value / 1e3) / 1e9 / HBM_PEAK_GBS,
                          "traffic": traffic,
-                         "kernel": "conv_igemm_kernel<bf16, 3x3, 16x16 px, 32 cout, GN+SiLU prologue> "
-                                   f"[{Bl},{S},{S},32] -> [{Bl},{S},{S},32] per launch ({chains} chain{'s' if chains > 1 else ''} of {Bl} images)",
+                         "kernel": "conv_igemm_kernel<bf16, 3x3, 32x16 px, 32 cout, GN+SiLU prologue, block tail inside the launch> "
+                                   f"[{Bl},{S},{S},32] (+ residual [{Bl},{S},{S},32]) -> [{Bl},{S},{S},32] per launch "
+                                   f"({chains} chain{'s' if chains > 1 else ''} of {Bl} images): block2.proj of downs.0.0, which also "
+                                   "closes its ResnetBlock (GroupNorm partial sums exchanged between the image's workgroups)",
                          "algorithmic_bytes": k_bytes.value, "launch_us": clk_ms.value * 1e3,
                          "launch_us_measured": f"device clock (100 MHz) stamps of the launch's workgroups, earliest start to latest "
                                                f"end, {clk_n.value} launches inside graph-replayed denoising steps with "
@@ -408,8 +410,10 @@ def main(argv=None):
                          "launch_us_hip_events_eager": p_ms.value * 1e3,
                          "launch_us_hip_events_eager_measured": f"HIP events around {p_n.value} launches inside eager denoising steps: marker-to-"
                                                f"marker {pair_ms.value * 1e3:.2f} us minus {mark_ms.value * 1e3:.2f} us for a marker by itself",
-                         "launch_us_back_to_back": k_ms.value * 1e3,
-                         "frac_back_to_back": kb2.value / (k_ms.value / 1e3) / 1e9 / HBM_PEAK_GBS},
+                         "back_to_back": {"what": "the same convolution WITHOUT the block tail (16x16-pixel tiles, input + output + "
+                                                  "weights), launched back to back on one tensor; HIP events on its stream",
+                                          "launch_us": k_ms.value * 1e3, "algorithmic_bytes": kb2.value,
+                                          "frac": kb2.value / (k_ms.value / 1e3) / 1e9 / HBM_PEAK_GBS}},
             # the whole captured step (time MLP + U-Net + posterior update) against the same roof
             "step": {"device_ms": sec_per_eval * 1e3, "algorithmic_bytes": alg_bytes,
                      "achieved_GBs": alg_bytes / sec_per_eval / 1e9,

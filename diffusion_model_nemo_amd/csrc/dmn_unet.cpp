@@ -322,6 +322,51 @@ static NormIn norm_in(const Act& a, const float* gamma, const float* beta, int B
 }
 
 // conv with optional: second source, input normalisation, residual, output statistics
+// Launches a convolution of the network, with the measurement hooks around it: the launch a probe site selects (or,
+// without a site, the dominant full-resolution one: block2.proj of downs.0.0) is timed by events (eager runs) or
+// clocked by its own workgroups (also inside captured steps).
+static void run_conv(Fwd& f, const PackedConv& pc, ConvArgs& a, const char* what) {
+    DmnUnet* u = f.u;
+    long long* const site = f.site_stamps();   // non-null: this launch is the one a probe site selects
+    if (site) a.dbg = site;
+    const bool target = u->probe_on && (u->probe_site < 0 ? &pc == &u->downs[0].rb[0].c2 : site != nullptr);
+    bool probe = target && u->probe_on == 1 && u->probe_n < kProbePairs;
+    if (probe) {   // never inside a stream capture: a captured event record carries no time
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        probe = hipStreamIsCapturing(f.s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
+    }
+    if (probe) {   // two markers back to back (what a marker itself costs), then the launch, then a third
+        (void)hipEventRecord(u->probe_ev[3 * u->probe_n], f.s);
+        (void)hipEventRecord(u->probe_ev[3 * u->probe_n + 1], f.s);
+    }
+    // device-clock form (also inside captured steps): every workgroup of this launch stamps its start and end
+    const bool clocked = target && u->probe_on == 2 && u->probe_stamps;
+    long long* stamps = clocked ? u->probe_stamps + (size_t)u->chain_id * kProbeMaxWgs * 8 : nullptr;   // per launch chain
+    if (clocked) a.dbg = stamps;
+    f.run(launch_conv(a, f.s), what);
+    if (clocked) {
+        const int tiles = ((a.Ho + 15) / 16) * ((a.Wo + 15) / 16);   // upper bound of the launch's workgroups (8x8 tiles: 4x)
+        int wgs = tiles * 4 * (a.Cout / 32) * f.B * a.nphase;
+        if (wgs > kProbeMaxWgs) wgs = kProbeMaxWgs;
+        f.run(launch_stamp_span(stamps, wgs, u->probe_acc + 2 * u->chain_id, f.s), "probe: span of the stamps");
+    }
+    if (probe || clocked) {
+        // what the launch must move: input, output, weights, and the residual tensor where it closes its block
+        const double px = (double)f.B * a.H * a.W;
+        u->probe_bytes = (px * pc.Cin + (double)f.B * a.out_H * a.out_W * pc.Cout * (a.res ? 2 : 1)) * f.esz() +
+                         (double)pc.Cin * pc.Cout * pc.ntaps * f.esz();
+        u->probe_shape[0] = 2.0 * f.B * a.out_H * a.out_W * pc.Cin * pc.Cout * pc.ntaps;
+        u->probe_shape[1] = pc.Cin;
+        u->probe_shape[2] = pc.Cout;
+        u->probe_shape[3] = a.out_H;
+        u->probe_shape[4] = pc.ntaps;
+    }
+    if (probe) {
+        (void)hipEventRecord(u->probe_ev[3 * u->probe_n + 2], f.s);
+        ++u->probe_n;
+    }
+}
+
 static Act do_conv(Fwd& f, const PackedConv& pc, const Act& in0, const Act* in1, const NormIn* pro, const Act* res, int epiG,
                    const PackedConv* shortcut = nullptr, Act* shortcut_out = nullptr, const void* pro_res = nullptr,
                    void* pro_out = nullptr, const ActEpi* act = nullptr) {
@@ -361,47 +406,11 @@ static Act do_conv(Fwd& f, const PackedConv& pc, const Act& in0, const Act* in1,
         }
     }
     if (f.ok() && !f.dry) {
-        // measurement hook: events around the dominant launch as it runs inside the step (block2.proj of downs.0.0)
-        DmnUnet* u = f.u;
-        long long* const site = f.site_stamps();   // non-null: this launch is the one a probe site selects
-        if (site) a.dbg = site;
-        const bool target = u->probe_on && (u->probe_site < 0 ? &pc == &u->downs[0].rb[0].c2 : site != nullptr);
-        bool probe = target && u->probe_on == 1 && u->probe_n < kProbePairs;
-        if (probe) {   // never inside a stream capture: a captured event record carries no time
-            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-            probe = hipStreamIsCapturing(f.s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
-        }
-        if (probe) {   // two markers back to back (what a marker itself costs), then the launch, then a third
-            (void)hipEventRecord(u->probe_ev[3 * u->probe_n], f.s);
-            (void)hipEventRecord(u->probe_ev[3 * u->probe_n + 1], f.s);
-        }
-        // device-clock form (also inside captured steps): every workgroup of this launch stamps its start and end
-        const bool clocked = target && u->probe_on == 2 && u->probe_stamps;
-        long long* stamps = clocked ? u->probe_stamps + (size_t)u->chain_id * kProbeMaxWgs * 8 : nullptr;   // per launch chain
-        if (clocked) a.dbg = stamps;
         char what[160];
         snprintf(what, sizeof(what), "conv kind %d %d->%d at %dx%d%s%s%s out@%zu stats@%zu", pc.kind, pc.Cin, pc.Cout, in0.H,
                  in0.W, pro ? (pro->silu ? " norm+silu" : " norm") : "", res ? " +res" : "", shortcut ? " +shortcut" : "",
                  (size_t)((char*)a.out - f.ar.base), out.stats ? (size_t)((char*)out.stats - f.ar.base) : (size_t)0);
-        f.run(launch_conv(a, f.s), what);
-        if (clocked) {
-            const int tiles = ((a.Ho + 15) / 16) * ((a.Wo + 15) / 16);   // upper bound of the launch's workgroups (8x8 tiles: 4x)
-            int wgs = tiles * 4 * (a.Cout / 32) * f.B * a.nphase;
-            if (wgs > kProbeMaxWgs) wgs = kProbeMaxWgs;
-            f.run(launch_stamp_span(stamps, wgs, u->probe_acc + 2 * u->chain_id, f.s), "probe: span of the stamps");
-        }
-        if (probe || clocked) {
-            u->probe_bytes = (double)f.B * in0.H * in0.W * (pc.Cin + pc.Cout) * f.esz() + (double)pc.Cin * pc.Cout * pc.ntaps * f.esz();
-            u->probe_shape[0] = 2.0 * f.B * a.out_H * a.out_W * pc.Cin * pc.Cout * pc.ntaps;
-            u->probe_shape[1] = pc.Cin;
-            u->probe_shape[2] = pc.Cout;
-            u->probe_shape[3] = a.out_H;
-            u->probe_shape[4] = pc.ntaps;
-        }
-        if (probe) {
-            (void)hipEventRecord(u->probe_ev[3 * u->probe_n + 2], f.s);
-            ++u->probe_n;
-        }
+        run_conv(f, pc, a, what);
     }
     return out;
 }
@@ -500,8 +509,8 @@ static Act resblock(Fwd& f, const ResBlockW& w, Act& x, Act* x2, const float* tb
                     out.stats = f.new_stats(statsG, out.sSlots);
                     a.tail_stats.stats = out.stats;
                 }
-                if (long long* st = f.site_stamps()) a.dbg = st;
-                if (f.ok() && !f.dry) f.run(launch_conv(a, f.s), "conv2 + block tail (in-launch statistics)");
+                if (f.ok() && !f.dry) run_conv(f, w.c2, a, "conv2 + block tail (in-launch statistics)");
+                else (void)f.site_stamps();
                 f.free_act(h1);
                 if (w.has_res) f.free_act(r);
                 return out;
@@ -557,6 +566,7 @@ static bool block_tail_is_local(Fwd& f, const ResBlockW& w, int H, int W) {
     a.plan_B = f.planB();
     a.C0 = w.c2.Cin;
     a.epi.G = f.u->cfg.groups;
+    a.tall_tail = !(f.u->path_mask & 131072);
     return conv_tail_fits(a) && (conv_epi_wgs(a) == 1 || !(f.u->path_mask & 16384));
 }
 

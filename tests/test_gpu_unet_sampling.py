@@ -711,7 +711,7 @@ def test_device_clock_probe_times_a_chosen_launch_inside_the_captured_steps():
     N.check(N.lib().dmn_unet_probe_result(h, C.byref(ms), C.byref(mark), C.byref(n), C.byref(nbytes)))
     assert torch.equal(plain, probed)
     assert n.value == 2 * 6 and 1e-3 < ms.value < 0.2                 # one launch per chain and step, microseconds each
-    assert nbytes.value == 16 * 64 * 64 * (32 + 32) * 2 + 32 * 32 * 9 * 2   # 16 images per launch: in + out + weights, bf16
+    assert nbytes.value == 16 * 64 * 64 * (32 + 32 + 32) * 2 + 32 * 32 * 9 * 2   # 16 images per launch: in + residual + out + weights, bf16
     found = []
     for site in range(8, 40):
         N.check(N.lib().dmn_test_probe_site(h, site, None))

@@ -54,7 +54,7 @@ while [ $# -gt 0 ]; do
     for c in FETCH_SIZE WRITE_SIZE; do pmc_run $o/${tag}_pmc_$c $c -- $short; done
     f=$(find $o/${tag}_pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1)
     w=$(find $o/${tag}_pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
-    python tools/traffic_summary.py $f $w conv_igemm_kernelIDF16bLi0ELi16ELi16ELi32ELi2ELi2ELi2ELb0E 131072 $o/${tag}_dominant_kernel_traffic.json 32 64 bf16 > /dev/null || exit 1
+    python tools/traffic_summary.py $f $w conv_igemm_kernelIDF16bLi0ELi32ELi16ELi32ELi4ELi1ELi2ELb0ELb1E 65536 $o/${tag}_dominant_kernel_traffic.json 32 64 bf16 > /dev/null || exit 1
     find $o/${tag}_pmc_FETCH_SIZE $o/${tag}_pmc_WRITE_SIZE -name "*.csv" -size +20M -delete
     pmc_run $o/${tag}_pmc_mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE -- $short
     python tools/mfma_util.py $o/${tag}_pmc_mfma $o/${tag}_mfma_utilisation.txt > /dev/null
