@@ -402,7 +402,9 @@ def main(argv=None):
                                                f"{chains} launch chain{'s' if chains > 1 else ''} in flight",
                          "note": "with two launch chains in flight a launch shares the machine with the other chain's kernels: its own "
                                  "bytes over its own duration understate what the machine moves meanwhile; single_chain is the same "
-                                 "kernel timed the same way with one chain (all images in one launch, nothing else in flight)",
+                                 "kernel timed the same way with one chain (nothing else in flight; a launch whose workgroups "
+                                 "exchange takes at most 256 of them, i.e. 32 images: one chain issues two such launches, the "
+                                 "figures are those of one)",
                          "single_chain": None if chains_default == 1 else {
                              "launch_us": one_ms.value * 1e3, "algorithmic_bytes": one_bytes.value, "launches": one_n.value,
                              "achieved": one_bytes.value / (one_ms.value / 1e3) / 1e9,

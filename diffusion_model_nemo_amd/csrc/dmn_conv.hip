@@ -539,6 +539,12 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
             __syncthreads();
             // (3) out = SiLU(GroupNorm(conv + bias)) + res, in the arithmetic of the stand-alone closing pass (which
             //     reads the convolution's output rounded to the activation type)
+            // A wave that holds every channel of its pixels (WN == 1, 32 channels = 64 bytes per pixel) passes its results
+            // through LDS (the dead halo tile) and stores whole pixel rows, 16 bytes per lane and 1 KB contiguous per
+            // instruction, instead of 8-byte pieces that fill every 64-byte segment in two instructions.
+            constexpr bool ROWSTORE = WN == 1 && sizeof(T) == 2 && BN == 32;
+            constexpr int OROW = BN * 2 + 16;
+            char* sOut = smem + 1024 + (size_t)wave * (MT * 16) * OROW;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const bool valid = col_ok && oyt0 + mt * ROWS < a.Ho;
@@ -568,8 +574,27 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
                                 o[r] = (__bf16)(silu_affine_fast(x, ca[r], cb[r], 0.f) + (float)rv[mt][nt][r]);
                                 acc[mt][nt][r] = (float)o[r];   // statistics of the value the consumer will read
                             }
-                            store_stream(reinterpret_cast<bf16x4*>(outp + obase + n), o);
+                            if constexpr (ROWSTORE) *reinterpret_cast<bf16x4*>(sOut + (mt * 16 + l15) * OROW + cl * 2) = o;
+                            else store_stream(reinterpret_cast<bf16x4*>(outp + obase + n), o);
                         }
+                    }
+                }
+            }
+            if constexpr (ROWSTORE) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                static_assert(!ROWSTORE || TW == 16, "a pixel tile is one row of the tile");
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {   // MT * 16 pixels x 4 units of 16 bytes = MT units per lane
+                    const int u = lane + 64 * j;
+                    const int pl = u >> 2, part = u & 3;
+                    const int oy = tile_y * TH + wm * MT + (pl >> 4), ox = tile_x * TW + (pl & 15);
+                    const uint4 v = *reinterpret_cast<const uint4*>(sOut + pl * OROW + part * 16);
+                    if (oy < a.Ho && ox < a.Wo) {
+                        const unsigned off = (unsigned)((b * a.out_H + oy * a.out_sy + P.out_oy) * a.out_W + ox * a.out_sx + P.out_ox) *
+                                             (unsigned)a.Cout + (unsigned)(n0 + part * 8);
+                        store_stream(reinterpret_cast<uint4*>(outp + off), v);
                     }
                 }
             }

@@ -351,11 +351,13 @@ static void run_conv(Fwd& f, const PackedConv& pc, ConvArgs& a, const char* what
         f.run(launch_stamp_span(stamps, wgs, u->probe_acc + 2 * u->chain_id, f.s), "probe: span of the stamps");
     }
     if (probe || clocked) {
-        // what the launch must move: input, output, weights, and the residual tensor where it closes its block
-        const double px = (double)f.B * a.H * a.W;
-        u->probe_bytes = (px * pc.Cin + (double)f.B * a.out_H * a.out_W * pc.Cout * (a.res ? 2 : 1)) * f.esz() +
+        // What the clocked launch must move: input, output, weights, and the residual tensor where it closes its block.
+        // A launch whose workgroups exchange is issued in pieces of at most 256 workgroups (launch_conv): the stamps
+        // then hold the last piece, of a.b_count images.
+        const int nb = a.b_count > 0 ? a.b_count : f.B;
+        u->probe_bytes = ((double)nb * a.H * a.W * pc.Cin + (double)nb * a.out_H * a.out_W * pc.Cout * (a.res ? 2 : 1)) * f.esz() +
                          (double)pc.Cin * pc.Cout * pc.ntaps * f.esz();
-        u->probe_shape[0] = 2.0 * f.B * a.out_H * a.out_W * pc.Cin * pc.Cout * pc.ntaps;
+        u->probe_shape[0] = 2.0 * nb * a.out_H * a.out_W * pc.Cin * pc.Cout * pc.ntaps;
         u->probe_shape[1] = pc.Cin;
         u->probe_shape[2] = pc.Cout;
         u->probe_shape[3] = a.out_H;
