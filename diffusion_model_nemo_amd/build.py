@@ -77,9 +77,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
         run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB_PATH, *objs])
         # the flags above are only as good as what they produce: disassemble the result and refuse a library that
         # holds a packed-FP32 instruction after all (toolchain change, vector-typed source line, dropped flag)
-        from .isa_check import assert_no_packed_fp32
+        # ... or whose exchanging kernels outgrew half a SIMD's registers (two of their workgroups must fit one CU)
+        from .isa_check import assert_exchanging_kernels_fit_half_a_cu, assert_no_packed_fp32
         try:
             assert_no_packed_fp32(LIB_PATH)
+            assert_exchanging_kernels_fit_half_a_cu(LIB_PATH)
         except Exception:
             os.replace(LIB_PATH, LIB_PATH + ".rejected")   # never leave a library behind that must not be loaded
             raise

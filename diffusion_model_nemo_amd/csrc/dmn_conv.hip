@@ -66,8 +66,10 @@ template <> struct KindTraits<DMN_KT2X2> { static constexpr int NTAPS = 4, EXT =
 // accumulators stay in registers while the image's workgroups exchange their GroupNorm partial sums (dmn_handoff.h),
 // then out = SiLU(GroupNorm(conv + bias)) + res is stored, with partial statistics of THAT tensor for the next
 // consumer. The convolution's own output never reaches memory and the block needs no closing pass.
+// A launch whose workgroups may wait for each other (TAIL) keeps to half a SIMD's registers: two such workgroups per CU
+// must be able to be resident together (dmn_handoff.h).
 template <typename T, int KIND, int TH, int TW, int BN, int WM, int WN, int PRO, bool RES, bool TAIL = false>
-__global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
+__global__ void __launch_bounds__(256, TAIL ? 2 : 1) conv_igemm_kernel(const ConvArgs a) {
     static_assert(!RES || KIND == DMN_K3X3, "the fused 1x1 shortcut rides on the 3x3 kernel");
     static_assert(!TAIL || (KIND == DMN_K3X3 && !RES), "the fused block tail rides on the plain 3x3 kernel");
     using KT = KindTraits<KIND>;

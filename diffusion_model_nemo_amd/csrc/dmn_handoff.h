@@ -19,8 +19,9 @@
 // they wait), but two such launches on two streams can starve each other once waiters of both fill the machine
 // (measured: about one stalled step in 3000 with two 512-workgroup launches in flight). Therefore every launch that
 // exchanges is small enough for ALL its workgroups to be resident beside all those of a second such launch: at most
-// kHandoffMaxWgsPerLaunch workgroups, each needing at most half a CU (80 KiB of LDS; 256 threads never need more than
-// half the registers). Hosts split the batch over several launches to stay below that, and leave shapes with more than
+// kHandoffMaxWgsPerLaunch workgroups, each needing at most half a CU: 80 KiB of LDS (checked by the launchers) and 256
+// of a SIMD's 512 registers per wave (the exchanging kernels are compiled with that bound -- __launch_bounds__(256, 2)
+// -- and the build reads the register counts of the finished library back: isa_check.py). Hosts split the batch over several launches to stay below that, and leave shapes with more than
 // kHandoffMaxWgsPerImage workgroups per image to the multi-launch forms. More than two exchanging launches at once
 // (several handles sampling concurrently on one GPU) are outside this guarantee; the spins are bounded all the same
 // (kHandoffSpinTicks of the 100 MHz clock), a give-up is counted in the area's header and surfaces as an error at the

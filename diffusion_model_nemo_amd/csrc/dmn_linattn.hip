@@ -407,8 +407,10 @@ __global__ void __launch_bounds__(256) la_merge_kernel(const LinAttnFusedArgs a)
 // ONE: the workgroup's slice is the whole image (grid (1, B)) and no first pass ran: after staging, wave h computes the
 //   context of head h itself (HeadContext, the arithmetic of the first pass) and leaves ctx^T in LDS where the merged
 //   context would have been copied to. The pixels are staged once and the whole attention is one launch.
+// Workgroups that may wait for each other (TAIL with several slices per image, i.e. not ONE) keep to half a SIMD's
+// registers: two of them per CU must be able to be resident together (dmn_handoff.h).
 template <typename T, int C, bool TAIL, bool ONE>
-__global__ void __launch_bounds__(256) la_fused_out_kernel(const LinAttnFusedArgs a) {
+__global__ void __launch_bounds__(256, (TAIL && !ONE) ? 2 : 1) la_fused_out_kernel(const LinAttnFusedArgs a) {
     constexpr int PER = ElemTraits<T>::kPer16B;
     constexpr int KCH = ElemTraits<T>::kChunk;
     constexpr int SUB = Sub<T>::N;

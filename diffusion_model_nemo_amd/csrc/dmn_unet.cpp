@@ -485,8 +485,8 @@ static Act resblock(Fwd& f, const ResBlockW& w, Act& x, Act* x2, const float* tb
         a.C0 = h1.C;
         a.pro = n1;
         a.epi.G = G;
-        // where nobody else would apply the tail (the closing pass is the alternative), full-resolution images may take
-        // the tall tile that brings them under the exchange's limit (DMN_UNET_PATHS bit 131072: never)
+        // full-resolution images may take the tall tile that brings them under the exchange's limit (DMN_UNET_PATHS bit
+        // 131072: never; block_tail_is_local asks with the same flag)
         a.tall_tail = !(f.u->path_mask & 131072) && !h1.activated;
         if (conv_tail_fits(a)) {
             unsigned long long* gran = f.handoff_take((size_t)f.B * G * conv_epi_slots(a) * kHandoffGranulesPerSlot * sizeof(unsigned long long));

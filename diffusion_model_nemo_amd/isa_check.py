@@ -75,6 +75,46 @@ def assert_no_packed_fp32(lib_path: str) -> Dict[str, Dict[str, int]]:
     return census
 
 
+# Kernels whose workgroups may wait for each other inside a launch (the GroupNorm exchange, csrc/dmn_handoff.h): the
+# convolution with the fused block tail (last template argument true) and the linear attention's second launch with
+# TAIL and several slices per image (TAIL true, ONE false). Two such 256-thread workgroups must fit one CU together, so
+# a wave may hold at most half a SIMD's 512 registers (vector + accumulation).
+EXCHANGING = re.compile(r"conv_igemm_kernelI\w*ELb[01]ELb1EEEv8ConvArgs|la_fused_out_kernelI\w*ELb1ELb0EEEv16LinAttnFusedArgs")
+MAX_EXCHANGING_REGS = 256
+
+
+def register_census(lib_path: str) -> Dict[str, int]:
+    """kernel symbol -> registers per lane (`.vgpr_count` of the code-object metadata: vector + accumulation registers
+    as the hardware allocates them) for every gfx950 kernel of the library."""
+    out: Dict[str, int] = {}
+    with tempfile.TemporaryDirectory(prefix="dmn_isa_") as tmp:
+        for co in extract_code_objects(lib_path, tmp):
+            r = subprocess.run([_tool("llvm-readelf"), "--notes", co], check=True, capture_output=True, text=True)
+            name = None
+            for ln in r.stdout.splitlines():
+                m = re.match(r"\s+(?:- )?\.name:\s+(\S+)", ln)
+                if m:
+                    name = m.group(1)
+                m = re.match(r"\s+(?:- )?\.vgpr_count:\s+(\d+)", ln)
+                if m and name:
+                    out[name] = int(m.group(1))
+                    name = None
+    return out
+
+
+def assert_exchanging_kernels_fit_half_a_cu(lib_path: str) -> Dict[str, int]:
+    regs = {k: v for k, v in register_census(lib_path).items() if EXCHANGING.search(k)}
+    if not regs:
+        raise RuntimeError(f"{lib_path}: no exchanging kernel found (symbol pattern out of date?)")
+    bad = {k: v for k, v in regs.items() if v > MAX_EXCHANGING_REGS}
+    if bad:
+        raise RuntimeError(
+            f"{lib_path}: kernels whose workgroups wait for each other use more than {MAX_EXCHANGING_REGS} registers: {bad}. "
+            "Two of their workgroups no longer fit one CU, and two launch chains can starve each other's waits; keep "
+            "their `__launch_bounds__(256, 2)`.")
+    return regs
+
+
 if __name__ == "__main__":
     here = os.path.dirname(os.path.abspath(__file__))
     path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "lib", "libdmn_hip.so")
@@ -84,3 +124,5 @@ if __name__ == "__main__":
         for k in total:
             total[k] += c[k]
     print(f"total: {total}")
+    regs = assert_exchanging_kernels_fit_half_a_cu(path)
+    print(f"exchanging kernels: {len(regs)}, registers per lane {min(regs.values())}..{max(regs.values())} (limit {MAX_EXCHANGING_REGS})")

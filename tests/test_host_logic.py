@@ -207,6 +207,19 @@ def test_shipped_library_holds_no_packed_fp32_instruction():
     assert not isa_check.FORBIDDEN.search("v_pk_add_f16 v1, v2, v3") and not isa_check.FORBIDDEN.search("v_fma_f32 v1, v2, v3, v4")
 
 
+def test_kernels_that_wait_inside_a_launch_fit_two_workgroups_per_cu():
+    """Workgroups that exchange GroupNorm partial sums inside a launch keep their place on the CU while they wait; the
+    residency rule (two exchanging launches of <= 256 workgroups resident together) needs two of them per CU, i.e. at
+    most 256 of a SIMD's 512 registers per wave. Read from the code-object metadata of the shipped library."""
+    from diffusion_model_nemo_amd import _native, isa_check
+    regs = isa_check.assert_exchanging_kernels_fit_half_a_cu(_native.LIB_PATH)
+    assert len(regs) >= 12, sorted(regs)                                 # bf16 + fp32, conv tiles + attention widths
+    assert any("Li32ELi16ELi32ELi4ELi1E" in k for k in regs)             # the 32x16-pixel tile among them
+    assert max(regs.values()) <= 256
+    # kernels that never wait (one workgroup per image: TAIL && ONE) are not held to it
+    assert not isa_check.EXCHANGING.search("_ZN12_GLOBAL__N_119la_fused_out_kernelIDF16bLi256ELb1ELb1EEEv16LinAttnFusedArgs")
+
+
 def test_nemo_archive_round_trip(tmp_path):
     """`.nemo` layout (tar: model_config.yaml + model_weights.ckpt) written and read back: same config, same weights,
     and the reader also accepts the gzip-compressed form without the './' member prefix."""
