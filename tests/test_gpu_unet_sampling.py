@@ -889,6 +889,29 @@ def test_two_launch_chains_never_starve_an_in_launch_exchange():
         assert torch.equal(x, first)
 
 
+def test_two_launch_chains_of_a_wide_network_never_starve_an_exchange():
+    """dim = 64 with three levels puts 256 channels at 16x16 pixels: the linear attention's closing launch then has four
+    waiting workgroups per image with the widest register footprint of the library, and the 128-channel level exchanges
+    through the 64-channel convolution tile. Both launch chains in flight, 2 x 150 steps: no wait may run out, same bits
+    both times and the bits of one chain."""
+    from diffusion_model_nemo_amd.modules import GaussianDiffusion, Unet
+    sd = make_state_dict(unet_param_shapes(dim=64, dim_mults=(1, 2, 4)))
+    u = Unet(input_dim=64, dim=64, dim_mults=[1, 2, 4], channels=3, resnet_block_groups=8, use_convnext=False,
+             dropout=0.0, compute_dtype="bf16")
+    u.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    u = u.cuda().eval()
+    gd = GaussianDiffusion(timesteps=150, schedule_name="cosine")
+    outs = []
+    for _ in range(2):
+        outs.append(gd.p_sample_loop(u, (32, 3, 64, 64), device="cuda", seed=5, keep="last", return_device_tensor=True).clone())
+        torch.cuda.synchronize()
+        assert u.handoff_giveups() == 0
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+    u.set_sample_chains(1)
+    one = gd.p_sample_loop(u, (32, 3, 64, 64), device="cuda", seed=5, keep="last", return_device_tensor=True)
+    assert u.handoff_giveups() == 0 and torch.equal(one, outs[0])
+
+
 @pytest.mark.parametrize("kind", ["ddpm", "learned", "ddim"])
 def test_sampler_update_inside_the_last_kernel_gives_the_bits_of_its_own_launch(monkeypatch, kind):
     """In the DDPM loop the network's last kernel applies the sampler update itself (posterior / learned variance / DDIM,
