@@ -256,7 +256,7 @@ static int run_loop(DmnUnet* u, const SampleKey& key_in, int nsteps, int evals, 
     u->ev_valid = false;
     // The in-launch exchanges are only safe while the exchanging launches on the GPU are those of ONE handle's chains
     // (dmn_handoff.h): a loop that starts while another handle's exchanging work is in flight closes every block with
-    // the separate passes instead (same bits). Its captured step differs, hence the extra key bit.
+    // the separate passes instead (results agree to summation order). Its captured step differs, hence the extra key bit.
     const bool want_exchange = !(u->path_mask & 128);
     const bool entered = want_exchange && exchange_guard_enter(u);
     u->exchange_off = want_exchange && !entered;

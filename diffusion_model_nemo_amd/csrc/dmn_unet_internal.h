@@ -143,7 +143,8 @@ struct DmnUnet {
     unsigned giveups_carry = 0;          // give-ups counted in areas that have been zeroed since
     // Set while a loop / forward of this handle is being enqueued or captured although another handle's exchanging work
     // is in flight on the device (exchange_guard_enter returned false): every closing then takes its separate pass, as
-    // under DMN_UNET_PATHS bit 7 -- same bits, no waiting workgroups -- because the residency guarantee of
+    // under DMN_UNET_PATHS bit 7 -- the same arithmetic up to the order in which partial sums meet, no waiting
+    // workgroups -- because the residency guarantee of
     // dmn_handoff.h covers the exchanging launches of ONE handle's two chains only.
     bool exchange_off = false;
 };

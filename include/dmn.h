@@ -83,7 +83,8 @@ int dmn_unet_set_plan_batch(DmnUnet* u, int batch);
  * that runs out is counted and the evaluation's result is invalid. Returns the count since the handle was created (it
  * never goes down: a caller compares it with the value it saw last); waits for the device. The exchanges are only
  * used while no OTHER handle has exchanging work in flight on the GPU: a loop or forward that starts beside one takes
- * the separate closing passes (same bits). No counterpart in the reference. */
+ * the separate closing passes (the same arithmetic with the partial sums of the following GroupNorm formed per pixel
+ * slice instead of per convolution tile: results agree to summation order). No counterpart in the reference. */
 int dmn_unet_handoff_giveups(DmnUnet* u, unsigned* count);
 /* Tuning aid, no counterpart in the reference: per-workgroup phase stamps of the convolution launch selected by the
  * environment variable DMN_PROBE_SITE (its number among an evaluation's convolution launches), taken inside the sampling
