@@ -740,6 +740,9 @@ __global__ void __launch_bounds__(256, TAIL ? 2 : 1) conv_igemm_kernel(const Con
         }
         }
     }
+    // a clocked launch's end is when its results have left: the stamping wave waits for its stores first (a profiler's
+    // dispatch duration includes that drain; without the wait the stamps end 1-2 us before it)
+    if (a.dbg) __builtin_amdgcn_s_waitcnt(0);   // every counter at zero: the wave's loads and stores have been answered
     DMN_STAMP(4)
 #undef DMN_STAMP
 }
