@@ -399,7 +399,10 @@ def main(argv=None):
                          "algorithmic_bytes": k_bytes.value, "launch_us": clk_ms.value * 1e3,
                          "launch_us_measured": f"device clock (100 MHz) stamps of the launch's workgroups, earliest start to latest "
                                                f"end, {clk_n.value} launches inside graph-replayed denoising steps with "
-                                               f"{chains} launch chain{'s' if chains > 1 else ''} in flight",
+                                               f"{chains} launch chain{'s' if chains > 1 else ''} in flight; the end stamp waits "
+                                               "for the workgroup's stores. A profiler's dispatch duration of the same launch is "
+                                               "2-3 us longer: dispatch and completion (1.6 us for any kernel here) and the "
+                                               "write-back of the 8.4 MB the launch leaves in L2 when it ends",
                          "note": "with two launch chains in flight a launch shares the machine with the other chain's kernels: its own "
                                  "bytes over its own duration understate what the machine moves meanwhile; single_chain is the same "
                                  "kernel timed the same way with one chain (nothing else in flight; a launch whose workgroups "

@@ -740,9 +740,13 @@ __global__ void __launch_bounds__(256, TAIL ? 2 : 1) conv_igemm_kernel(const Con
         }
         }
     }
-    // a clocked launch's end is when its results have left: the stamping wave waits for its stores first (a profiler's
-    // dispatch duration includes that drain; without the wait the stamps end 1-2 us before it)
-    if (a.dbg) __builtin_amdgcn_s_waitcnt(0);   // every counter at zero: the wave's loads and stores have been answered
+    // a clocked launch's end is when its results have left: every wave waits until its stores have been answered, then
+    // the workgroup stamps (a profiler's dispatch duration includes that drain; without the wait the stamps end 1-3 us
+    // before it, most of all where an exchange makes all workgroups store at the same time)
+    if (a.dbg) {
+        __builtin_amdgcn_s_waitcnt(0);   // every counter at zero
+        __syncthreads();
+    }
     DMN_STAMP(4)
 #undef DMN_STAMP
 }
