@@ -56,15 +56,16 @@ template <> struct Vec16<__bf16> {
     __device__ __forceinline__ void set(int i, float x) { v[i] = (__bf16)x; }
 };
 
-// Streaming store of a 16-byte (or 8-byte) vector: written through the L2 instead of left dirty in it. Every kernel
-// here produces a tensor that the NEXT launch reads, possibly from another XCD, so the data has to reach memory
-// before the kernel can retire; written through, that drain overlaps the kernel instead of extending its end.
-template <typename V> __device__ __forceinline__ void store_stream(V* dst, const V& v) {
+// Store of a 16-byte (or 8-byte) vector as ONE instruction with the default cache policy. Every kernel here produces a
+// tensor that the NEXT launch reads: left in L2 (written back when the kernel ends) the consumer finds most of it in
+// L2 or the Infinity Cache. Measured on MI355X, two launch chains: the non-temporal hint (`nt`) costs 0.3 % of the
+// step, system-scope write-through (`sc0 sc1`) 5.4 %.
+template <typename V> __device__ __forceinline__ void store_vec(V* dst, const V& v) {
     if constexpr (sizeof(V) == 16) {
-        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(dst));
+        *reinterpret_cast<u32x4*>(dst) = __builtin_bit_cast(u32x4, v);
     } else {
         static_assert(sizeof(V) == 8, "8- or 16-byte vectors");
-        __builtin_nontemporal_store(__builtin_bit_cast(u32x2, v), reinterpret_cast<u32x2*>(dst));
+        *reinterpret_cast<u32x2*>(dst) = __builtin_bit_cast(u32x2, v);
     }
 }
 

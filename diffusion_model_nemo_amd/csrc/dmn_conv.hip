@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(256, TAIL ? 2 : 1) conv_igemm_kernel(const Con
                         const int ly = pix / IW, lx = pix - ly * IW;
                         if (in && pro_store && ly >= P.pad_y && ly < P.pad_y + TH * S && lx >= P.pad_x && lx < P.pad_x + TW * S) {
                             const unsigned off = (unsigned)((b * a.H + iy0 + ly) * a.W + ix0 + lx) * (unsigned)a.C0 + (unsigned)c;
-                            store_stream(reinterpret_cast<V*>(static_cast<T*>(a.pro_out) + off), v.v);
+                            store_vec(reinterpret_cast<V*>(static_cast<T*>(a.pro_out) + off), v.v);
                         }
                     }
                 }
@@ -567,7 +567,7 @@ __global__ void __launch_bounds__(256, TAIL ? 2 : 1) conv_igemm_kernel(const Con
                                 t += 0.f;
                                 acc[mt][nt][r] = t + rv[mt][nt][r];
                             }
-                            store_stream(reinterpret_cast<f32x4*>(outp + obase + n), acc[mt][nt]);
+                            store_vec(reinterpret_cast<f32x4*>(outp + obase + n), acc[mt][nt]);
                         } else {
                             bf16x4 o;
 #pragma unroll
@@ -577,7 +577,7 @@ __global__ void __launch_bounds__(256, TAIL ? 2 : 1) conv_igemm_kernel(const Con
                                 acc[mt][nt][r] = (float)o[r];   // statistics of the value the consumer will read
                             }
                             if constexpr (ROWSTORE) *reinterpret_cast<bf16x4*>(sOut + (mt * 16 + l15) * OROW + cl * 2) = o;
-                            else store_stream(reinterpret_cast<bf16x4*>(outp + obase + n), o);
+                            else store_vec(reinterpret_cast<bf16x4*>(outp + obase + n), o);
                         }
                     }
                 }
@@ -596,7 +596,7 @@ __global__ void __launch_bounds__(256, TAIL ? 2 : 1) conv_igemm_kernel(const Con
                     if (oy < a.Ho && ox < a.Wo) {
                         const unsigned off = (unsigned)((b * a.out_H + oy * a.out_sy + P.out_oy) * a.out_W + ox * a.out_sx + P.out_ox) *
                                              (unsigned)a.Cout + (unsigned)(n0 + part * 8);
-                        store_stream(reinterpret_cast<uint4*>(outp + off), v);
+                        store_vec(reinterpret_cast<uint4*>(outp + off), v);
                     }
                 }
             }
@@ -656,7 +656,7 @@ __global__ void __launch_bounds__(256, TAIL ? 2 : 1) conv_igemm_kernel(const Con
                                     float t = (acc[mt][nt][r] + bias[nt][r]) * ca[r] + cb[r];
                                     y[r] = silu_precise(t) + ct[r];
                                 }
-                                store_stream(reinterpret_cast<f32x4*>(outp + obase + n), f32x4{y[0], y[1], y[2], y[3]});
+                                store_vec(reinterpret_cast<f32x4*>(outp + obase + n), f32x4{y[0], y[1], y[2], y[3]});
                             } else {
                                 bf16x4 o;
 #pragma unroll
@@ -664,7 +664,7 @@ __global__ void __launch_bounds__(256, TAIL ? 2 : 1) conv_igemm_kernel(const Con
                                     const float x = (float)(__bf16)(acc[mt][nt][r] + bias[nt][r]);
                                     o[r] = (__bf16)silu_affine_fast(x, ca[r], cb[r], ct[r]);
                                 }
-                                store_stream(reinterpret_cast<bf16x4*>(outp + obase + n), o);
+                                store_vec(reinterpret_cast<bf16x4*>(outp + obase + n), o);
                             }
                         }
                     }
@@ -699,13 +699,13 @@ __global__ void __launch_bounds__(256, TAIL ? 2 : 1) conv_igemm_kernel(const Con
                     constexpr bool STREAM = KIND != DMN_KT2X2;
                     if constexpr (sizeof(T) == 4) {
                         const f32x4 o = f32x4{v[0], v[1], v[2], v[3]};
-                        if constexpr (STREAM) store_stream(reinterpret_cast<f32x4*>(outp + obase + n), o);
+                        if constexpr (STREAM) store_vec(reinterpret_cast<f32x4*>(outp + obase + n), o);
                         else *reinterpret_cast<f32x4*>(outp + obase + n) = o;
                     } else {
                         bf16x4 o;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) o[r] = (__bf16)v[r];
-                        if constexpr (STREAM) store_stream(reinterpret_cast<bf16x4*>(outp + obase + n), o);
+                        if constexpr (STREAM) store_vec(reinterpret_cast<bf16x4*>(outp + obase + n), o);
                         else *reinterpret_cast<bf16x4*>(outp + obase + n) = o;
                     }
                 }
@@ -723,12 +723,12 @@ __global__ void __launch_bounds__(256, TAIL ? 2 : 1) conv_igemm_kernel(const Con
                         // the shortcut is a stride-1 convolution: its output grid is the input grid
                         const unsigned o = (unsigned)((b * a.out_H + oyt0 + mt * ROWS) * a.out_W + oxt) * (unsigned)a.Cout + n;
                         if constexpr (sizeof(T) == 4) {
-                            store_stream(reinterpret_cast<f32x4*>(out2 + o), acc2[mt][nt] + b2);
+                            store_vec(reinterpret_cast<f32x4*>(out2 + o), acc2[mt][nt] + b2);
                         } else {
                             bf16x4 ov;
 #pragma unroll
                             for (int r = 0; r < 4; ++r) ov[r] = (__bf16)(acc2[mt][nt][r] + b2[r]);
-                            store_stream(reinterpret_cast<bf16x4*>(out2 + o), ov);
+                            store_vec(reinterpret_cast<bf16x4*>(out2 + o), ov);
                         }
                     }
                 }

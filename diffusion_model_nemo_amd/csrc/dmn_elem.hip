@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(kNormThreads) norm_apply_kernel(const NormAppl
                 sd[e / 4] += d;
                 qd[e / 4] += d * d;
             }
-            store_stream(reinterpret_cast<V*>(out + (size_t)i * PER), v.v);
+            store_vec(reinterpret_cast<V*>(out + (size_t)i * PER), v.v);
         }
     }
     if (want) {
@@ -349,7 +349,7 @@ __device__ __forceinline__ void ingest_mfma_body(const IngestArgs& a, int bx, in
                 bf16x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = (__bf16)acc[r][nt][j];
-                store_stream(reinterpret_cast<bf16x4*>(dst + nt * 16 + lq * 4), o);
+                store_vec(reinterpret_cast<bf16x4*>(dst + nt * 16 + lq * 4), o);
             }
         }
     }
@@ -484,7 +484,8 @@ __global__ void __launch_bounds__(256) egress_kernel(const EgressArgs a) {
             xn[r] = ddpm_update_element(st, tr, x[r], sEps[c * 256 + 4 * j + r], v, z[r]);
         }
         *reinterpret_cast<f32x4*>(sc.x_out + xi) = xn;
-        if (sc.keep) *reinterpret_cast<f32x4*>(sc.keep + (size_t)row * sc.keep_stride + xi) = xn;
+        // the history row is not read again on the device: keep it out of the way of what the next launch reads
+        if (sc.keep) __builtin_nontemporal_store(xn, reinterpret_cast<f32x4*>(sc.keep + (size_t)row * sc.keep_stride + xi));
     }
 }
 

@@ -679,13 +679,13 @@ __global__ void __launch_bounds__(256, (TAIL && !ONE) ? 2 : 1) la_fused_out_kern
                     if constexpr (sizeof(T) == 4) {
                         const f32x4 ov = f32x4{v[0], v[1], v[2], v[3]};
                         if constexpr (TAIL) *reinterpret_cast<f32x4*>(yl) = ov;
-                        else store_stream(reinterpret_cast<f32x4*>(yout + (size_t)px * C + c), ov);
+                        else store_vec(reinterpret_cast<f32x4*>(yout + (size_t)px * C + c), ov);
                     } else {
                         bf16x4 ov;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) ov[r] = (__bf16)v[r];
                         if constexpr (TAIL) *reinterpret_cast<bf16x4*>(yl) = ov;
-                        else store_stream(reinterpret_cast<bf16x4*>(yout + (size_t)px * C + c), ov);
+                        else store_vec(reinterpret_cast<bf16x4*>(yout + (size_t)px * C + c), ov);
                     }
                 }
             }
@@ -772,7 +772,7 @@ __global__ void __launch_bounds__(256, (TAIL && !ONE) ? 2 : 1) la_fused_out_kern
                         }
                         v.set(e, y + r.get(e));
                     }
-                    store_stream(reinterpret_cast<V*>(outp + (size_t)(p0 + row) * C + part * PER), v.v);
+                    store_vec(reinterpret_cast<V*>(outp + (size_t)(p0 + row) * C + part * PER), v.v);
                 }
             }
         }
