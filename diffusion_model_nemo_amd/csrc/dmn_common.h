@@ -56,16 +56,21 @@ template <> struct Vec16<__bf16> {
     __device__ __forceinline__ void set(int i, float x) { v[i] = (__bf16)x; }
 };
 
-// Store of a 16-byte (or 8-byte) vector as ONE instruction with the default cache policy. Every kernel here produces a
-// tensor that the NEXT launch reads: left in L2 (written back when the kernel ends) the consumer finds most of it in
-// L2 or the Infinity Cache. Measured on MI355X, two launch chains: the non-temporal hint (`nt`) costs 0.3 % of the
-// step, system-scope write-through (`sc0 sc1`) 5.4 %.
+// Store of a 16-byte (or 8-byte) vector as ONE instruction at agent scope (`sc1`): the data goes through the L2 to the
+// memory side while the kernel runs instead of waiting, dirty, for the write-back at its end, and the next launch --
+// every kernel here produces a tensor that the NEXT launch reads, from any XCD -- finds it in the Infinity Cache.
+// Measured on MI355X with two launch chains, per denoising step: default policy +0.3 %, default policy with the
+// non-temporal hint +0.65 %, `sc0 sc1 nt` +5.7 %, `sc0 sc1` as agent scope. Inline assembly because the language has
+// no scoped store of 16 bytes; the trailing s_nop covers the wait states between a wide vector-memory store and a
+// write to its data registers, which the compiler inserts for stores it knows.
 template <typename V> __device__ __forceinline__ void store_vec(V* dst, const V& v) {
     if constexpr (sizeof(V) == 16) {
-        *reinterpret_cast<u32x4*>(dst) = __builtin_bit_cast(u32x4, v);
+        const u32x4 w = __builtin_bit_cast(u32x4, v);
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(w) : "memory");
     } else {
         static_assert(sizeof(V) == 8, "8- or 16-byte vectors");
-        *reinterpret_cast<u32x2*>(dst) = __builtin_bit_cast(u32x2, v);
+        const u32x2 w = __builtin_bit_cast(u32x2, v);
+        asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(w) : "memory");
     }
 }
 
