@@ -483,7 +483,7 @@ __global__ void __launch_bounds__(256) egress_kernel(const EgressArgs a) {
             const float v = st.learned_variance ? sEps[(sc.C + c) * 256 + 4 * j + r] : 0.f;
             xn[r] = ddpm_update_element(st, tr, x[r], sEps[c * 256 + 4 * j + r], v, z[r]);
         }
-        *reinterpret_cast<f32x4*>(sc.x_out + xi) = xn;
+        store_vec(reinterpret_cast<f32x4*>(sc.x_out + xi), xn);
         // the history row is not read again on the device: keep it out of the way of what the next launch reads
         if (sc.keep) __builtin_nontemporal_store(xn, reinterpret_cast<f32x4*>(sc.keep + (size_t)row * sc.keep_stride + xi));
     }
