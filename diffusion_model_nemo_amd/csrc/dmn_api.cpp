@@ -284,7 +284,7 @@ static int run_loop_inner(DmnUnet* u, const SampleKey& key_in, int nsteps, hipSt
     // steps per captured graph: a divisor of both the loop length and the pacing block
     int K = 1;
     if (use_graph && s != nullptr && u->loop_graph_steps > 1) {
-        const int blk = u->loop_pace > 0 ? u->loop_pace : 16;
+        const int blk = u->loop_pace > 0 ? u->loop_pace : 8;
         for (int k = 1; k <= u->loop_graph_steps && k <= blk; ++k)
             if (nsteps % k == 0 && blk % k == 0) K = k;
     }
@@ -335,7 +335,7 @@ static int run_loop_inner(DmnUnet* u, const SampleKey& key_in, int nsteps, hipSt
     // per step over the first 300 steps of a loop on MI355X, and a profiler's kernel trace of the same loop shows no
     // such trend in the kernels themselves -- the cost follows the host's burst of packet and kernel-argument writes.
     // So the host waits, every `pace` steps, until the block before the last one has finished: at most two blocks are
-    // ever in flight, which is still tens of steps (milliseconds) ahead of the device.
+    // ever in flight (16 steps by default: about 11 ms ahead of the device; fewer steps in flight measure faster).
     const int pace = (s != nullptr && u->loop_pace > 0) ? u->loop_pace : 0;
     const int depth = u->loop_depth;
     if (pace)
@@ -357,7 +357,7 @@ static int run_loop_inner(DmnUnet* u, const SampleKey& key_in, int nsteps, hipSt
             // Two chains run fastest in LOCKSTEP -- the same kernels side by side -- and slowest half a step apart
             // (733 against 750 us per step, tools/chain_phase.py); left alone they drift apart in about every second
             // loop. So each chain also waits, on the device, for the other one's end of the block: they start every
-            // block together (the drift inside a block of 16 steps is a few hundredths of a step).
+            // block together (the drift inside a block of 8-16 steps is a few hundredths of a step).
             if (nchains == 2 && u->loop_lockstep && i + K < nsteps) {
                 DMN_HIP_CHECK(hipStreamWaitEvent(cs[0], u->ev_pace[slot][1], 0));
                 DMN_HIP_CHECK(hipStreamWaitEvent(cs[1], u->ev_pace[slot][0], 0));

@@ -109,7 +109,7 @@ struct DmnUnet {
     // pacing of a loop's enqueue (dmn_api.cpp:run_loop_inner): [slot][chain], recorded every loop_pace steps
     static constexpr int kPaceSlots = 64;
     hipEvent_t ev_pace[kPaceSlots][2] = {};
-    int loop_pace = 16;                  // steps between pacing events (0: unpaced; DMN_LOOP_PACE)
+    int loop_pace = 8;                   // steps between pacing events (0: unpaced; DMN_LOOP_PACE)
     bool loop_lockstep = true;           // the two chains start every pacing block together (DMN_LOOP_LOCKSTEP=0: left to drift)
     int loop_graph_steps = 1;            // denoising steps per captured graph, at most (DMN_LOOP_GRAPH_STEPS)
     int loop_depth = 2;                  // blocks of loop_pace steps in flight at most (2..kPaceSlots; DMN_LOOP_DEPTH)
