@@ -79,8 +79,11 @@ __global__ void __launch_bounds__(256, TAIL ? 2 : 1) conv_igemm_kernel(const Con
     // weight ring depth: the 16x16-pixel tiles run at high occupancy and only look RS fragments ahead (few
     // registers, latency hidden by the other waves); the 8x8 tiles of the wide layers run one workgroup per CU
     // and keep a whole iteration in flight
-    constexpr int RS = TW == 16 ? (NTAPS == 9 ? 3 : (E >= 4 ? 4 : E)) : E;
-    static_assert(E % RS == 0, "ring depth must divide the iteration");
+    // ... and for 3x3 even TWO iterations (k-steps): a k-step is 18 matrix instructions per wave (290 cycles), an L2
+    // round trip two to three times that, so with one k-step in flight the loop ran at the latency of the weights
+    constexpr bool DEEP = KIND == DMN_K3X3 && TW == 8;
+    constexpr int RS = TW == 16 ? (NTAPS == 9 ? 3 : (E >= 4 ? 4 : E)) : (DEEP ? 2 * E : E);
+    static_assert(E % RS == 0 || DEEP, "ring depth must divide the iteration");
     constexpr int BM = TH * TW;
     constexpr int MT = BM / (16 * WM);
     constexpr int NT = BN / (16 * WN);
@@ -319,7 +322,10 @@ __global__ void __launch_bounds__(256, TAIL ? 2 : 1) conv_igemm_kernel(const Con
             const int rstride = IW * rowB;
             const int rb0 = TW == 16 ? ((wm * MT) * IW + l15) * rowB + lq * 16
                                      : ((2 * wm * MT + (l15 >> 3)) * IW + (l15 & 7)) * rowB + lq * 16;
-            for (int ksl = 0; ksl < KSG; ++ksl) {
+            // one k-step; with the deep ring, k-steps alternate between the ring's halves (par), so the slots stay
+            // compile-time register indices
+            auto k3_step = [&](const int ksl, auto par_c) {
+                constexpr int par = decltype(par_c)::value;
                 const int ks = ksbase + ksl;
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
@@ -333,9 +339,10 @@ __global__ void __launch_bounds__(256, TAIL ? 2 : 1) conv_igemm_kernel(const Con
                     for (int i = 0; i < 3; ++i) {
                         const int e = dx * 3 + i;
                         const int dy = k3_tap<TW>(e) / 3;
+                        const int slot = DEEP ? par * E + e : e % RS;
                         Vec16<T> wv[NT];
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) wv[nt].v = w[e % RS][nt];
+                        for (int nt = 0; nt < NT; ++nt) wv[nt].v = w[slot][nt];
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) {
                             const int fj = TW == 16 ? mt + dy : (dy == 1 ? MT + 1 + mt : mt + dy / 2);
@@ -356,10 +363,21 @@ __global__ void __launch_bounds__(256, TAIL ? 2 : 1) conv_igemm_kernel(const Con
                                 }
                             }
                         }
-                        ring_fill3(e % RS, ks, e + RS);   // the slot just consumed
+                        ring_fill3(slot, ks, e + RS);   // the slot just consumed
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
+            };
+            if constexpr (DEEP) {
+                int ksl = 0;
+                for (; ksl + 1 < KSG; ksl += 2) {
+                    k3_step(ksl, std::integral_constant<int, 0>{});
+                    k3_step(ksl + 1, std::integral_constant<int, 1>{});
+                }
+                // an odd number of k-steps only occurs where all channels are one staged group (no ring continues)
+                if (ksl < KSG) k3_step(ksl, std::integral_constant<int, 0>{});
+            } else {
+                for (int ksl = 0; ksl < KSG; ++ksl) k3_step(ksl, std::integral_constant<int, 0>{});
             }
         } else
         for (int ksl = 0; ksl < KSG; ksl += GK) {
