@@ -479,17 +479,42 @@ __global__ void __launch_bounds__(256, (TAIL && !ONE) ? 2 : 1) la_fused_out_kern
     }
     XStager<T, C> st;
     st.begin(a.x, b, a.n, p0, slice);
+    // With up to two splits the partial contexts this thread will merge are requested here, ahead of the coefficient
+    // round trip and the staging arithmetic, instead of one round trip per split behind them (same values, same order).
+    constexpr int kEarlySplits = 2;
+    const bool early = S > 0 && S <= kEarlySplits;
+    f32x4 pv[4][kEarlySplits];
+    if (early) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float* base = part_b + (size_t)j * S * kPartStride + ((tid >> 3) & 31) * kD + (tid & 7) * 4;
+#pragma unroll
+            for (int s = 0; s < kEarlySplits; ++s) pv[j][s] = *reinterpret_cast<const f32x4*>(base + (size_t)(s < S ? s : S - 1) * kPartStride);
+        }
+    }
     if (S > 0 && tid < kHidden) {
         const int hd = tid;
         const float* base = part_b + (size_t)(hd >> 5) * S * kPartStride + kD * kD + (hd & 31);
-        float M = -INFINITY;
-        for (int s = 0; s < S; ++s) M = fmaxf(M, base[(size_t)s * kPartStride]);
-        float Z = 0.f;
-        for (int s = 0; s < S; ++s) {
-            const float f = expf(base[(size_t)s * kPartStride] - M);
-            sFac[hd * S + s] = f;
-            Z += base[(size_t)s * kPartStride + kD] * f;
+        // the maxima and sums of all splits in flight together (S <= kMergeInOutMaxSplits); arithmetic in split order
+        float mv[kMergeInOutMaxSplits], zv[kMergeInOutMaxSplits];
+#pragma unroll
+        for (int s = 0; s < kMergeInOutMaxSplits; ++s) {
+            const size_t o = (size_t)(s < S ? s : S - 1) * kPartStride;
+            mv[s] = base[o];
+            zv[s] = base[o + kD];
         }
+        float M = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < kMergeInOutMaxSplits; ++s)
+            if (s < S) M = fmaxf(M, mv[s]);
+        float Z = 0.f;
+#pragma unroll
+        for (int s = 0; s < kMergeInOutMaxSplits; ++s)
+            if (s < S) {
+                const float f = expf(mv[s] - M);
+                sFac[hd * S + s] = f;
+                Z += zv[s] * f;
+            }
         const float inv = 0.17677669529663687f / Z;
         for (int s = 0; s < S; ++s) sFac[hd * S + s] *= inv;
     }
@@ -510,10 +535,22 @@ __global__ void __launch_bounds__(256, (TAIL && !ONE) ? 2 : 1) la_fused_out_kern
         }
     } else {
         // ctx^T in operand order: row e, position pos holds ctx[d = perm32(pos)][e]
-        for (int i = tid; i < kHeads * kD * kD / 4; i += 256) {
+        static_assert(kHeads * kD * kD / 4 == 4 * 256, "four units per thread");
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = tid + 256 * j;
             const int hh = i >> 8, d = (i >> 3) & 31, e4 = (i & 7) * 4;
             const float* base = part_b + (size_t)hh * S * kPartStride + d * kD + e4;
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (early) {
+#pragma unroll
+                for (int s = 0; s < kEarlySplits; ++s)
+                    if (s < S) {
+                        const float f = sFac[(hh * kD + d) * S + s];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[r] = fmaf(pv[j][s][r], f, acc[r]);
+                    }
+            } else
             for (int s = 0; s < S; ++s) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)s * kPartStride);
                 const float f = sFac[(hh * kD + d) * S + s];
