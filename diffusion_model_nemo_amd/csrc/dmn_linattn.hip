@@ -364,18 +364,49 @@ __global__ void __launch_bounds__(256) la_merge_kernel(const LinAttnFusedArgs a)
     float* sFac = reinterpret_cast<float*>(smem);             // [128][splits] (this head's 32 rows are used)
     const int b = blockIdx.x, head = blockIdx.y, S = a.splits;
     const float* part_b = a.ctx_part + (size_t)b * kHeads * S * kPartStride;
+    // Up to kBatch splits (the full-resolution level has 8) are fetched together instead of one round trip per split and
+    // pass; the arithmetic keeps the split order, so the bits are those of the plain loops below.
+    constexpr int kBatch = 8;
     for (int hd = head * kD + threadIdx.x; hd < (head + 1) * kD; hd += 256) {
         const float* base = part_b + (size_t)(hd >> 5) * S * kPartStride + kD * kD + (hd & 31);
-        float M = -INFINITY;
-        for (int s = 0; s < S; ++s) M = fmaxf(M, base[(size_t)s * kPartStride]);
-        float Z = 0.f;
-        for (int s = 0; s < S; ++s) {
-            const float f = expf(base[(size_t)s * kPartStride] - M);
-            sFac[hd * S + s] = f;
-            Z += base[(size_t)s * kPartStride + kD] * f;
+        float M = -INFINITY, Z = 0.f;
+        if (S <= kBatch) {
+            float mv[kBatch], zv[kBatch];
+#pragma unroll
+            for (int s = 0; s < kBatch; ++s) {
+                const size_t o = (size_t)(s < S ? s : S - 1) * kPartStride;
+                mv[s] = base[o];
+                zv[s] = base[o + kD];
+            }
+#pragma unroll
+            for (int s = 0; s < kBatch; ++s)
+                if (s < S) M = fmaxf(M, mv[s]);
+#pragma unroll
+            for (int s = 0; s < kBatch; ++s)
+                if (s < S) {
+                    const float f = expf(mv[s] - M);
+                    sFac[hd * S + s] = f;
+                    Z += zv[s] * f;
+                }
+        } else {
+            for (int s = 0; s < S; ++s) M = fmaxf(M, base[(size_t)s * kPartStride]);
+            for (int s = 0; s < S; ++s) {
+                const float f = expf(base[(size_t)s * kPartStride] - M);
+                sFac[hd * S + s] = f;
+                Z += base[(size_t)s * kPartStride + kD] * f;
+            }
         }
         const float inv = 0.17677669529663687f / Z;
         for (int s = 0; s < S; ++s) sFac[hd * S + s] *= inv;
+    }
+    // the context rows this thread merges, requested before the barrier (they do not depend on the factors)
+    const int i0 = head * (kD * kD / 4) + threadIdx.x;   // kD * kD / 4 == 256: one unit per thread
+    f32x4 pv[kBatch];
+    if (S <= kBatch) {
+        const int hh = i0 >> 8, d = (i0 >> 3) & 31, e4 = (i0 & 7) * 4;
+        const float* base = part_b + (size_t)hh * S * kPartStride + d * kD + e4;
+#pragma unroll
+        for (int s = 0; s < kBatch; ++s) pv[s] = *reinterpret_cast<const f32x4*>(base + (size_t)(s < S ? s : S - 1) * kPartStride);
     }
     __syncthreads();
     // ctx^T in operand order: row e, position pos holds ctx[d = perm32(pos)][e]
@@ -384,6 +415,15 @@ __global__ void __launch_bounds__(256) la_merge_kernel(const LinAttnFusedArgs a)
         const int hh = i >> 8, d = (i >> 3) & 31, e4 = (i & 7) * 4;
         const float* base = part_b + (size_t)hh * S * kPartStride + d * kD + e4;
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (S <= kBatch && i == i0) {
+#pragma unroll
+            for (int s = 0; s < kBatch; ++s)
+                if (s < S) {
+                    const float f = sFac[(hh * kD + d) * S + s];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] = fmaf(pv[s][r], f, acc[r]);
+                }
+        } else
         for (int s = 0; s < S; ++s) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)s * kPartStride);
             const float f = sFac[(hh * kD + d) * S + s];
