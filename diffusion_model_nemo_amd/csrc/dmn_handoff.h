@@ -114,7 +114,7 @@ __device__ __forceinline__ void handoff_group_stats(const HandoffArgs& h, unsign
                 }
                 break;
             }
-            __builtin_amdgcn_s_sleep(4);
+            __builtin_amdgcn_s_sleep(1);
         }
         float s = 0.f;
 #pragma unroll
