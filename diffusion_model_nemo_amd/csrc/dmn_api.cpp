@@ -358,7 +358,9 @@ static int run_loop_inner(DmnUnet* u, const SampleKey& key_in, int nsteps, hipSt
             // (733 against 750 us per step, tools/chain_phase.py); left alone they drift apart in about every second
             // loop. So each chain also waits, on the device, for the other one's end of the block: they start every
             // block together (the drift inside a block of 8-16 steps is a few hundredths of a step).
-            if (nchains == 2 && u->loop_lockstep && i + K < nsteps) {
+            // (at every loop_lockstep_every-th pacing point: the wait costs about as much as a pacing point itself, and
+            // the chains need tens of steps to drift apart measurably)
+            if (nchains == 2 && u->loop_lockstep && i + K < nsteps && (i / pace) % u->loop_lockstep_every == u->loop_lockstep_every - 1) {
                 DMN_HIP_CHECK(hipStreamWaitEvent(cs[0], u->ev_pace[slot][1], 0));
                 DMN_HIP_CHECK(hipStreamWaitEvent(cs[1], u->ev_pace[slot][0], 0));
                 if (u->sample_skew_us > 0 && (rc = launch_delay(u->sample_skew_us, cs[1]))) return rc;   // tuning: a fixed lag

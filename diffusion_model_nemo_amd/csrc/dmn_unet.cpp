@@ -1460,6 +1460,7 @@ extern "C" int dmn_unet_create(const DmnUnetCfg* cfg, DmnUnet** out) {
     if (const char* e = getenv("DMN_LOOP_PACE")) u->loop_pace = atoi(e) < 0 ? 0 : (atoi(e) > 4096 ? 4096 : atoi(e));
     if (const char* e = getenv("DMN_LOOP_GRAPH_STEPS")) u->loop_graph_steps = atoi(e) < 1 ? 1 : (atoi(e) > 64 ? 64 : atoi(e));
     if (const char* e = getenv("DMN_LOOP_LOCKSTEP")) u->loop_lockstep = atoi(e) != 0;
+    if (const char* e = getenv("DMN_LOOP_LOCKSTEP_EVERY")) u->loop_lockstep_every = atoi(e) < 1 ? 1 : (atoi(e) > 1024 ? 1024 : atoi(e));
     if (const char* e = getenv("DMN_LOOP_DEPTH")) u->loop_depth = atoi(e) < 2 ? 2 : (atoi(e) > DmnUnet::kPaceSlots ? DmnUnet::kPaceSlots : atoi(e));
     if (const char* e = getenv("DMN_SAMPLE_SKEW_US")) u->sample_skew_us = atoi(e) < 0 ? 0 : (atoi(e) > 5000 ? 5000 : atoi(e));
     u->downs.resize(cfg->n_mults);

@@ -112,6 +112,7 @@ struct DmnUnet {
     int loop_pace = 8;                   // steps between pacing events (0: unpaced; DMN_LOOP_PACE)
     bool loop_lockstep = true;           // the two chains start every pacing block together (DMN_LOOP_LOCKSTEP=0: left to drift)
     int loop_graph_steps = 1;            // denoising steps per captured graph, at most (DMN_LOOP_GRAPH_STEPS)
+    int loop_lockstep_every = 4;         // lockstep wait at every n-th pacing point (DMN_LOOP_LOCKSTEP_EVERY)
     int loop_depth = 2;                  // blocks of loop_pace steps in flight at most (2..kPaceSlots; DMN_LOOP_DEPTH)
     bool ev_valid = false;
     // measurement hook: HIP event pairs around the launches of the step's dominant convolution (eager launches only)
