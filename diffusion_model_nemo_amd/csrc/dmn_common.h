@@ -62,7 +62,8 @@ template <> struct Vec16<__bf16> {
 // Measured on MI355X with two launch chains, per denoising step: default policy +0.3 %, default policy with the
 // non-temporal hint +0.65 %, `sc0 sc1 nt` +5.7 %, `sc0 sc1` as agent scope. Inline assembly because the language has
 // no scoped store of 16 bytes; the trailing s_nop covers the wait states between a wide vector-memory store and a
-// write to its data registers, which the compiler inserts for stores it knows.
+// write to its data registers, which the compiler inserts for stores it knows. dst must point to GLOBAL memory (a
+// tensor in device memory): the instruction takes the pointer's value as a global address.
 template <typename V> __device__ __forceinline__ void store_vec(V* dst, const V& v) {
     if constexpr (sizeof(V) == 16) {
         const u32x4 w = __builtin_bit_cast(u32x4, v);
