@@ -229,13 +229,21 @@ template <typename T> __global__ __launch_bounds__(256) void gn_bwd_apply_kernel
     const T* dy = reinterpret_cast<const T*>(a.dy);
     T* dx = reinterpret_cast<T*>(a.dx);
     __shared__ float S1[64], S2[64];
+    __shared__ float P1[1024], P2[1024];   // C <= 1024 (checked by the launcher)
     const int b = blockIdx.y, tid = threadIdx.x, Cg = a.C / a.G, c4n = a.C >> 2;
+    // gamma * sums per channel by all threads (every load in flight at once), then one thread per group adds its
+    // channels from LDS in channel order: the sums of the plain loop, without one memory round trip per channel
+    for (int c = tid; c < a.C; c += 256) {
+        const float g = a.gamma[c];
+        P1[c] = g * a.sums[((size_t)b * a.C + c) * 3 + 1];
+        P2[c] = g * a.sums[((size_t)b * a.C + c) * 3 + 0];
+    }
+    __syncthreads();
     if (tid < a.G) {
         float t1 = 0.f, t2 = 0.f;
         for (int c = tid * Cg; c < (tid + 1) * Cg; ++c) {
-            const float g = a.gamma[c];
-            t1 += g * a.sums[((size_t)b * a.C + c) * 3 + 1];
-            t2 += g * a.sums[((size_t)b * a.C + c) * 3 + 0];
+            t1 += P1[c];
+            t2 += P2[c];
         }
         S1[tid] = t1;
         S2[tid] = t2;
