@@ -572,11 +572,18 @@ __global__ __launch_bounds__(256) void linattn_ctx_kernel(const T* __restrict__ 
     const T* base = qkv + (size_t)b * n * ld;
     int pb, pe;
     split_range(n, pb, pe);
-    if (tid < 32) {
+    {   // the maximum over all splits (up to 32 of them): eight threads per channel share the splits instead of one
+        // thread walking them one memory round trip at a time; Ks is free until the first barrier of the loop below
         float m = -INFINITY;
-        for (int i = 0; i < (int)gridDim.y; ++i) m = fmaxf(m, pmax[((size_t)bh * gridDim.y + i) * 32 + tid]);
-        kmx[tid] = m;
-        if (blockIdx.y == 0) kstat[(size_t)bh * 64 + tid] = m;
+        for (int i = tid >> 5; i < (int)gridDim.y; i += 8) m = fmaxf(m, pmax[((size_t)bh * gridDim.y + i) * 32 + (tid & 31)]);
+        Ks[tid] = m;
+        __syncthreads();
+        if (tid < 32) {
+            m = Ks[tid];
+            for (int i = 1; i < 8; ++i) m = fmaxf(m, Ks[i * 32 + tid]);
+            kmx[tid] = m;
+            if (blockIdx.y == 0) kstat[(size_t)bh * 64 + tid] = m;
+        }
     }
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, sums = acc;
     for (int p0 = pb; p0 < pe; p0 += 64) {
