@@ -551,7 +551,18 @@ __global__ __launch_bounds__(256) void linattn_kmax_kernel(const T* __restrict__
     split_range(n, pb, pe);
     const int d = tid & 31, pl = tid >> 5;
     float mx = -INFINITY;
-    for (int p = pb + pl; p < pe; p += 8) mx = fmaxf(mx, Io<T>::ld(base + (size_t)p * ld + hid + h * kD + d));
+    {   // eight pixels' loads in flight together (unconditional, from clamped addresses); max is order-independent
+        const T* col = base + hid + h * kD + d;
+        int p = pb + pl;
+        for (; p + 56 < pe; p += 64) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = Io<T>::ld(col + (size_t)(p + 8 * u) * ld);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) mx = fmaxf(mx, v[u]);
+        }
+        for (; p < pe; p += 8) mx = fmaxf(mx, Io<T>::ld(col + (size_t)p * ld));
+    }
     red[pl * 32 + d] = mx;
     __syncthreads();
     if (tid < 32) {
