@@ -597,16 +597,30 @@ __global__ __launch_bounds__(256) void linattn_ctx_kernel(const T* __restrict__ 
         }
     }
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, sums = acc;
+    // the next tile's k and v are requested (unconditionally, from clamped rows) before the current tile's outer
+    // products, so that a tile costs its arithmetic instead of arithmetic plus a memory round trip
+    float kraw[8], vraw[8];
+    auto fetch = [&](int p0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + 256 * i, p = idx >> 5, dd = idx & 31;
+            const int pr = p0 + p < pe ? p0 + p : pe - 1;
+            const T* row = base + (size_t)pr * ld;
+            kraw[i] = Io<T>::ld(row + hid + h * kD + dd);
+            vraw[i] = Io<T>::ld(row + 2 * hid + h * kD + dd);
+        }
+    };
+    if (pb < pe) fetch(pb);
     for (int p0 = pb; p0 < pe; p0 += 64) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int idx = tid + 256 * i, p = idx >> 5, dd = idx & 31;
             const bool ok = p0 + p < pe;
-            const T* row = base + (size_t)(p0 + p) * ld;
-            Ks[p * kLdT + dd] = ok ? expf(Io<T>::ld(row + hid + h * kD + dd) - kmx[dd]) : 0.f;
-            Vs[p * kLdT + dd] = ok ? Io<T>::ld(row + 2 * hid + h * kD + dd) : 0.f;
+            Ks[p * kLdT + dd] = ok ? expf(kraw[i] - kmx[dd]) : 0.f;
+            Vs[p * kLdT + dd] = ok ? vraw[i] : 0.f;
         }
+        if (p0 + 64 < pe) fetch(p0 + 64);
         __syncthreads();
         tile_outer_acc<true>(Ks, Vs, lane, wave, acc, sums);
     }
