@@ -731,11 +731,18 @@ __global__ __launch_bounds__(256) void linattn_out_kernel(const T* __restrict__ 
         CxT[e * 33 + perm_col(d)] = ctx_un[(size_t)bh * 1024 + i] / kstat[(size_t)bh * 64 + 32 + d];
     }
     __syncthreads();
+    float nq[8];   // the next 16 pixels' q, requested before the current ones are worked on
+    if (pb + 16 * wave < pe) load8(base + (size_t)(pb + 16 * wave + r < pe ? pb + 16 * wave + r : pb) * ld + h * kD, q, pb + 16 * wave + r < pe, nq);
     for (int p0 = pb + 16 * wave; p0 < pe; p0 += 64) {
         const int pix = p0 + r;
         const bool ok = pix < pe;
         float qv[8], qs[8], o[8];
-        load8(base + (size_t)pix * ld + h * kD, q, ok, qv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qv[i] = nq[i];
+        if (p0 + 64 < pe) {
+            const int np = p0 + 64 + r;
+            load8(base + (size_t)(np < pe ? np : pb) * ld + h * kD, q, np < pe, nq);
+        }
         softmax8(qv, qs);
         mat32_apply<BF>(CxT, qs, o, r, q);
 #pragma unroll
@@ -757,10 +764,28 @@ __global__ __launch_bounds__(256) void linattn_dctx_kernel(const T* __restrict__
     int pb, pe;
     split_range(n, pb, pe);
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, unused = acc;
+    // the next tile's q and dout rows are requested (from clamped rows) before the current tile is worked on
+    float qa[8], da[8];
+    auto fetch = [&](int p0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + 256 * i, p = idx >> 5, d = idx & 31;
+            const int pr = p0 + p < pe ? p0 + p : pe - 1;
+            qa[i] = Io<T>::ld(base + (size_t)pr * ld + h * kD + d);
+            da[i] = Io<T>::ld(dob + (size_t)pr * hid + h * kD + d);
+        }
+    };
+    if (pb < pe) fetch(pb);
     for (int p0 = pb; p0 < pe; p0 += 64) {
         __syncthreads();
-        load_tile<T, kLdT>(As, base, ld, h * kD, p0, pe, tid, 0.f);
-        load_tile<T, kLdT>(Bs, dob, hid, h * kD, p0, pe, tid, 0.f);   // rows beyond the range are zero: they add nothing
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + 256 * i, p = idx >> 5, d = idx & 31;
+            const bool ok = p0 + p < pe;   // rows beyond the range are zero: they add nothing
+            As[p * kLdT + d] = ok ? qa[i] : 0.f;
+            Bs[p * kLdT + d] = ok ? da[i] : 0.f;
+        }
+        if (p0 + 64 < pe) fetch(p0 + 64);
         __syncthreads();
         softmax_q_rows<kLdT>(As, tid);
         __syncthreads();
@@ -810,15 +835,31 @@ __global__ __launch_bounds__(256) void linattn_bwd_pix_kernel(const T* __restric
         kin8[t] = 1.0f / kstat[(size_t)bh * 64 + 32 + ch];
         sv8[t] = sv[ch];
     }
+    // the next 16 pixels' operands are requested before the current ones are worked on (a memory round trip per
+    // iteration otherwise)
+    float nq[8], nk[8], nv[8], nd[8];
+    auto fetch = [&](int p0) {
+        const int pix = p0 + r;
+        const bool ok = pix < pe;
+        const T* row = base + (size_t)(ok ? pix : pb) * ld + h * kD;
+        load8(row, q, ok, nq);
+        load8(row + hid, q, ok, nk);
+        load8(row + 2 * hid, q, ok, nv);
+        load8(dob + (size_t)(ok ? pix : pb) * hid + h * kD, q, ok, nd);
+    };
+    if (pb + 16 * wave < pe) fetch(pb + 16 * wave);
     for (int p0 = pb + 16 * wave; p0 < pe; p0 += 64) {
         const int pix = p0 + r;
         const bool ok = pix < pe;
-        const T* row = base + (size_t)pix * ld + h * kD;
         float qv[8], kv[8], vv[8], dov[8], qs[8], y[8], res[8];
-        load8(row, q, ok, qv);
-        load8(row + hid, q, ok, kv);
-        load8(row + 2 * hid, q, ok, vv);
-        load8(dob + (size_t)pix * hid + h * kD, q, ok, dov);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            qv[i] = nq[i];
+            kv[i] = nk[i];
+            vv[i] = nv[i];
+            dov[i] = nd[i];
+        }
+        if (p0 + 64 < pe) fetch(p0 + 64);
         softmax8(qv, qs);
         // dqhat[d] = sum_e ctx[d][e] dout[e]; dq = scale * s[d] * (dqhat[d] - sum_d' s[d'] dqhat[d'])
         mat32_apply<BF>(Cx, dov, y, r, q);
