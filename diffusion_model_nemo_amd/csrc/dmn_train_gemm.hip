@@ -960,15 +960,33 @@ template <typename T, bool BF> static void wgemm_dispatch(const WGemmArgs& a, in
 }
 
 // Workgroups a weight-gradient launch aims for: every workgroup ends with one float atomic per element of its output
-// tile, so more pixel splits buy occupancy with atomic traffic (2048 splits of a 64x64 tile are 8 M atomics).
-static int wgemm_wg_target() {
-    static int v = 0;
-    if (!v) {
+// tile, so more pixel splits buy occupancy with atomic traffic (2048 splits of a 64x64 tile are 8 M atomics). These
+// launches run beside the chain of pixel kernels and the step ends when the last of them does, so the step time follows
+// this number closely (measured, ms per step at 128 / 256 / 320 / 384 / 512 / 1024: fp32 activations 11.6 / 10.42 /
+// 10.44 / 10.46 / 10.75 / 11.8; bf16 activations, whose 8-byte loads leave a workgroup with half the bytes in flight,
+// 14.6 / 10.63 / 10.16 / 10.18 / 10.38 / 11.2).
+static int wgemm_wg_target(int adt) {
+    static int v = -1;
+    if (v < 0) {
         const char* e = getenv("DMN_WGEMM_WGS");
-        v = e ? atoi(e) : 256;
-        if (v < 64) v = 64;
+        v = e ? atoi(e) : 0;
+        if (v && v < 64) v = 64;
     }
-    return v;
+    return v ? v : (adt == 1 ? 352 : 256);
+}
+// ... and for launches whose whole weight block is one or two tiles (the 32-channel layers at full resolution): every
+// split adds to the same one or two thousand addresses, and that contention costs more than the occupancy buys
+// (measured, ms per step at 64 / 128 / 192 / 256 / 512 / 1024 / 4096 for these launches alone: fp32 activations 10.70 /
+// 10.41 / 10.38 / 10.43 / 10.61 / 11.03 / 12.9; bf16 activations - / 10.45 / 10.17 / 10.13 / 10.30 / 10.69 / 12.3).
+static int wgemm_small_target(int adt, int tiles_kn) {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("DMN_WGEMM_SMALL_WGS");
+        v = e ? atoi(e) : 0;
+        if (v && v < 32) v = 32;
+    }
+    if (tiles_kn > 2) return wgemm_wg_target(adt);
+    return v ? v : (adt == 1 ? 256 : 192);
 }
 
 int launch_wgemm(const WGemmArgs& a, hipStream_t s) {
@@ -982,7 +1000,7 @@ int launch_wgemm(const WGemmArgs& a, hipStream_t s) {
     if (!slow && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.tmode == 0 && (a.Ho & 7) == 0 && (a.Wo & 7) == 0 &&
         a.Hi == a.Ho && a.Wi == a.Wo && (a.lddy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.dy) & 15) == 0) {
         const int tiles = a.B * (a.Ho >> 3) * (a.Wo >> 3), cit = a.Cin / 32, cot = (a.N + 31) / 32;
-        int ns = wgemm_wg_target() / (cit * cot);
+        int ns = wgemm_small_target(a.adt, cit * cot) / (cit * cot);
         if (ns > tiles) ns = tiles;
         if (ns < 1) ns = 1;
         const int per = (tiles + ns - 1) / ns;
@@ -996,7 +1014,7 @@ int launch_wgemm(const WGemmArgs& a, hipStream_t s) {
     }
     const int tm = (!slow && big_m) ? 64 : 32, tn = big_n ? 64 : 32;
     const int rt = (K + tm - 1) / tm, ct = (a.N + tn - 1) / tn;
-    int nsplit = wgemm_wg_target() / (rt * ct);
+    int nsplit = wgemm_small_target(a.adt, rt * ct) / (rt * ct);
     const int max_split = (M + 127) / 128;
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;
