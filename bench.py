@@ -140,13 +140,13 @@ def _dry_train_step(dev, rank, world):
     return step
 
 
-def _real_train_step(dev, rank):
+def _real_train_step(dev, rank, activations=None):
     from diffusion_model_nemo_amd.modules import GaussianDiffusion, Unet
     from diffusion_model_nemo_amd.training import UnetTrainer, cosine_annealing_lr
     Bt, St = 32, 128
     net = Unet(input_dim=St, dim=32, dim_mults=[1, 2, 4, 8], channels=3, resnet_block_groups=8, use_convnext=False,
                dropout=0.0, compute_dtype="bf16").to(dev)
-    tr = UnetTrainer(net, "l2")
+    tr = UnetTrainer(net, "l2", activations=activations)
     gd = GaussianDiffusion(timesteps=1000, schedule_name="cosine")
     sa, sb = gd.sqrt_alphas_cumprod.to(dev), gd.sqrt_one_minus_alphas_cumprod.to(dev)
     gen = torch.Generator(device=dev).manual_seed(100 + rank)
@@ -209,7 +209,27 @@ def train_step_extra(dev, rank, world, dist, dry=False):
     if dist is not None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
-    return {"metric": "images/sec, DDPM training step (q_sample + fwd + L_simple + bwd + grad all-reduce + clip + AdamW)",
+    other = None
+    if dist is None and not dry:
+        # the same step with the saved activations STORED in bf16 (wider gradient band, see the training tests): reported
+        # beside the default mode, single GPU only
+        try:
+            del step
+            step2 = _real_train_step(dev, rank, activations="bf16")
+            for i in range(1 + warm):
+                loss2 = step2(i, True)
+            sync()
+            t0 = time.perf_counter()
+            for i in range(iters):
+                loss2 = step2(1 + warm + i, True)
+            sync()
+            dt2 = (time.perf_counter() - t0) / iters
+            other = {"value": 32 / dt2, "unit": "images/sec", "ms_per_step": dt2 * 1e3, "loss": float(loss2),
+                     "dtype": "bf16 matrix-core operands and activation storage, fp32 accumulate / optimiser"}
+        except Exception as e:   # noqa: BLE001
+            print(f"[bench] bf16-activation training step skipped: {e}", file=sys.stderr)
+    return {"bf16_activation_storage": other,
+            "metric": "images/sec, DDPM training step (q_sample + fwd + L_simple + bwd + grad all-reduce + clip + AdamW)",
             "value": 32 * world / dt, "unit": "images/sec", "ms_per_step": dt * 1e3, "n_gpus": world,
             "config": {"workload": "128x128x3 DDPM U-Net (dim 32, mults 1-2-4-8), 32 images per GPU", "global_batch": 32 * world,
                        "parallelism": f"dp{world}, one all-reduce of 32.3 MB fp32 gradients per step"},

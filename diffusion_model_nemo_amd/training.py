@@ -41,8 +41,8 @@ class UnetTrainer:
         """`unet.compute_dtype` selects the matrix-core operand type ('fp32' exact, 'bf16' rounded operands with fp32
         accumulation). `activations` selects how the saved activations and their gradients are stored: 'fp32', or
         'bf16' (only with bf16 operands; halves the workspace and the step's memory traffic at a wider gradient error
-        band; parameters, their gradients, statistics and the optimiser stay fp32). Default 'fp32': the kernels are
-        latency- rather than bandwidth-bound today, so the narrower storage buys memory, not time."""
+        band; parameters, their gradients, statistics and the optimiser stay fp32). Default 'fp32', the parity mode; on one MI355X the bf16
+        storage moves 29 GB instead of 48 GB per step of 32 images at 128x128 and takes 10.1 ms instead of 10.4."""
         if loss_type not in LOSS_KINDS:
             raise ValueError("loss_type must be 'l1', 'l2' or 'huber'")
         if activations is None:

@@ -6,7 +6,8 @@
 #             the per-dispatch trace is deleted), the same with ONE launch chain plus its step timeline, FETCH_SIZE and
 #             WRITE_SIZE passes (one counter per run) over a short chain, one matrix-core counter pass
 #   counters  two SQ counter passes over a 10-step chain, summarised per kernel
-#   training  configuration-5 timings in the three modes, kernel stats, HBM traffic of one step (two counter passes)
+#   training  configuration-5 timings in the three modes, kernel stats, HBM traffic of one step (two counter passes), the
+#             last two also with bf16 activation storage
 #   extras    improved-DDPM bench line, exchange stress, A/B of the in-launch exchanges against separate closing passes
 #   bygrid    a 300-step two-chain bench under the kernel trace, summarised per (kernel, grid); extra bench arguments
 #             after "--"
@@ -87,6 +88,21 @@ t["achieved_TBs_over_the_step"] = t["total_GB"] / b["ms_per_step"]
 json.dump(t, open("$o/${tag}_train_traffic.json", "w"), indent=1)
 PY
     find $o/${tag}_pmc_train_* -name "*.csv" -size +20M -delete
+    # the same with the saved activations stored in bf16: per-kernel times and traffic
+    run_log $o/${tag}_prof_train_bf16act.log 300 rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_prof_train_bf16act -- python tools/train_bench.py --steps 3 --warmup 1 --activations bf16
+    for t in $(find $o/${tag}_prof_train_bf16act -name "*_kernel_stats.csv"); do cp $t $o/${tag}_train_bf16_activations_kernel_stats.csv; done
+    find $o/${tag}_prof_train_bf16act -name "*_kernel_trace.csv" -size +20M -delete
+    for c in FETCH_SIZE WRITE_SIZE; do pmc_run $o/${tag}_pmc_trainb_$c $c -- python tools/train_bench.py --steps 1 --warmup 1 --activations bf16; done
+    python tools/train_traffic.py $o/${tag}_pmc_trainb_FETCH_SIZE $o/${tag}_pmc_trainb_WRITE_SIZE $o/${tag}_train_traffic_bf16_activations.json > /dev/null || exit 1
+    python - <<PY
+import json
+t = json.load(open("$o/${tag}_train_traffic_bf16_activations.json"))
+b = json.loads(open("$o/${tag}_train_bench_bf16_activations.json").read())
+t["ms_per_step_of_this_build"] = b["ms_per_step"]
+t["achieved_TBs_over_the_step"] = t["total_GB"] / b["ms_per_step"]
+json.dump(t, open("$o/${tag}_train_traffic_bf16_activations.json", "w"), indent=1)
+PY
+    find $o/${tag}_pmc_trainb_* -name "*.csv" -size +20M -delete
     ;;
   extras)
     run_log $o/${tag}_bench_improved_ddpm.log 300 python bench.py --learned-variance --no-train --no-cpu-baseline
