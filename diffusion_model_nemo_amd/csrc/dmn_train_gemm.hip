@@ -989,6 +989,18 @@ static int wgemm_small_target(int adt, int tiles_kn) {
     return v ? v : (adt == 1 ? 256 : 192);
 }
 
+// ... and for the element-wise gather path (the 3-channel ingest convolution): its output gradient is the last tensor
+// of the backward pass, so this launch runs alone at the end of the step, where only its own length counts
+static int wgemm_slow_target() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("DMN_WGEMM_SLOW_WGS");
+        v = e ? atoi(e) : 1024;   // ms per step at 256 / 512 / 1024 / 2048 / 4096 / 8192: 10.49 / 10.39 / 10.35 / 10.38 / 10.37 / 10.44
+        if (v < 64) v = 64;
+    }
+    return v;
+}
+
 int launch_wgemm(const WGemmArgs& a, hipStream_t s) {
     DMN_REQUIRE(a.x && a.dy && a.dw && a.B > 0 && a.N > 0 && a.Cin > 0, DMN_ERR_INVALID, "wgemm: bad argument");
     const long long Ml = (long long)a.B * a.Ho * a.Wo;
@@ -1014,7 +1026,7 @@ int launch_wgemm(const WGemmArgs& a, hipStream_t s) {
     }
     const int tm = (!slow && big_m) ? 64 : 32, tn = big_n ? 64 : 32;
     const int rt = (K + tm - 1) / tm, ct = (a.N + tn - 1) / tn;
-    int nsplit = wgemm_small_target(a.adt, rt * ct) / (rt * ct);
+    int nsplit = (slow ? wgemm_slow_target() : wgemm_small_target(a.adt, rt * ct)) / (rt * ct);
     const int max_split = (M + 127) / 128;
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;
