@@ -1271,26 +1271,109 @@ __device__ __forceinline__ void repack_index(const RepackDesc& d, long long idx,
         co = (int)(r / d.n_in);
     }
 }
+// Tiles of 32 outer x 32 (16 for 4x4 kernels) inner channels with all their taps pass through LDS, so that the reference
+// layout ([outer][inner][tap], rows of inner * taps contiguous floats) and both GEMM layouts are read and written in
+// contiguous 64-128 byte runs; element by element the two transposed copies were 4-byte writes a row apart each.
+// Kernels with more than 16 taps (the 7x7 ingest convolution: a few thousand elements) keep the element-wise walk.
+constexpr int kRpMaxTaps = 16;
+constexpr int kRpLds = 32 * 297;   // 32 rows of taps * (CT + 1) floats, made odd: 9 * 33 = 297, 16 * 17 + 1 = 273
+struct RepackTile {
+    int R, Cn, taps, CT, CTP, ldl, tc, ntiles;
+    __device__ __forceinline__ RepackTile(const RepackDesc& d) {
+        R = d.transposed ? d.n_in : d.n_out;     // outer dimension of the reference tensor
+        Cn = d.transposed ? d.n_out : d.n_in;    // inner
+        taps = d.taps;
+        CT = taps <= 9 ? 32 : 16;
+        CTP = CT + 1;
+        ldl = (taps * CTP) | 1;
+        tc = (Cn + CT - 1) / CT;
+        ntiles = ((R + 31) / 32) * tc;
+    }
+};
 __global__ __launch_bounds__(256) void repack_kernel(const RepackDesc* __restrict__ descs, const float* __restrict__ params,
                                                      float* __restrict__ wf, float* __restrict__ wb) {
+    __shared__ float L[kRpLds];
     const RepackDesc d = descs[blockIdx.y];
-    const long long numel = (long long)d.n_out * d.n_in * d.taps;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < numel; idx += (long long)gridDim.x * 256) {
-        int co, ci, tap;
-        repack_index(d, idx, co, ci, tap);
-        const float v = params[d.src_off + idx];
-        wf[d.f_off + ((long long)tap * d.n_in + ci) * d.f_ld + co] = v;
-        wb[d.b_off + ((long long)tap * d.n_out + co) * d.b_ld + ci] = v;
+    const int tid = threadIdx.x;
+    if (d.taps > kRpMaxTaps) {
+        const long long numel = (long long)d.n_out * d.n_in * d.taps;
+        for (long long idx = (long long)blockIdx.x * 256 + tid; idx < numel; idx += (long long)gridDim.x * 256) {
+            int co, ci, tap;
+            repack_index(d, idx, co, ci, tap);
+            const float v = params[d.src_off + idx];
+            wf[d.f_off + ((long long)tap * d.n_in + ci) * d.f_ld + co] = v;
+            wb[d.b_off + ((long long)tap * d.n_out + co) * d.b_ld + ci] = v;
+        }
+        return;
+    }
+    const RepackTile t(d);
+    // destination A: rows (tap, inner), contiguous over outer; destination B: rows (tap, outer), contiguous over inner
+    float* A = d.transposed ? wb + d.b_off : wf + d.f_off;
+    float* Bp = d.transposed ? wf + d.f_off : wb + d.b_off;
+    const int ldA = d.transposed ? d.b_ld : d.f_ld, ldB = d.transposed ? d.f_ld : d.b_ld;
+    const int grp = tid >> 5, l = tid & 31;
+    for (int tile = blockIdx.x; tile < t.ntiles; tile += gridDim.x) {
+        const int r0 = (tile / t.tc) * 32, c0 = (tile % t.tc) * t.CT;
+        const int rw = min(32, t.R - r0), cw = min(t.CT, t.Cn - c0), rowlen = cw * t.taps;
+        __syncthreads();   // the previous tile has been written out
+        for (int r = grp; r < rw; r += 8) {
+            const float* src = params + d.src_off + ((long long)(r0 + r) * t.Cn + c0) * t.taps;
+            for (int j = l; j < rowlen; j += 32) {
+                const int c = j / t.taps, tap = j - c * t.taps;
+                L[r * t.ldl + tap * t.CTP + c] = src[j];
+            }
+        }
+        __syncthreads();
+        for (int row = grp; row < t.taps * cw; row += 8) {
+            const int tap = row / cw, c = row - tap * cw;
+            if (l < rw) A[((long long)tap * t.Cn + c0 + c) * ldA + r0 + l] = L[l * t.ldl + tap * t.CTP + c];
+        }
+        for (int row = grp; row < t.taps * rw; row += 8) {
+            const int tap = row / rw, r = row - tap * rw;
+            if (l < cw) Bp[((long long)tap * t.R + r0 + r) * ldB + c0 + l] = L[r * t.ldl + tap * t.CTP + l];
+        }
     }
 }
 __global__ __launch_bounds__(256) void unpack_grads_kernel(const RepackDesc* __restrict__ descs, const float* __restrict__ dwf,
                                                            float* __restrict__ grads) {
+    __shared__ float L[kRpLds];
     const RepackDesc d = descs[blockIdx.y];
-    const long long numel = (long long)d.n_out * d.n_in * d.taps;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < numel; idx += (long long)gridDim.x * 256) {
-        int co, ci, tap;
-        repack_index(d, idx, co, ci, tap);
-        grads[d.src_off + idx] = dwf[d.f_off + ((long long)tap * d.n_in + ci) * d.f_ld + co];
+    const int tid = threadIdx.x;
+    if (d.taps > kRpMaxTaps) {
+        const long long numel = (long long)d.n_out * d.n_in * d.taps;
+        for (long long idx = (long long)blockIdx.x * 256 + tid; idx < numel; idx += (long long)gridDim.x * 256) {
+            int co, ci, tap;
+            repack_index(d, idx, co, ci, tap);
+            grads[d.src_off + idx] = dwf[d.f_off + ((long long)tap * d.n_in + ci) * d.f_ld + co];
+        }
+        return;
+    }
+    const RepackTile t(d);
+    const float* src = dwf + d.f_off;   // rows (tap, cin) of f_ld floats: contiguous over the outer dimension unless transposed
+    const int grp = tid >> 5, l = tid & 31;
+    for (int tile = blockIdx.x; tile < t.ntiles; tile += gridDim.x) {
+        const int r0 = (tile / t.tc) * 32, c0 = (tile % t.tc) * t.CT;
+        const int rw = min(32, t.R - r0), cw = min(t.CT, t.Cn - c0), rowlen = cw * t.taps;
+        __syncthreads();
+        if (!d.transposed) {
+            for (int row = grp; row < t.taps * cw; row += 8) {
+                const int tap = row / cw, c = row - tap * cw;
+                if (l < rw) L[l * t.ldl + tap * t.CTP + c] = src[((long long)tap * t.Cn + c0 + c) * d.f_ld + r0 + l];
+            }
+        } else {
+            for (int row = grp; row < t.taps * rw; row += 8) {
+                const int tap = row / rw, r = row - tap * rw;
+                if (l < cw) L[r * t.ldl + tap * t.CTP + l] = src[((long long)tap * t.R + r0 + r) * d.f_ld + c0 + l];
+            }
+        }
+        __syncthreads();
+        for (int r = grp; r < rw; r += 8) {
+            float* dst = grads + d.src_off + ((long long)(r0 + r) * t.Cn + c0) * t.taps;
+            for (int j = l; j < rowlen; j += 32) {
+                const int c = j / t.taps, tap = j - c * t.taps;
+                dst[j] = L[r * t.ldl + tap * t.CTP + c];
+            }
+        }
     }
 }
 
@@ -1514,12 +1597,12 @@ int launch_attn_train_bwd(const void* qkv, const void* out, const void* dout, in
 }
 int launch_repack(const RepackDesc* descs_dev, int n_desc, long long max_numel, const float* params, float* wf, float* wb,
                   hipStream_t s) {
-    repack_kernel<<<dim3(grid_for(max_numel, 1024, 256), n_desc), 256, 0, s>>>(descs_dev, params, wf, wb);
+    repack_kernel<<<dim3(grid_for(max_numel, 4096, 128), n_desc), 256, 0, s>>>(descs_dev, params, wf, wb);
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }
 int launch_unpack_grads(const RepackDesc* descs_dev, int n_desc, long long max_numel, const float* dwf, float* grads, hipStream_t s) {
-    unpack_grads_kernel<<<dim3(grid_for(max_numel, 1024, 256), n_desc), 256, 0, s>>>(descs_dev, dwf, grads);
+    unpack_grads_kernel<<<dim3(grid_for(max_numel, 4096, 128), n_desc), 256, 0, s>>>(descs_dev, dwf, grads);
     DMN_LAUNCH_CHECK();
     return DMN_OK;
 }
