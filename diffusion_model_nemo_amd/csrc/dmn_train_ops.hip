@@ -1276,6 +1276,7 @@ __device__ __forceinline__ void repack_index(const RepackDesc& d, long long idx,
 // contiguous 64-128 byte runs; element by element the two transposed copies were 4-byte writes a row apart each.
 // Kernels with more than 16 taps (the 7x7 ingest convolution: a few thousand elements) keep the element-wise walk.
 constexpr int kRpMaxTaps = 16;
+constexpr int kRpBatch = 12;
 constexpr int kRpLds = 32 * 297;   // 32 rows of taps * (CT + 1) floats, made odd: 9 * 33 = 297, 16 * 17 + 1 = 273
 struct RepackTile {
     int R, Cn, taps, CT, CTP, ldl, tc, ntiles;
@@ -1316,12 +1317,22 @@ __global__ __launch_bounds__(256) void repack_kernel(const RepackDesc* __restric
         const int r0 = (tile / t.tc) * 32, c0 = (tile % t.tc) * t.CT;
         const int rw = min(32, t.R - r0), cw = min(t.CT, t.Cn - c0), rowlen = cw * t.taps;
         __syncthreads();   // the previous tile has been written out
-        for (int r = grp; r < rw; r += 8) {
-            const float* src = params + d.src_off + ((long long)(r0 + r) * t.Cn + c0) * t.taps;
-            for (int j = l; j < rowlen; j += 32) {
-                const int c = j / t.taps, tap = j - c * t.taps;
-                L[r * t.ldl + tap * t.CTP + c] = src[j];
+        // kRpBatch loads in flight per thread (one after the other they cost a memory round trip each)
+        const float* src = params + d.src_off + ((long long)r0 * t.Cn + c0) * t.taps;
+        const int total = rw * rowlen, rstride = t.Cn * t.taps;
+        for (int e0 = tid; e0 < total; e0 += 256 * kRpBatch) {
+            float v[kRpBatch];
+            int at[kRpBatch];
+#pragma unroll
+            for (int u = 0; u < kRpBatch; ++u) {
+                const int e = min(e0 + 256 * u, total - 1);
+                const int r = e / rowlen, j = e - r * rowlen, c = j / t.taps, tap = j - c * t.taps;
+                v[u] = src[(long long)r * rstride + j];
+                at[u] = r * t.ldl + tap * t.CTP + c;
             }
+#pragma unroll
+            for (int u = 0; u < kRpBatch; ++u)
+                if (e0 + 256 * u < total) L[at[u]] = v[u];
         }
         __syncthreads();
         for (int row = grp; row < t.taps * cw; row += 8) {
@@ -1355,16 +1366,23 @@ __global__ __launch_bounds__(256) void unpack_grads_kernel(const RepackDesc* __r
         const int r0 = (tile / t.tc) * 32, c0 = (tile % t.tc) * t.CT;
         const int rw = min(32, t.R - r0), cw = min(t.CT, t.Cn - c0), rowlen = cw * t.taps;
         __syncthreads();
-        if (!d.transposed) {
-            for (int row = grp; row < t.taps * cw; row += 8) {
-                const int tap = row / cw, c = row - tap * cw;
-                if (l < rw) L[l * t.ldl + tap * t.CTP + c] = src[((long long)tap * t.Cn + c0 + c) * d.f_ld + r0 + l];
+        // rows of 32 lanes: (tap, inner) x outer, or (tap, outer) x inner when transposed; kRpBatch loads in flight
+        const int per = d.transposed ? rw : cw, lanes = d.transposed ? cw : rw, nrows = t.taps * per;
+        const long long base = d.transposed ? (long long)r0 * d.f_ld + c0 : (long long)c0 * d.f_ld + r0;
+        const long long tapstride = (long long)(d.transposed ? t.R : t.Cn) * d.f_ld;
+        for (int row0 = grp; row0 < nrows; row0 += 8 * kRpBatch) {
+            float v[kRpBatch];
+            int at[kRpBatch];
+#pragma unroll
+            for (int u = 0; u < kRpBatch; ++u) {
+                const int row = min(row0 + 8 * u, nrows - 1);
+                const int tap = row / per, i = row - tap * per, ll = min(l, lanes - 1);
+                v[u] = src[base + tap * tapstride + (long long)i * d.f_ld + ll];
+                at[u] = d.transposed ? i * t.ldl + tap * t.CTP + ll : ll * t.ldl + tap * t.CTP + i;
             }
-        } else {
-            for (int row = grp; row < t.taps * rw; row += 8) {
-                const int tap = row / rw, r = row - tap * rw;
-                if (l < cw) L[r * t.ldl + tap * t.CTP + l] = src[((long long)tap * t.R + r0 + r) * d.f_ld + c0 + l];
-            }
+#pragma unroll
+            for (int u = 0; u < kRpBatch; ++u)
+                if (row0 + 8 * u < nrows && l < lanes) L[at[u]] = v[u];
         }
         __syncthreads();
         for (int r = grp; r < rw; r += 8) {
