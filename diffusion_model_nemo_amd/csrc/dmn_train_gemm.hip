@@ -735,7 +735,7 @@ __global__ __launch_bounds__(256) void wgemm_kernel(const WGemmArgs a, const int
 // per 8x8 pixel tile the 10x10 halo of x and the tile of dy are staged once and every tap takes its A operand from the
 // halo at its own offset (the per-tap kernel above reads both tensors nine times). Wave w owns the 16x16 block
 // (w >> 1, w & 1) of every tap: nine accumulators.
-template <typename T, bool BF>
+template <typename T, bool BF, bool DEEP>
 __global__ __launch_bounds__(256) void wgemm_halo_kernel(const WGemmArgs a, const int tiles, const int per) {
     const T* x = reinterpret_cast<const T*>(a.x);
     const T* dy = reinterpret_cast<const T*>(a.dy);
@@ -752,54 +752,52 @@ __global__ __launch_bounds__(256) void wgemm_halo_kernel(const WGemmArgs a, cons
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    f32x4 xr[4], yr[2];
-    auto load_tile = [&](int tile) {
+    // DEEP: two tiles' operands in flight (register sets A / B alternate) instead of one: a workgroup walks its tiles one
+    // after the other and a tile's matrix work hides nothing of the next round trip. It pays where the step is not
+    // bound by memory bandwidth as a whole (bf16 activation storage: -2.3 % step time) and costs where it is (fp32
+    // storage: +1 %), so the launcher picks by storage type. Every load is issued unconditionally from a clamped
+    // address and masked when stored: a load inside a branch makes the compiler wait for ALL outstanding loads before
+    // each use, which would turn two tiles in flight into none. The launcher guarantees N % 4 == 0.
+    f32x4 xa[4], ya[2], xb[4], yb[2];
+    unsigned ma = 0, mb = 0;                 // bit i: halo piece i of the set lies inside the image
+    const int yn = n0 + (tid & 7) * 4;
+    const bool yok = yn < a.N;
+    auto load_tile = [&](int tile, f32x4 (&xr)[4], f32x4 (&yr)[2], unsigned& m) {
         const int b = tile / (tw * th), trem = tile - b * tw * th;
         const int oy0 = (trem / tw) * 8, ox0 = (trem % tw) * 8;
+        m = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i;
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (idx < 800) {
-                const int pix = idx >> 3, c4 = (idx & 7) * 4;
-                const int hy = pix / 10, hx = pix - hy * 10;
-                const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-                if (iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi)
-                    v = Io<T>::ld4(x + ((size_t)(b * a.Hi + iy) * a.Wi + ix) * a.ldx + ci0 + c4);
-            }
-            xr[i] = v;
+            const int idx = min(tid + 256 * i, 799);
+            const int pix = idx >> 3, c4 = (idx & 7) * 4;
+            const int hy = pix / 10, hx = pix - hy * 10;
+            const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+            const bool in = (iy >= 0) & (iy < a.Hi) & (ix >= 0) & (ix < a.Wi);
+            m |= (unsigned)in << i;
+            const int cy = min(max(iy, 0), a.Hi - 1), cx = min(max(ix, 0), a.Wi - 1);
+            xr[i] = Io<T>::ld4(x + ((size_t)(b * a.Hi + cy) * a.Wi + cx) * a.ldx + ci0 + c4);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int idx = tid + 256 * i, pix = idx >> 3, c4 = (idx & 7) * 4;
-            const int n = n0 + c4;
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            const T* p = dy + ((size_t)(b * a.Ho + oy0 + (pix >> 3)) * a.Wo + ox0 + (pix & 7)) * a.lddy + n;
-            if (n + 3 < a.N) {
-                v = Io<T>::ld4(p);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (n + e < a.N) v[e] = Io<T>::ld(p + e);
-            }
-            yr[i] = v;
+            const int pix = (tid + 256 * i) >> 3;
+            yr[i] = Io<T>::ld4(dy + ((size_t)(b * a.Ho + oy0 + (pix >> 3)) * a.Wo + ox0 + (pix & 7)) * a.lddy + (yok ? yn : 0));
         }
     };
-    if (t0 < t1) load_tile(t0);
-    for (int tile = t0; tile < t1; ++tile) {
+    auto work = [&](int tile, f32x4 (&xr)[4], f32x4 (&yr)[2], unsigned& m) {
         __syncthreads();
+        const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = tid + 256 * i;
-            if (idx < 800) *reinterpret_cast<f32x4*>(&Xs[(idx >> 3) * LDX + (idx & 7) * 4]) = xr[i];
+            if (idx < 800) *reinterpret_cast<f32x4*>(&Xs[(idx >> 3) * LDX + (idx & 7) * 4]) = ((m >> i) & 1u) ? xr[i] : zero;
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int idx = tid + 256 * i;
-            *reinterpret_cast<f32x4*>(&Ys[(idx >> 3) * LDY + (idx & 7) * 4]) = yr[i];
+            *reinterpret_cast<f32x4*>(&Ys[(idx >> 3) * LDY + (idx & 7) * 4]) = yok ? yr[i] : zero;
         }
         __syncthreads();
-        if (tile + 1 < t1) load_tile(tile + 1);
+        load_tile(min(tile + (DEEP ? 2 : 1), t1 - 1), xr, yr, m);   // past the end: a repeated, unused load instead of a branch
         if (do_bias) {
 #pragma unroll 8
             for (int p = 0; p < 64; ++p) bsum += Ys[p * LDY + tid];
@@ -836,6 +834,18 @@ __global__ __launch_bounds__(256) void wgemm_halo_kernel(const WGemmArgs a, cons
                 }
             }
         }
+    };
+    if (t0 < t1) {
+        load_tile(t0, xa, ya, ma);
+        if constexpr (DEEP) load_tile(min(t0 + 1, t1 - 1), xb, yb, mb);
+    }
+    if constexpr (DEEP) {
+        for (int tile = t0; tile < t1; tile += 2) {
+            work(tile, xa, ya, ma);
+            if (tile + 1 < t1) work(tile + 1, xb, yb, mb);
+        }
+    } else {
+        for (int tile = t0; tile < t1; ++tile) work(tile, xa, ya, ma);
     }
     if (t0 >= t1) return;
     if (do_bias && n0 + tid < a.N) unsafeAtomicAdd(a.dbias + n0 + tid, bsum);
@@ -1010,7 +1020,7 @@ int launch_wgemm(const WGemmArgs& a, hipStream_t s) {
     const bool big_m = (a.Cin % 64) == 0, big_n = a.N > 32;
     const bool slow = (a.Cin & 31) != 0 || (a.ldx & 3) != 0 || (reinterpret_cast<uintptr_t>(a.x) & 15) != 0;
     if (!slow && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.tmode == 0 && (a.Ho & 7) == 0 && (a.Wo & 7) == 0 &&
-        a.Hi == a.Ho && a.Wi == a.Wo && (a.lddy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.dy) & 15) == 0) {
+        a.Hi == a.Ho && a.Wi == a.Wo && (a.lddy & 3) == 0 && (a.N & 3) == 0 && (reinterpret_cast<uintptr_t>(a.dy) & 15) == 0) {
         const int tiles = a.B * (a.Ho >> 3) * (a.Wo >> 3), cit = a.Cin / 32, cot = (a.N + 31) / 32;
         int ns = wgemm_small_target(a.adt, cit * cot) / (cit * cot);
         if (ns > tiles) ns = tiles;
@@ -1018,9 +1028,9 @@ int launch_wgemm(const WGemmArgs& a, hipStream_t s) {
         const int per = (tiles + ns - 1) / ns;
         ns = (tiles + per - 1) / per;
         DMN_REQUIRE(cit <= 65535 && cot <= 65535, DMN_ERR_LIMIT, "wgemm: grid %d x %d", cit, cot);
-        if (a.adt == 1) wgemm_halo_kernel<__bf16, true><<<dim3(ns, cit, cot), 256, 0, s>>>(a, tiles, per);
-        else if (a.bf16) wgemm_halo_kernel<float, true><<<dim3(ns, cit, cot), 256, 0, s>>>(a, tiles, per);
-        else wgemm_halo_kernel<float, false><<<dim3(ns, cit, cot), 256, 0, s>>>(a, tiles, per);
+        if (a.adt == 1) wgemm_halo_kernel<__bf16, true, true><<<dim3(ns, cit, cot), 256, 0, s>>>(a, tiles, per);
+        else if (a.bf16) wgemm_halo_kernel<float, true, false><<<dim3(ns, cit, cot), 256, 0, s>>>(a, tiles, per);
+        else wgemm_halo_kernel<float, false, false><<<dim3(ns, cit, cot), 256, 0, s>>>(a, tiles, per);
         DMN_LAUNCH_CHECK();
         return DMN_OK;
     }
