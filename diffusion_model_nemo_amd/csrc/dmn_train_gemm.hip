@@ -588,7 +588,7 @@ __global__ __launch_bounds__(256) void pgemm_halo_kernel(const PGemmArgs a) {
 // Weight gradient tile TM (weight rows = (tap, cin)) x TN (cout) per workgroup, reduced over a contiguous range of
 // output pixels; 32 pixels per stage staged through LDS pixel-major for both operands (the MFMA's k index is the
 // pixel). Partial sums of the pixel splits meet in dw through hardware float atomics.
-template <typename T, int TM, int TN, bool SLOW, bool BF>
+template <typename T, int TM, int TN, bool SLOW, bool BF, bool DEEP = false>
 __global__ __launch_bounds__(256) void wgemm_kernel(const WGemmArgs a, const int M, const int chunk) {
     const T* x = reinterpret_cast<const T*>(a.x);
     const T* dy = reinterpret_cast<const T*>(a.dy);
@@ -666,14 +666,8 @@ __global__ __launch_bounds__(256) void wgemm_kernel(const WGemmArgs a, const int
         }
     };
 
-    if (ms < me) load_stage(ms);
-    for (int mb = ms; mb < me; mb += 32) {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) *reinterpret_cast<f32x4*>(&Xs[(tid / TPX + i * PPX) * LDX + (tid % TPX) * 4]) = xn[i];
-#pragma unroll
-        for (int i = 0; i < NY; ++i) *reinterpret_cast<f32x4*>(&Ys[(tid / TPY + i * PPY) * LDY + (tid % TPY) * 4]) = yn[i];
-        __syncthreads();
-        if (mb + 32 < me) load_stage(mb + 32);
+    // the stage in LDS: bias sums and matrix products
+    auto compute = [&]() {
         if (do_bias) {
 #pragma unroll 8
             for (int p = 0; p < 32; ++p) bsum += Ys[p * LDY + tid];
@@ -713,7 +707,70 @@ __global__ __launch_bounds__(256) void wgemm_kernel(const WGemmArgs a, const int
                     for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
             }
         }
-        __syncthreads();
+    };
+    if constexpr (DEEP) {
+        // Two stages' operands in flight (register sets A / B alternate), loads unconditional from clamped addresses and
+        // masked when stored (see wgemm_halo_kernel); the launcher guarantees vector-aligned dy rows and N % 4 == 0.
+        f32x4 xb[NX], yb[NY];
+        unsigned mxa = 0, mya = 0, mxb = 0, myb = 0;
+        const int yn0 = n0 + (tid % TPY) * 4;
+        const bool ynok = yn0 < a.N;
+        auto load_u = [&](int mb, f32x4 (&X)[NX], f32x4 (&Y)[NY], unsigned& mx, unsigned& my) {
+            mx = my = 0;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const int m = mb + tid / TPX + i * PPX, c4 = (tid % TPX) * 4;
+                const int mc = min(m, me - 1);
+                const int b = mc / hw, rem = mc - b * hw;
+                const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+                int iy = 0, ix = 0;
+                const bool oky = src_coord(oy, tky, a.stride, a.pad, a.tmode, a.Hi, iy);
+                const bool okx = src_coord(ox, tkx, a.stride, a.pad, a.tmode, a.Wi, ix);
+                const bool ok = oky & okx;
+                mx |= (unsigned)(ok & (m < me)) << i;
+                X[i] = Io<T>::ld4(x + ((size_t)(b * a.Hi + (ok ? iy : 0)) * a.Wi + (ok ? ix : 0)) * a.ldx + ci0 + c4);
+            }
+#pragma unroll
+            for (int i = 0; i < NY; ++i) {
+                const int m = mb + tid / TPY + i * PPY;
+                my |= (unsigned)(ynok & (m < me)) << i;
+                Y[i] = Io<T>::ld4(dy + (size_t)min(m, me - 1) * a.lddy + (ynok ? yn0 : 0));
+            }
+        };
+        const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int last = ms < me ? ms + ((me - ms - 1) / 32) * 32 : ms;
+        auto work = [&](int mb, f32x4 (&X)[NX], f32x4 (&Y)[NY], unsigned& mx, unsigned& my) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i)
+                *reinterpret_cast<f32x4*>(&Xs[(tid / TPX + i * PPX) * LDX + (tid % TPX) * 4]) = ((mx >> i) & 1u) ? X[i] : zero;
+#pragma unroll
+            for (int i = 0; i < NY; ++i)
+                *reinterpret_cast<f32x4*>(&Ys[(tid / TPY + i * PPY) * LDY + (tid % TPY) * 4]) = ((my >> i) & 1u) ? Y[i] : zero;
+            __syncthreads();
+            load_u(min(mb + 64, last), X, Y, mx, my);   // past the end: a repeated, unused load instead of a branch
+            compute();
+            __syncthreads();
+        };
+        if (ms < me) {
+            load_u(ms, xn, yn, mxa, mya);
+            load_u(min(ms + 32, last), xb, yb, mxb, myb);
+        }
+        for (int mb = ms; mb < me; mb += 64) {
+            work(mb, xn, yn, mxa, mya);
+            if (mb + 32 < me) work(mb + 32, xb, yb, mxb, myb);
+        }
+    } else {
+        if (ms < me) load_stage(ms);
+        for (int mb = ms; mb < me; mb += 32) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) *reinterpret_cast<f32x4*>(&Xs[(tid / TPX + i * PPX) * LDX + (tid % TPX) * 4]) = xn[i];
+#pragma unroll
+            for (int i = 0; i < NY; ++i) *reinterpret_cast<f32x4*>(&Ys[(tid / TPY + i * PPY) * LDY + (tid % TPY) * 4]) = yn[i];
+            __syncthreads();
+            if (mb + 32 < me) load_stage(mb + 32);
+            compute();
+            __syncthreads();
+        }
     }
     if (ms >= me) return;
     if (do_bias && n0 + tid < a.N) unsafeAtomicAdd(a.dbias + n0 + tid, bsum);
@@ -956,16 +1013,17 @@ int launch_pgemm(const PGemmArgs& a, hipStream_t s) {
     return DMN_OK;
 }
 
-template <typename T, bool BF> static void wgemm_dispatch(const WGemmArgs& a, int M, int chunk, bool slow, int tm, int tn, dim3 grid, hipStream_t s) {
+template <typename T, bool BF, bool DEEP = false>
+static void wgemm_dispatch(const WGemmArgs& a, int M, int chunk, bool slow, int tm, int tn, dim3 grid, hipStream_t s) {
     if (slow) {
         if (tn == 64) wgemm_kernel<T, 32, 64, true, BF><<<grid, 256, 0, s>>>(a, M, chunk);
         else wgemm_kernel<T, 32, 32, true, BF><<<grid, 256, 0, s>>>(a, M, chunk);
     } else if (tm == 64) {
-        if (tn == 64) wgemm_kernel<T, 64, 64, false, BF><<<grid, 256, 0, s>>>(a, M, chunk);
-        else wgemm_kernel<T, 64, 32, false, BF><<<grid, 256, 0, s>>>(a, M, chunk);
+        if (tn == 64) wgemm_kernel<T, 64, 64, false, BF, DEEP><<<grid, 256, 0, s>>>(a, M, chunk);
+        else wgemm_kernel<T, 64, 32, false, BF, DEEP><<<grid, 256, 0, s>>>(a, M, chunk);
     } else {
-        if (tn == 64) wgemm_kernel<T, 32, 64, false, BF><<<grid, 256, 0, s>>>(a, M, chunk);
-        else wgemm_kernel<T, 32, 32, false, BF><<<grid, 256, 0, s>>>(a, M, chunk);
+        if (tn == 64) wgemm_kernel<T, 32, 64, false, BF, DEEP><<<grid, 256, 0, s>>>(a, M, chunk);
+        else wgemm_kernel<T, 32, 32, false, BF, DEEP><<<grid, 256, 0, s>>>(a, M, chunk);
     }
 }
 
@@ -1045,7 +1103,10 @@ int launch_wgemm(const WGemmArgs& a, hipStream_t s) {
     nsplit = (M + chunk - 1) / chunk;
     dim3 grid(nsplit, rt, ct);
     DMN_REQUIRE(rt <= 65535 && ct <= 65535, DMN_ERR_LIMIT, "wgemm: grid %d x %d", rt, ct);
-    if (a.adt == 1) wgemm_dispatch<__bf16, true>(a, M, chunk, slow, tm, tn, grid, s);
+    // bf16 activation storage: two stages in flight where every dy row can be fetched as whole vectors (see the kernel)
+    const bool deep = a.adt == 1 && !slow && (a.N & 3) == 0 && (a.lddy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.dy) & 15) == 0;
+    if (deep) wgemm_dispatch<__bf16, true, true>(a, M, chunk, slow, tm, tn, grid, s);
+    else if (a.adt == 1) wgemm_dispatch<__bf16, true>(a, M, chunk, slow, tm, tn, grid, s);
     else if (a.bf16) wgemm_dispatch<float, true>(a, M, chunk, slow, tm, tn, grid, s);
     else wgemm_dispatch<float, false>(a, M, chunk, slow, tm, tn, grid, s);
     DMN_LAUNCH_CHECK();
