@@ -1032,7 +1032,8 @@ static void wgemm_dispatch(const WGemmArgs& a, int M, int chunk, bool slow, int 
 // launches run beside the chain of pixel kernels and the step ends when the last of them does, so the step time follows
 // this number closely (measured, ms per step at 128 / 256 / 320 / 384 / 512 / 1024: fp32 activations 11.6 / 10.42 /
 // 10.44 / 10.46 / 10.75 / 11.8; bf16 activations, whose 8-byte loads leave a workgroup with half the bytes in flight,
-// 14.6 / 10.63 / 10.16 / 10.18 / 10.38 / 11.2).
+// 14.6 / 10.63 / 10.16 / 10.18 / 10.38 / 11.2 with one stage in flight; with two, as the kernels run now, 160 / 192 /
+// 224 / 256 / 288 / 448 / 512: 9.98 / 9.53 / 9.53 / 9.59 / 9.61 / 9.64 / 9.75).
 static int wgemm_wg_target(int adt) {
     static int v = -1;
     if (v < 0) {
@@ -1040,7 +1041,7 @@ static int wgemm_wg_target(int adt) {
         v = e ? atoi(e) : 0;
         if (v && v < 64) v = 64;
     }
-    return v ? v : (adt == 1 ? 352 : 256);
+    return v ? v : (adt == 1 ? 224 : 256);
 }
 // ... and for launches whose whole weight block is one or two tiles (the 32-channel layers at full resolution): every
 // split adds to the same one or two thousand addresses, and that contention costs more than the occupancy buys
