@@ -42,7 +42,7 @@ class UnetTrainer:
         accumulation). `activations` selects how the saved activations and their gradients are stored: 'fp32', or
         'bf16' (only with bf16 operands; halves the workspace and the step's memory traffic at a wider gradient error
         band; parameters, their gradients, statistics and the optimiser stay fp32). Default 'fp32', the parity mode; on one MI355X the bf16
-        storage moves 30 GB instead of 46 GB per step of 32 images at 128x128 and takes 10.0 ms instead of 10.2."""
+        storage moves 30 GB instead of 46 GB per step of 32 images at 128x128 and takes 9.5 ms instead of 10.1."""
         if loss_type not in LOSS_KINDS:
             raise ValueError("loss_type must be 'l1', 'l2' or 'huber'")
         if activations is None:
