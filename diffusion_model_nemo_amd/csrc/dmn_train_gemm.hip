@@ -1046,7 +1046,8 @@ static int wgemm_wg_target(int adt) {
 // ... and for launches whose whole weight block is one or two tiles (the 32-channel layers at full resolution): every
 // split adds to the same one or two thousand addresses, and that contention costs more than the occupancy buys
 // (measured, ms per step at 64 / 128 / 192 / 256 / 512 / 1024 / 4096 for these launches alone: fp32 activations 10.70 /
-// 10.41 / 10.38 / 10.43 / 10.61 / 11.03 / 12.9; bf16 activations - / 10.45 / 10.17 / 10.13 / 10.30 / 10.69 / 12.3).
+// 10.41 / 10.38 / 10.43 / 10.61 / 11.03 / 12.9; bf16 activations, two stages in flight, 128 / 192 / 256 / 320: 9.46 / 9.47 /
+// 9.51 / 9.54).
 static int wgemm_small_target(int adt, int tiles_kn) {
     static int v = -1;
     if (v < 0) {
@@ -1055,7 +1056,8 @@ static int wgemm_small_target(int adt, int tiles_kn) {
         if (v && v < 32) v = 32;
     }
     if (tiles_kn > 2) return wgemm_wg_target(adt);
-    return v ? v : (adt == 1 ? 256 : 192);
+    (void)adt;
+    return v ? v : 192;
 }
 
 // ... and for the element-wise gather path (the 3-channel ingest convolution): its output gradient is the last tensor
