@@ -211,7 +211,7 @@ def train_step_extra(dev, rank, world, dist, dry=False):
     dt = float(tt.item())
     other = None
     if dist is None and not dry:
-        # the same step with the saved activations STORED in bf16 (wider gradient band, see the training tests): reported
+        # the same step with the saved activations STORED in bf16 (same gradient band as fp32 storage in the training tests): reported
         # beside the default mode, single GPU only
         try:
             del step

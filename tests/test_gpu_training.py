@@ -132,12 +132,13 @@ def test_clip_and_adamw_match_torch_and_sampling_sees_the_update():
     assert float((got.cpu() - want).abs().max()) <= 5e-4
 
 
-@pytest.mark.parametrize("activations,rel_tol,cos_tol", [("fp32", 4e-2, 0.995), ("bf16", 1.5e-1, 0.97)])
+@pytest.mark.parametrize("activations,rel_tol,cos_tol", [("fp32", 4e-2, 0.995), ("bf16", 6e-2, 0.995)])
 def test_bf16_modes_stay_close_to_fp32_gradients(activations, rel_tol, cos_tol):
     """bf16 matrix-core operands (fp32 accumulate), with fp32 or bf16 STORAGE of the saved activations: loss within
     2e-3 / 1e-2 relative of the oracle and every gradient tensor within rel_tol of its largest entry with cosine
     similarity >= cos_tol (report-only bands in the spirit of the reference's own bf16-autocast deviation; the fp32
-    mode above is the parity mode)."""
+    mode above is the parity mode). Observed: 0.027 / 0.9999 with fp32 storage, 0.027 / 0.9998 with bf16 storage -- the
+    rounding of the operands dominates, the rounding of the stored activations adds little."""
     u, tr, sd = build(dtype="bf16", activations=activations)
     gen = torch.Generator().manual_seed(9)
     x0 = torch.tanh(torch.randn(2, 3, 32, 32, generator=gen))
@@ -155,6 +156,29 @@ def test_bf16_modes_stay_close_to_fp32_gradients(activations, rel_tol, cos_tol):
         worst_rel, worst_cos = max(worst_rel, rel), min(worst_cos, cos)
         assert rel <= rel_tol and cos >= cos_tol, (name, rel, cos)
     print("bf16 operands,", activations, "activations: worst relative error", worst_rel, "worst cosine", worst_cos)
+
+
+def test_bf16_storage_at_a_ragged_size_stays_in_its_band():
+    """Three 24x24 images: 1728 / 432 / 108 / 27 pixels per level, none a multiple of a 32-pixel stage and only the first
+    level a multiple of 8x8 tiles, so the weight-gradient kernels that keep two stages in flight for bf16 storage run
+    their clamped, masked loads on partial stages and padded taps. Observed: 0.038 of the largest entry, cosine 0.9997."""
+    u, tr, sd = build(dtype="bf16", activations="bf16")
+    gen = torch.Generator().manual_seed(21)
+    x0 = torch.tanh(torch.randn(3, 3, 24, 24, generator=gen))
+    noise = torch.randn(3, 3, 24, 24, generator=gen)
+    t = torch.tensor([40, 500, 900])
+    c = R.ddpm_constants(1000, "cosine")
+    val, ref = oracle_grads(sd, x0, t, noise)
+    got = tr.loss_and_grads(x0.cuda(), t.cuda(), noise.cuda(), c["sqrt_alphas_cumprod"], c["sqrt_one_minus_alphas_cumprod"])
+    assert abs(float(got) - val) <= 1e-2 * abs(val), (float(got), val)
+    worst_rel, worst_cos = 0.0, 1.0
+    for name, g in ref.items():
+        mine = tr.grad_of(name).cpu()
+        rel = float((mine - g).abs().max()) / (float(g.abs().max()) + 1e-30)
+        cos = float((mine * g).sum() / (mine.norm() * g.norm() + 1e-30))
+        worst_rel, worst_cos = max(worst_rel, rel), min(worst_cos, cos)
+        assert rel <= 8e-2 and cos >= 0.995, (name, rel, cos)
+    print("bf16 storage, 3 x 24x24: worst relative error", worst_rel, "worst cosine", worst_cos)
 
 
 def test_class_conditional_gradients_match_oracle_and_null_row_stays_frozen():
